@@ -1,0 +1,26 @@
+# Builds libtcow_hip.so (gfx950 only) and the oracle's C/CPU helpers.  `python __graft_entry__.py` calls this.
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH ?= gfx950
+CSRC := tcow_amd/csrc
+OBJ := build/obj
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wno-unused-result -ffp-contract=off
+SRCS := $(wildcard $(CSRC)/*.hip) $(wildcard $(CSRC)/*.cpp)
+OBJS := $(patsubst $(CSRC)/%,$(OBJ)/%.o,$(SRCS))
+LIB := tcow_amd/libtcow_hip.so
+
+all: $(LIB)
+
+$(OBJ)/%.hip.o: $(CSRC)/%.hip $(CSRC)/common.h include/tcow_hip.h
+	@mkdir -p $(OBJ)
+	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
+
+$(OBJ)/%.cpp.o: $(CSRC)/%.cpp $(CSRC)/common.h include/tcow_hip.h
+	@mkdir -p $(OBJ)
+	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
+
+$(LIB): $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+
+clean:
+	rm -rf build $(LIB)
+.PHONY: all clean

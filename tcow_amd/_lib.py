@@ -1,0 +1,66 @@
+"""ctypes binding of libtcow_hip.so (the C ABI declared in include/tcow_hip.h).
+
+The library is the product: if it is missing or fails to load, importing the kernels raises -- there is
+no PyTorch/CPU fallback on this path.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libtcow_hip.so')
+
+TCOW_F32, TCOW_BF16 = 0, 1
+ACT_NONE, ACT_GELU, ACT_DGELU = 0, 1, 2
+
+
+class TcowError(RuntimeError):
+    """Raised when a libtcow_hip entry point returns a non-zero status (message from tcow_last_error)."""
+
+
+class GemmArgs(ctypes.Structure):
+    _fields_ = [('M', ctypes.c_int), ('N', ctypes.c_int), ('K', ctypes.c_int), ('dtype', ctypes.c_int),
+                ('A', ctypes.c_void_p), ('lda', ctypes.c_long), ('W', ctypes.c_void_p), ('ldw', ctypes.c_long),
+                ('C', ctypes.c_void_p), ('ldc', ctypes.c_long), ('out_f32', ctypes.c_int),
+                ('bias', ctypes.c_void_p), ('row_scale', ctypes.c_void_p), ('resid', ctypes.c_void_p),
+                ('ldr', ctypes.c_long), ('act', ctypes.c_int), ('aux', ctypes.c_void_p), ('ldaux', ctypes.c_long)]
+
+
+_lib = None
+
+_vp, _i, _l = ctypes.c_void_p, ctypes.c_int, ctypes.c_long
+# name -> (restype, argtypes): every entry point declared in include/tcow_hip.h.  Explicit argtypes matter:
+# without them ctypes passes Python ints as 32-bit C ints and `long` strides arrive with garbage upper halves.
+SIGNATURES = {
+    'tcow_version': (_i, []),
+    'tcow_last_error': (ctypes.c_char_p, []),
+    'tcow_gemm_nt': (_i, [_vp, ctypes.POINTER(GemmArgs)]),
+    'tcow_gemm_tn_workspace_bytes': (_l, [_i, _i, _i]),
+    'tcow_gemm_tn': (_i, [_vp, _i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _vp, _i, _vp, _l]),
+}
+
+
+def _declare(L):
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(L, name)          # AttributeError here = header/library mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise TcowError(f'{LIB_PATH} not found: build it with `make` (or __graft_entry__.build()); '
+                            'the Seeker HIP path has no fallback')
+        L = ctypes.CDLL(LIB_PATH)
+        L.tcow_last_error.restype = ctypes.c_char_p
+        L.tcow_version.restype = ctypes.c_int
+        _declare(L)
+        _lib = L
+    return _lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        raise TcowError(f'{what} failed (status {rc}): {lib().tcow_last_error().decode()}')

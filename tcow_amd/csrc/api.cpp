@@ -1,0 +1,82 @@
+// C ABI glue of libtcow_hip.so: argument validation, dtype dispatch, thread-local error text.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void tcow_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int tcow_gemm_nt_bf16(hipStream_t stream, const tcow_gemm_args* a);
+int tcow_gemm_nt_f32(hipStream_t stream, const tcow_gemm_args* a);
+int tcow_gemm_tn_bf16(hipStream_t stream, int M, int N, int K, const bf16_t* dY, long ldy, const bf16_t* X, long ldx, float* slab, int splits, int* nz_out);
+int tcow_gemm_tn_f32(hipStream_t stream, int M, int N, int K, const float* dY, long ldy, const float* X, long ldx, float* dW, long lddw, int accumulate,
+                     float* slab, int splits);
+int tcow_tn_splits(int M, int N, int K, int tile_outputs);
+int tcow_launch_slab_reduce(hipStream_t stream, const float* slab, int nz, long rows, long cols, float* out, long ldo, int accumulate);
+int tcow_launch_colsum(hipStream_t stream, int dtype, const void* Y, long ldy, int M, int N, float* out, int accumulate, float* part, int max_parts);
+
+extern "C" {
+
+int tcow_version(void) { return 1; }
+const char* tcow_last_error(void) { return g_err; }
+
+int tcow_gemm_nt(void* stream, const tcow_gemm_args* a) {
+    TCOW_CHECK_ARG(a != nullptr, "tcow_gemm_nt: null args");
+    TCOW_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0, "tcow_gemm_nt: bad shape M=%d N=%d K=%d", a->M, a->N, a->K);
+    TCOW_CHECK_ARG(a->A && a->W && a->C, "tcow_gemm_nt: null operand");
+    TCOW_CHECK_ARG(a->act != TCOW_ACT_DGELU || a->aux, "tcow_gemm_nt: TCOW_ACT_DGELU needs aux");
+    if (a->dtype == TCOW_BF16) return tcow_gemm_nt_bf16((hipStream_t)stream, a);
+    if (a->dtype == TCOW_F32) {
+        TCOW_CHECK_ARG(a->out_f32 || true, "unreachable");
+        return tcow_gemm_nt_f32((hipStream_t)stream, a);
+    }
+    tcow_set_error("tcow_gemm_nt: unknown dtype %d", a->dtype);
+    return TCOW_ERR_INVALID_ARG;
+}
+
+static const int kColsumParts = 64;
+
+long tcow_gemm_tn_workspace_bytes(int M, int N, int K) {
+    const int s_bf = tcow_tn_splits(M, N, K, 128), s_f = tcow_tn_splits(M, N, K, 64);
+    const int s = s_bf > s_f ? s_bf : s_f;
+    return ((long)(s + 1) * N * K + (long)kColsumParts * N) * 4 + 256;
+}
+
+int tcow_gemm_tn(void* stream, int dtype, int M, int N, int K, const void* dY, long ldy, const void* X, long ldx, float* dW, long lddw,
+                 float* bias_grad, int accumulate, void* workspace, long workspace_bytes) {
+    TCOW_CHECK_ARG(M > 0 && N > 0 && K > 0 && dY && X && dW && workspace, "tcow_gemm_tn: bad arguments");
+    TCOW_CHECK_ARG(workspace_bytes >= tcow_gemm_tn_workspace_bytes(M, N, K), "tcow_gemm_tn: workspace too small (%ld < %ld)", workspace_bytes,
+                   tcow_gemm_tn_workspace_bytes(M, N, K));
+    float* slab = (float*)workspace;
+    int rc;
+    if (dtype == TCOW_BF16) {
+        const int splits = tcow_tn_splits(M, N, K, 128);
+        int nz = 0;
+        rc = tcow_gemm_tn_bf16((hipStream_t)stream, M, N, K, (const bf16_t*)dY, ldy, (const bf16_t*)X, ldx, slab, splits, &nz);
+        if (rc) return rc;
+        rc = tcow_launch_slab_reduce((hipStream_t)stream, slab, nz, N, K, dW, lddw, accumulate);
+        if (rc) return rc;
+    } else if (dtype == TCOW_F32) {
+        const int splits = tcow_tn_splits(M, N, K, 64);
+        rc = tcow_gemm_tn_f32((hipStream_t)stream, M, N, K, (const float*)dY, ldy, (const float*)X, ldx, dW, lddw, accumulate, slab, splits);
+        if (rc) return rc;
+    } else {
+        tcow_set_error("tcow_gemm_tn: unknown dtype %d", dtype);
+        return TCOW_ERR_INVALID_ARG;
+    }
+    if (bias_grad) {
+        float* part = slab + (size_t)(workspace_bytes / 4 - (long)kColsumParts * N - 8);
+        rc = tcow_launch_colsum((hipStream_t)stream, dtype, dY, ldy, M, N, bias_grad, accumulate, part, kColsumParts);
+        if (rc) return rc;
+    }
+    return TCOW_OK;
+}
+
+}  // extern "C"

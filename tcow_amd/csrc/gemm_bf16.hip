@@ -1,0 +1,358 @@
+// bf16 MFMA GEMMs for the Seeker hot path (gfx950).
+//
+//   gemm_nt_bf16 : C[M,N] = epi(A[M,K] . W[N,K]^T)  -- every nn.Linear forward and input-gradient on the path
+//                  (vit.py:50-61,74-76,111,146; mask_tracker.py:113) with bias / DropPath row-scale / GELU /
+//                  GELU' / residual fused in the epilogue.
+//   gemm_tn_bf16 : dW[N,K] += dY[M,N]^T . X[M,K]    -- weight gradients, token dimension split across
+//                  workgroups, operands transposed on the fly with ds_read_b64_tr_b16.
+//
+// Structure of gemm_nt (per 256-thread workgroup = 4 waves as 2x2):
+//   128x128 output tile, K walked in 64-element (128-byte) slices, two LDS stages filled with direct-to-LDS
+//   loads (global_load_lds_dwordx4, no VGPR round trip).  Each 16-byte chunk c of tile row r is stored at chunk
+//   position c ^ ((r>>1)&7) (applied on the per-lane SOURCE address, the LDS image of a wave-load stays
+//   lane-linear), which makes the ds_read_b128 fragment reads of the 32x32x16 MFMA conflict-free.  Accumulators
+//   are staged through LDS as f32 so that bias / residual loads and the C stores are full-row coalesced.
+//   blockIdx is remapped so that each XCD (private L2) owns a contiguous band of row tiles.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128;
+constexpr int BK = 64;                    // bf16 elements per k-slice (128 bytes per tile row)
+constexpr int TILE_BYTES = BM * 128;      // 16 KiB per operand per stage
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;
+constexpr int NT_LDS_BYTES = 2 * STAGE_BYTES;  // 64 KiB (also holds the 128x128 f32 epilogue tile)
+
+struct NtParams {
+    int M, N, K;
+    const bf16_t* A; long lda;
+    const bf16_t* W; long ldw;
+    void* C; long ldc; int out_f32;
+    const float* bias;
+    const float* row_scale;
+    const float* resid; long ldr;
+    int act;
+    bf16_t* aux; long ldaux;
+    int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    // Blocks are dispatched round-robin over the 8 XCDs; give each XCD a contiguous chunk of tile ids.
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, k = bid >> 3;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + k;
+}
+
+__device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((GLB_PTR(const uint32_t))gsrc, (LDS_PTR(uint32_t))lds_wave_base, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(NtParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    const int nblk = p.tiles_m * p.tiles_n;
+    const int pid = xcd_remap(blockIdx.x, nblk);
+    const int pm = pid / p.tiles_n, pn = pid - pm * p.tiles_n;
+    const int m0 = pm * BM, n0 = pn * BN;
+
+    // ---- per-lane source pointers for the direct-to-LDS loads: wave w issues wave-loads 4w..4w+3 per operand,
+    // each covering 8 tile rows x 128 B; lane -> (row r = 8*q + (lane>>3), LDS chunk position lane&7).
+    const bf16_t* a_src[4];
+    const bf16_t* w_src[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = (wave * 4 + j) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        int gm = m0 + r; gm = gm < p.M ? gm : p.M - 1;
+        int gn = n0 + r; gn = gn < p.N ? gn : p.N - 1;
+        a_src[j] = p.A + (size_t)gm * p.lda + c * 8;
+        w_src[j] = p.W + (size_t)gn * p.ldw + c * 8;
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = p.K / BK;
+    auto issue = [&](int kt, int stage) {
+        char* sa = smem + stage * STAGE_BYTES;
+        char* sw = sa + TILE_BYTES;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            glds16(a_src[j] + (size_t)kt * BK, sa + (wave * 4 + j) * 1024);
+            glds16(w_src[j] + (size_t)kt * BK, sw + (wave * 4 + j) * 1024);
+        }
+    };
+
+    // fragment byte offsets inside a tile (row-dependent part), constant over k
+    int a_off[2], w_off[2], a_sw[2], w_sw[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int ra = wm * 64 + i * 32 + l31, rw = wn * 64 + i * 32 + l31;
+        a_off[i] = ra * 128; a_sw[i] = (ra >> 1) & 7;
+        w_off[i] = rw * 128; w_sw[i] = (rw >> 1) & 7;
+    }
+
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int stage = kt & 1;
+        if (kt + 1 < nk) issue(kt + 1, stage ^ 1);
+        const char* sa = smem + stage * STAGE_BYTES;
+        const char* sw = sa + TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int c = 2 * ks + hi;
+            bf16x8 fa[2], fw[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                fa[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sa + a_off[i] + ((c ^ a_sw[i]) << 4)));
+                fw[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sw + w_off[i] + ((c ^ w_sw[i]) << 4)));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fw[j], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---- epilogue: accumulators -> LDS (f32 [128][128]) -> coalesced row-wise stores
+    float* ct = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * 64 + i * 32 + crow32(r, hi);
+                const int col = wn * 64 + j * 32 + l31;
+                ct[row * BN + col] = acc[i][j][r];
+            }
+    __syncthreads();
+
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+        const int idx = it * 256 + tid;
+        const int row = idx >> 5, c4 = (idx & 31) * 4;
+        const int gm = m0 + row, gn = n0 + c4;
+        if (gm >= p.M || gn >= p.N) continue;
+        float4 v = *reinterpret_cast<const float4*>(ct + row * BN + c4);
+        float vv[4] = {v.x, v.y, v.z, v.w};
+        const int nv = (p.N - gn) < 4 ? (p.N - gn) : 4;
+        const float rs = p.row_scale ? p.row_scale[gm] : 1.0f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (e < nv) {
+                float x = vv[e];
+                if (p.bias) x += p.bias[gn + e];
+                x *= rs;
+                if (p.act == TCOW_ACT_GELU) {
+                    if (p.aux) p.aux[(size_t)gm * p.ldaux + gn + e] = f2bf(x);
+                    x = gelu_erf(x);
+                } else if (p.act == TCOW_ACT_DGELU) {
+                    x *= gelu_erf_grad(bf2f(p.aux[(size_t)gm * p.ldaux + gn + e]));
+                }
+                if (p.resid) x += p.resid[(size_t)gm * p.ldr + gn + e];
+                vv[e] = x;
+            }
+        }
+        if (nv == 4) {
+            if (p.out_f32) st4(reinterpret_cast<float*>(p.C) + (size_t)gm * p.ldc + gn, make_float4(vv[0], vv[1], vv[2], vv[3]));
+            else st4(reinterpret_cast<bf16_t*>(p.C) + (size_t)gm * p.ldc + gn, make_float4(vv[0], vv[1], vv[2], vv[3]));
+        } else {
+            for (int e = 0; e < nv; ++e) {
+                if (p.out_f32) reinterpret_cast<float*>(p.C)[(size_t)gm * p.ldc + gn + e] = vv[e];
+                else reinterpret_cast<bf16_t*>(p.C)[(size_t)gm * p.ldc + gn + e] = f2bf(vv[e]);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+int tcow_gemm_nt_bf16(hipStream_t stream, const tcow_gemm_args* a) {
+    TCOW_CHECK_ARG(a->K % BK == 0, "tcow_gemm_nt(bf16): K=%d must be a multiple of %d", a->K, BK);
+    TCOW_CHECK_ARG(a->lda % 8 == 0 && a->ldw % 8 == 0, "tcow_gemm_nt(bf16): lda/ldw must be multiples of 8 elements");
+    TCOW_CHECK_ARG(a->ldc % 4 == 0, "tcow_gemm_nt(bf16): ldc must be a multiple of 4");
+    NtParams p;
+    p.M = a->M; p.N = a->N; p.K = a->K;
+    p.A = (const bf16_t*)a->A; p.lda = a->lda; p.W = (const bf16_t*)a->W; p.ldw = a->ldw;
+    p.C = a->C; p.ldc = a->ldc; p.out_f32 = a->out_f32; p.bias = a->bias; p.row_scale = a->row_scale;
+    p.resid = a->resid; p.ldr = a->ldr; p.act = a->act; p.aux = (bf16_t*)a->aux; p.ldaux = a->ldaux;
+    p.tiles_m = cdiv(a->M, BM); p.tiles_n = cdiv(a->N, BN);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_nt_bf16_kernel, dim3(p.tiles_m * p.tiles_n), dim3(256), NT_LDS_BYTES, stream, p);
+    TCOW_CHECK_LAUNCH();
+    return TCOW_OK;
+}
+
+// =====================================================================================================
+// Weight-gradient GEMM: slab[z][N][K] = sum over token rows of slice z of dY[m][n] * X[m][k].
+// Both operands have the contraction index (token row m) as their slow dimension, so the MFMA fragments
+// (8 consecutive m for one column) are gathered with the LDS transpose read ds_read_b64_tr_b16:
+// within a 16-lane group lane 4r+c supplies the address of row r / 4-element column quad c of a [4][16]
+// block and receives column (lane&15), rows 0..3 (verified on hardware, profiles/r01_hw_probe.txt).
+// LDS rows are 256 B (128 columns); 16-byte chunk c of row r sits at chunk position c ^ ((r&3)<<2) so the four
+// rows a half-wave touches per read fall into four different 64-byte bank segments.
+namespace {
+
+constexpr int TN_T = 128;                 // output tile edge (n and k)
+constexpr int TN_MC = 64;                 // token rows per LDS stage
+constexpr int TN_TILE_BYTES = TN_MC * 256;
+constexpr int TN_STAGE_BYTES = 2 * TN_TILE_BYTES;
+constexpr int TN_LDS_BYTES = 2 * TN_STAGE_BYTES;
+
+__device__ uint4 g_zero16 = {0u, 0u, 0u, 0u};
+
+struct TnParams {
+    int M, N, K;
+    const bf16_t* dY; long ldy;
+    const bf16_t* X; long ldx;
+    float* slab;
+    int tiles_n, tiles_k, mps;   // mps: token rows per slice (multiple of TN_MC)
+};
+
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int off0) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(tile + off0));
+    const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(tile + off0 + 4 * 256));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 v = __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(TnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int pn = blockIdx.x / p.tiles_k, pk = blockIdx.x - pn * p.tiles_k;
+    const int n0 = pn * TN_T, k0 = pk * TN_T;
+    const int mbeg = blockIdx.y * p.mps;
+    const int mend = (mbeg + p.mps < p.M) ? mbeg + p.mps : p.M;
+
+    // direct-to-LDS loads: wave-load q (16 per operand per stage) covers tile rows 4q..4q+3 x 256 B.
+    const int lrow = lane >> 4;
+    const int schunk = (lane & 15) ^ (lrow << 2);
+    int ncol = n0 + schunk * 8; const bool n_ok = ncol < p.N;     // N, K multiples of 8 -> whole chunk in or out
+    int kcol = k0 + schunk * 8; const bool k_ok = kcol < p.K;
+    const bf16_t* zero = reinterpret_cast<const bf16_t*>(&g_zero16);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto issue = [&](int mt, int stage) {
+        char* sy = smem + stage * TN_STAGE_BYTES;
+        char* sx = sy + TN_TILE_BYTES;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = wave * 4 + j;
+            const int gm = mt + q * 4 + lrow;
+            const bool ok = gm < mend;
+            const bf16_t* ys = (ok && n_ok) ? p.dY + (size_t)gm * p.ldy + ncol : zero;
+            const bf16_t* xs = (ok && k_ok) ? p.X + (size_t)gm * p.ldx + kcol : zero;
+            glds16(ys, sy + q * 1024);
+            glds16(xs, sx + q * 1024);
+        }
+    };
+
+    // transpose-read addressing (constant over the loop)
+    const int q16 = lane & 15, g16 = (lane >> 4) & 1, hi = lane >> 5;
+    int y_off[2], x_off[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int cy = wm * 64 + i * 32 + 16 * g16 + 4 * (q16 & 3);
+        const int cx = wn * 64 + i * 32 + 16 * g16 + 4 * (q16 & 3);
+        const int rr = 8 * hi + (q16 >> 2);
+        y_off[i] = rr * 256 + ((((cy >> 3) ^ ((q16 >> 2) << 2))) << 4) + (cy & 7) * 2;
+        x_off[i] = rr * 256 + ((((cx >> 3) ^ ((q16 >> 2) << 2))) << 4) + (cx & 7) * 2;
+    }
+
+    const int nmt = (mend - mbeg + TN_MC - 1) / TN_MC;
+    if (nmt > 0) {
+        issue(mbeg, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    for (int it = 0; it < nmt; ++it) {
+        const int stage = it & 1;
+        if (it + 1 < nmt) issue(mbeg + (it + 1) * TN_MC, stage ^ 1);
+        const char* sy = smem + stage * TN_STAGE_BYTES;
+        const char* sx = sy + TN_TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 fy[2], fx[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                fy[i] = tr_frag(sy, y_off[i] + ks * 16 * 256);
+                fx[i] = tr_frag(sx, x_off[i] + ks * 16 * 256);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fy[i], fx[j], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    float* out = p.slab + (size_t)blockIdx.y * p.N * p.K;
+    const int l31 = lane & 31;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int gk = k0 + wn * 64 + j * 32 + l31;
+            if (gk >= p.K) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int gn = n0 + wm * 64 + i * 32 + crow32(r, hi);
+                if (gn < p.N) out[(size_t)gn * p.K + gk] = acc[i][j][r];
+            }
+        }
+}
+
+}  // namespace
+
+int tcow_gemm_tn_bf16(hipStream_t stream, int M, int N, int K, const bf16_t* dY, long ldy, const bf16_t* X, long ldx, float* slab, int splits,
+                      int* nz_out) {
+    TCOW_CHECK_ARG(N % 8 == 0 && K % 8 == 0 && ldy % 8 == 0 && ldx % 8 == 0, "tcow_gemm_tn(bf16): N, K, ldy, ldx must be multiples of 8");
+    TnParams p;
+    p.M = M; p.N = N; p.K = K; p.dY = dY; p.ldy = ldy; p.X = X; p.ldx = ldx; p.slab = slab;
+    p.tiles_n = cdiv(N, TN_T); p.tiles_k = cdiv(K, TN_T);
+    int mps = cdiv(M, splits); mps = ((mps + TN_MC - 1) / TN_MC) * TN_MC;
+    p.mps = mps;
+    const int nz = cdiv(M, mps);
+    *nz_out = nz;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3(p.tiles_n * p.tiles_k, nz), dim3(256), TN_LDS_BYTES, stream, p);
+    TCOW_CHECK_LAUNCH();
+    return TCOW_OK;
+}

@@ -1,0 +1,196 @@
+// Exact-f32 GEMMs (parity mode) on the f32-input MFMA (v_mfma_f32_32x32x2_f32: bitwise an fmaf chain).
+// One stride-generic kernel serves the NT form (forward / input-gradient) and the TN form (weight gradient):
+//   C[i,j] = sum_k A(i,k) * B(j,k),  A(i,k) = A[i*sai + k*sak],  B(j,k) = B[j*sbj + k*sbk].
+// 64x64 tile per 256-thread workgroup (4 waves, one 32x32 MFMA tile each), k walked 16 at a time through LDS
+// stored k-major so that fragment reads are conflict-free ds_read_b32.  Speed is secondary here: this path
+// exists so that the HIP pipeline can be compared with the fp32 reference below 1e-3.
+#include "common.h"
+
+namespace {
+
+constexpr int FT = 64;   // tile edge
+constexpr int FK = 16;   // k-slice
+constexpr int FLD = FT + 4;
+
+struct F32Params {
+    int M, N, K;
+    const float* A; long sai, sak;
+    const float* B; long sbj, sbk;
+    void* C; long ldc;
+    const float* bias; const float* row_scale; const float* resid; long ldr;
+    int act; float* aux; long ldaux;
+    int kps;          // contraction elements per z-slice (multiple of FK)
+    float* slab;      // if non-NULL: raw partial sums to slab[z][M][N], no epilogue
+};
+
+__device__ __forceinline__ void load_tile(const float* __restrict__ P, long s_row, long s_k, int row0, int nrows, int k0, int kend,
+                                          float (*dst)[FLD], int tid) {
+    // 64 rows x 16 k = 1024 elements, 4 per thread, vectorised along whichever index is contiguous.
+    if (s_k == 1) {
+        const int r = tid >> 2, kk = (tid & 3) * 4;
+        const int gr = row0 + r;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (gr < nrows) {
+            const float* src = P + (size_t)gr * s_row + k0 + kk;
+            if (k0 + kk + 3 < kend && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
+                float4 t = *reinterpret_cast<const float4*>(src); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+            } else {
+                for (int e = 0; e < 4; ++e) if (k0 + kk + e < kend) v[e] = src[e];
+            }
+        }
+        for (int e = 0; e < 4; ++e) dst[kk + e][r] = v[e];
+    } else {
+        const int kk = tid >> 4, r = (tid & 15) * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (k0 + kk < kend) {
+            const float* src = P + (size_t)(k0 + kk) * s_k;
+            if (s_row == 1 && row0 + r + 3 < nrows && ((reinterpret_cast<uintptr_t>(src + row0 + r) & 15) == 0)) {
+                float4 t = *reinterpret_cast<const float4*>(src + row0 + r); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+            } else {
+                for (int e = 0; e < 4; ++e) if (row0 + r + e < nrows) v[e] = src[(size_t)(row0 + r + e) * s_row];
+            }
+        }
+        *reinterpret_cast<float4*>(&dst[kk][r]) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void gemm_f32_kernel(F32Params p) {
+    __shared__ __attribute__((aligned(16))) float As[FK][FLD];
+    __shared__ __attribute__((aligned(16))) float Bs[FK][FLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, hi = lane >> 5;
+    const int m0 = blockIdx.y * FT, n0 = blockIdx.x * FT;
+    const int kbeg = blockIdx.z * p.kps;
+    const int kend = (kbeg + p.kps < p.K) ? kbeg + p.kps : p.K;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int k0 = kbeg; k0 < kend; k0 += FK) {
+        load_tile(p.A, p.sai, p.sak, m0, p.M, k0, kend, As, tid);
+        load_tile(p.B, p.sbj, p.sbk, n0, p.N, k0, kend, Bs, tid);
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < FK / 2; ++s) {
+            const float a = As[2 * s + hi][wm * 32 + l31];
+            const float b = Bs[2 * s + hi][wn * 32 + l31];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    const int gn = n0 + wn * 32 + l31;
+    if (gn >= p.N) return;
+    if (p.slab) {
+        float* out = p.slab + (size_t)blockIdx.z * p.M * p.N;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int gm = m0 + wm * 32 + crow32(r, hi);
+            if (gm < p.M) out[(size_t)gm * p.N + gn] = acc[r];
+        }
+        return;
+    }
+    const float bv = p.bias ? p.bias[gn] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int gm = m0 + wm * 32 + crow32(r, hi);
+        if (gm >= p.M) continue;
+        float x = acc[r] + bv;
+        if (p.row_scale) x *= p.row_scale[gm];
+        if (p.act == TCOW_ACT_GELU) {
+            if (p.aux) p.aux[(size_t)gm * p.ldaux + gn] = x;
+            x = gelu_erf(x);
+        } else if (p.act == TCOW_ACT_DGELU) {
+            x *= gelu_erf_grad(p.aux[(size_t)gm * p.ldaux + gn]);
+        }
+        if (p.resid) x += p.resid[(size_t)gm * p.ldr + gn];
+        reinterpret_cast<float*>(p.C)[(size_t)gm * p.ldc + gn] = x;
+    }
+}
+
+// out[i] (+)= sum_z slab[z][i]   and optional column sums for the bias gradient are handled elsewhere
+__global__ void slab_reduce_kernel(const float* __restrict__ slab, int nz, long n, float* __restrict__ out, long rows, long cols, long ldo, int accumulate) {
+    long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        float s = 0.f;
+        for (int z = 0; z < nz; ++z) s += slab[(size_t)z * n + i];
+        const long r = i / cols, c = i - r * cols;
+        float* o = out + r * ldo + c;
+        *o = accumulate ? (*o + s) : s;
+    }
+}
+
+// column sums of Y[M,N] (bias gradient): one workgroup per 64 columns x row-slice, two-stage through a slab
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ Y, long ldy, int M, int N, int rows_per_blk, float* __restrict__ part) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int w = threadIdx.x >> 6;
+    const int r0 = blockIdx.y * rows_per_blk;
+    const int r1 = (r0 + rows_per_blk < M) ? r0 + rows_per_blk : M;
+    float s = 0.f;
+    if (c < N)
+        for (int r = r0 + w; r < r1; r += 4) s += Elem<T>::ld(Y + (size_t)r * ldy + c);
+    red[w][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (w == 0 && c < N) part[(size_t)blockIdx.y * N + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+}  // namespace
+
+int tcow_gemm_nt_f32(hipStream_t stream, const tcow_gemm_args* a) {
+    F32Params p;
+    p.M = a->M; p.N = a->N; p.K = a->K;
+    p.A = (const float*)a->A; p.sai = a->lda; p.sak = 1;
+    p.B = (const float*)a->W; p.sbj = a->ldw; p.sbk = 1;
+    p.C = a->C; p.ldc = a->ldc; p.bias = a->bias; p.row_scale = a->row_scale; p.resid = a->resid; p.ldr = a->ldr;
+    p.act = a->act; p.aux = (float*)a->aux; p.ldaux = a->ldaux; p.kps = ((a->K + FK - 1) / FK) * FK; p.slab = nullptr;
+    hipLaunchKernelGGL(gemm_f32_kernel, dim3(cdiv(a->N, FT), cdiv(a->M, FT), 1), dim3(256), 0, stream, p);
+    TCOW_CHECK_LAUNCH();
+    return TCOW_OK;
+}
+
+// number of token-dimension slices used by the weight-gradient GEMMs (both dtypes)
+int tcow_tn_splits(int M, int N, int K, int tile_outputs) {
+    const int tiles = cdiv(N, tile_outputs) * cdiv(K, tile_outputs);
+    int s = cdiv(1024, tiles);                 // aim for ~4 workgroups per CU
+    const int max_s = cdiv(M, 512);            // at least 512 tokens per slice
+    if (s > max_s) s = max_s;
+    if (s < 1) s = 1;
+    if (s > 64) s = 64;
+    return s;
+}
+
+int tcow_launch_slab_reduce(hipStream_t stream, const float* slab, int nz, long rows, long cols, float* out, long ldo, int accumulate) {
+    const long n = rows * cols;
+    int blocks = cdiv(n, 256); if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, stream, slab, nz, n, out, rows, cols, ldo, accumulate);
+    TCOW_CHECK_LAUNCH();
+    return TCOW_OK;
+}
+
+int tcow_launch_colsum(hipStream_t stream, int dtype, const void* Y, long ldy, int M, int N, float* out, int accumulate, float* part, int max_parts) {
+    int parts = cdiv(M, 256); if (parts > max_parts) parts = max_parts; if (parts < 1) parts = 1;
+    const int rpb = cdiv(M, parts);
+    parts = cdiv(M, rpb);
+    if (dtype == TCOW_BF16)
+        hipLaunchKernelGGL(colsum_partial_kernel<bf16_t>, dim3(cdiv(N, 64), parts), dim3(256), 0, stream, (const bf16_t*)Y, ldy, M, N, rpb, part);
+    else
+        hipLaunchKernelGGL(colsum_partial_kernel<float>, dim3(cdiv(N, 64), parts), dim3(256), 0, stream, (const float*)Y, ldy, M, N, rpb, part);
+    TCOW_CHECK_LAUNCH();
+    return tcow_launch_slab_reduce(stream, part, parts, 1, N, out, N, accumulate);
+}
+
+int tcow_gemm_tn_f32(hipStream_t stream, int M, int N, int K, const float* dY, long ldy, const float* X, long ldx, float* dW, long lddw,
+                     int accumulate, float* slab, int splits) {
+    F32Params p;
+    p.M = N; p.N = K; p.K = M;                       // output [N,K], contraction over tokens
+    p.A = dY; p.sai = 1; p.sak = ldy;
+    p.B = X; p.sbj = 1; p.sbk = ldx;
+    p.C = nullptr; p.ldc = 0; p.bias = nullptr; p.row_scale = nullptr; p.resid = nullptr; p.ldr = 0; p.act = 0; p.aux = nullptr; p.ldaux = 0;
+    int kps = cdiv(M, splits); kps = ((kps + FK - 1) / FK) * FK;
+    const int nz = cdiv(M, kps);
+    p.kps = kps; p.slab = slab;
+    hipLaunchKernelGGL(gemm_f32_kernel, dim3(cdiv(K, FT), cdiv(N, FT), nz), dim3(256), 0, stream, p);
+    TCOW_CHECK_LAUNCH();
+    return tcow_launch_slab_reduce(stream, slab, nz, N, K, dW, lddw, accumulate);
+}
