@@ -85,6 +85,90 @@ int tcow_gemm_tn(void* stream, int dtype, int M, int N, int K, const void* dY, l
                  long ldx, float* dW, long lddw, float* bias_grad, int accumulate, void* workspace,
                  long workspace_bytes);
 
+/* ------------------------------------------------------------------------------------------- LayerNorm
+ * y = (x - mean) / sqrt(var + eps) * gamma + beta over the last dimension of the f32 residual stream
+ * (nn.LayerNorm(D, eps=1e-6): vit.py:135 norm1, :142 temporal_norm1, :150 norm2, :283 norm; eps vit.py:428).
+ * y has `dtype` elements; mean / rstd (f32 [rows], may be NULL in inference) are saved for the backward.
+ * Backward: dx = dres + dLN(dy) (dres = gradient arriving through the residual connection, may be NULL),
+ * dgamma / dbeta (+)= column sums (both NULL to skip; otherwise workspace of tcow_layernorm_bwd_workspace_bytes). */
+int tcow_layernorm_fwd(void* stream, int dtype, int rows, int D, const float* x, long ldx, const float* gamma,
+                       const float* beta, float eps, void* y, long ldy, float* mean, float* rstd);
+long tcow_layernorm_bwd_workspace_bytes(int D);
+int tcow_layernorm_bwd(void* stream, int dtype, int rows, int D, const void* dy, long lddy, const float* x, long ldx,
+                       const float* mean, const float* rstd, const float* gamma, const float* dres, long lddres,
+                       float* dx, long lddx, float* dgamma, float* dbeta, int accumulate, void* workspace,
+                       long workspace_bytes);
+
+/* ------------------------------------------------------------------------------------------- attention
+ * softmax(q k^T / 8 [mask]) v per head (head_dim 64) straight on the qkv GEMM output [rows, 3D]
+ * (column order which*D + head*64 + j, vit.py:81-83) -> out [rows, D] (head*64 + j, vit.py:109).
+ *   temporal: one sequence of T frames per (clip b, slot s >= 1, head) -- Block.forward vit.py:169-172 with the
+ *             causal mask of Attention.forward vit.py:93-99: causal in {1,2}: key_t <= query_t; causal >= 3:
+ *             key_t <= query_t + causal - 2; causal <= 0: none.  Rows of slot 0 are written as zeros.
+ *   spatial : one sequence per (clip, frame, head) over slots 0..S-1 when causal in {0,1} (cls takes part,
+ *             vit.py:180-186) or 1..S-1 otherwise (vit.py:202-208; slot-0 rows written as zeros).  No mask.
+ * lse: f32 [rows, heads] log-sum-exp of the scaled scores (NULL in inference), consumed by the backward, which
+ * recomputes the probabilities instead of storing the (T,T) / (S,S) score matrices the reference materialises.
+ * Backward writes dqkv [rows, 3D] (rows of unused slots zeroed). workspace: tcow_attn_bwd_workspace_bytes. */
+typedef struct {
+    int B, T, S;        /* clips, frames, slots per frame (patches + 1) */
+    int D, heads;       /* D == heads * 64 */
+    int causal;         /* the reference's causal_attention value */
+    int dtype;
+} tcow_attn_shape;
+int tcow_attn_temporal_fwd(void* stream, const tcow_attn_shape* shape, const void* qkv, void* out, float* lse);
+int tcow_attn_spatial_fwd(void* stream, const tcow_attn_shape* shape, const void* qkv, void* out, float* lse);
+long tcow_attn_bwd_workspace_bytes(const tcow_attn_shape* shape);
+int tcow_attn_temporal_bwd(void* stream, const tcow_attn_shape* shape, const void* qkv, const void* out,
+                           const void* dout, const float* lse, void* dqkv, void* workspace, long workspace_bytes);
+int tcow_attn_spatial_bwd(void* stream, const tcow_attn_shape* shape, const void* qkv, const void* out,
+                          const void* dout, const float* lse, void* dqkv, void* workspace, long workspace_bytes);
+
+/* ------------------------------------------------------------------------------------------- token glue
+ * tcow_im2col: cat([rgb (B,3,T,H,W), query (B,1,T,H,W)]) (mask_tracker.py:107-108), optional (rgb-0.45)/0.225
+ *   (vision_tf.py:81-89), flattened per patch in Conv2d weight order c*P*P + py*P + px (vit.py:233-240) into
+ *   rows (b,t,1+n); slot-0 rows are zeros.  out: `dtype` [B*T*S, 4*P*P].
+ * tcow_embed_fwd: in place on the f32 patch-embed output: slot 0 <- cls_token + pos_embed[0]; slot s >= 1 <-
+ *   x + pos_embed[s] + time_embed[t] (vision_tf.py:99-138; dropouts are p = 0).  pos [S,D], time [T,D].
+ * tcow_embed_bwd: dpos[s] (+)= sum_{b,t} g[b,t,s];  dtime[t] (+)= sum_{b,s>=1} g[b,t,s]
+ *   (d cls_token = dpos[0]; d patch_embed.bias = sum_t dtime[t]).
+ * tcow_cls_merge: after the spatial projection, make every frame's slot 0 equal to the clip's single cls token:
+ *   mode 1 = frame 0's row (causal_attention == 1), mode 0 = mean over frames (== 0) (vit.py:189-198,215).
+ *   backward != 0 applies the adjoint to a gradient buffer in place. */
+int tcow_im2col(void* stream, int dtype, int B, int T, int H, int W, int P, const float* rgb, const float* query,
+                int pretrained_norm, void* out);
+int tcow_embed_fwd(void* stream, int B, int T, int S, int D, float* x, const float* cls, const float* pos,
+                   const float* time_embed);
+int tcow_embed_bwd(void* stream, int B, int T, int S, int D, const float* g, float* dpos, float* dtime,
+                   int accumulate);
+int tcow_cls_merge(void* stream, int B, int T, int S, int D, float* x, int mode, int backward);
+
+/* ------------------------------------------------------------------------------------------- mask head
+ * tcow_unpatchify_pool_fwd: head output pm [B*T*S, C*P*P] (`dtype`, (c,py,px) order, mask_tracker.py:113-115)
+ *   -> pooled f32 [B*T, C, H/st, W/st] = avg_pool2d(st) of the un-patchified frame (mask_tracker.py:118-122).
+ * tcow_upsample_fwd: pooled -> out f32 (B, C, T, H, W): bilinear (align_corners=True) or nearest x st
+ *   (mask_tracker.py:124-132).  h, w are the pooled sizes.
+ * tcow_flags_fwd: flags[bt, f] = Wf . mean_{s>=1} x[bt, s] + bf  (mask_tracker.py:135-137), x f32 [B*T*S, D]. */
+int tcow_unpatchify_pool_fwd(void* stream, int dtype, int BT, int Hp, int Wp, int P, int C, int st, const void* pm,
+                             float* pooled);
+int tcow_unpatchify_pool_bwd(void* stream, int dtype, int BT, int Hp, int Wp, int P, int C, int st,
+                             const float* dpooled, void* dpm);
+int tcow_upsample_fwd(void* stream, int B, int T, int C, int h, int w, int st, int bilinear, const float* pooled,
+                      float* out);
+int tcow_upsample_bwd(void* stream, int B, int T, int C, int h, int w, int st, int bilinear, const float* dout,
+                      float* dpooled);
+int tcow_flags_fwd(void* stream, int BT, int S, int D, int F, const float* x, const float* Wf, const float* bf,
+                   float* flags);
+
+/* ------------------------------------------------------------------------------------------- casts
+ * tcow_scale_cast: dst[r,:] = dtype(src[r,:] * row_scale[r]) (row_scale may be NULL): f32 residual-stream
+ *   values / gradients -> GEMM operands (fuses the DropPath scale, vit_utils.py:139-154, in the backward).
+ * tcow_cast_transpose: W f32 [N,K] -> Wc `dtype` [N,K] and/or Wt `dtype` [K,N] (either may be NULL): the
+ *   per-step operand copies of the f32 master weights (Wt feeds the input-gradient GEMMs). */
+int tcow_scale_cast(void* stream, int dtype, long rows, int D, const float* src, long ld_src, const float* row_scale,
+                    void* dst, long ld_dst);
+int tcow_cast_transpose(void* stream, int dtype, int N, int K, const float* W, void* Wc, void* Wt);
+
 #ifdef __cplusplus
 }
 #endif

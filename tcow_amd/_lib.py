@@ -17,6 +17,11 @@ class TcowError(RuntimeError):
     """Raised when a libtcow_hip entry point returns a non-zero status (message from tcow_last_error)."""
 
 
+class AttnShape(ctypes.Structure):
+    _fields_ = [('B', ctypes.c_int), ('T', ctypes.c_int), ('S', ctypes.c_int), ('D', ctypes.c_int),
+                ('heads', ctypes.c_int), ('causal', ctypes.c_int), ('dtype', ctypes.c_int)]
+
+
 class GemmArgs(ctypes.Structure):
     _fields_ = [('M', ctypes.c_int), ('N', ctypes.c_int), ('K', ctypes.c_int), ('dtype', ctypes.c_int),
                 ('A', ctypes.c_void_p), ('lda', ctypes.c_long), ('W', ctypes.c_void_p), ('ldw', ctypes.c_long),
@@ -27,7 +32,8 @@ class GemmArgs(ctypes.Structure):
 
 _lib = None
 
-_vp, _i, _l = ctypes.c_void_p, ctypes.c_int, ctypes.c_long
+_vp, _i, _l, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
+_ash = ctypes.POINTER(AttnShape)
 # name -> (restype, argtypes): every entry point declared in include/tcow_hip.h.  Explicit argtypes matter:
 # without them ctypes passes Python ints as 32-bit C ints and `long` strides arrive with garbage upper halves.
 SIGNATURES = {
@@ -36,6 +42,25 @@ SIGNATURES = {
     'tcow_gemm_nt': (_i, [_vp, ctypes.POINTER(GemmArgs)]),
     'tcow_gemm_tn_workspace_bytes': (_l, [_i, _i, _i]),
     'tcow_gemm_tn': (_i, [_vp, _i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _vp, _i, _vp, _l]),
+    'tcow_layernorm_fwd': (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _vp, _f, _vp, _l, _vp, _vp]),
+    'tcow_layernorm_bwd_workspace_bytes': (_l, [_i]),
+    'tcow_layernorm_bwd': (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _l, _vp, _vp, _vp, _vp, _l, _vp, _l, _vp, _vp, _i, _vp, _l]),
+    'tcow_attn_temporal_fwd': (_i, [_vp, _ash, _vp, _vp, _vp]),
+    'tcow_attn_spatial_fwd': (_i, [_vp, _ash, _vp, _vp, _vp]),
+    'tcow_attn_bwd_workspace_bytes': (_l, [_ash]),
+    'tcow_attn_temporal_bwd': (_i, [_vp, _ash, _vp, _vp, _vp, _vp, _vp, _vp, _l]),
+    'tcow_attn_spatial_bwd': (_i, [_vp, _ash, _vp, _vp, _vp, _vp, _vp, _vp, _l]),
+    'tcow_im2col': (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
+    'tcow_embed_fwd': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    'tcow_embed_bwd': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _i]),
+    'tcow_cls_merge': (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i]),
+    'tcow_unpatchify_pool_fwd': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    'tcow_unpatchify_pool_bwd': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    'tcow_upsample_fwd': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    'tcow_upsample_bwd': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    'tcow_flags_fwd': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    'tcow_scale_cast': (_i, [_vp, _i, _l, _i, _vp, _l, _vp, _vp, _l]),
+    'tcow_cast_transpose': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
 }
 
 

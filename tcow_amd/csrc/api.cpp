@@ -19,7 +19,7 @@ int tcow_gemm_tn_bf16(hipStream_t stream, int M, int N, int K, const bf16_t* dY,
 int tcow_gemm_tn_f32(hipStream_t stream, int M, int N, int K, const float* dY, long ldy, const float* X, long ldx, float* dW, long lddw, int accumulate,
                      float* slab, int splits);
 int tcow_tn_splits(int M, int N, int K, int tile_outputs);
-int tcow_launch_slab_reduce(hipStream_t stream, const float* slab, int nz, long rows, long cols, float* out, long ldo, int accumulate);
+int tcow_launch_slab_reduce(hipStream_t stream, const float* slab, int nz, long slab_stride, long rows, long cols, float* out, long ldo, int accumulate);
 int tcow_launch_colsum(hipStream_t stream, int dtype, const void* Y, long ldy, int M, int N, float* out, int accumulate, float* part, int max_parts);
 
 extern "C" {
@@ -61,7 +61,7 @@ int tcow_gemm_tn(void* stream, int dtype, int M, int N, int K, const void* dY, l
         int nz = 0;
         rc = tcow_gemm_tn_bf16((hipStream_t)stream, M, N, K, (const bf16_t*)dY, ldy, (const bf16_t*)X, ldx, slab, splits, &nz);
         if (rc) return rc;
-        rc = tcow_launch_slab_reduce((hipStream_t)stream, slab, nz, N, K, dW, lddw, accumulate);
+        rc = tcow_launch_slab_reduce((hipStream_t)stream, slab, nz, (long)N * K, N, K, dW, lddw, accumulate);
         if (rc) return rc;
     } else if (dtype == TCOW_F32) {
         const int splits = tcow_tn_splits(M, N, K, 64);

@@ -1,0 +1,376 @@
+// Bandwidth-bound glue kernels of the Seeker path: patch gather, embeddings, cls handling, mask head re-layout,
+// coarsening (avg-pool + bilinear), flags, weight/gradient casts.  All are simple grid-stride kernels with
+// 8-16 byte vector accesses along the contiguous dimension.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------ im2col
+// rows (b,t,s): s = 0 -> zeros, s = 1+n -> flattened patch n of frame (b,t) of cat([rgb, query]) in the order
+// c*P*P + py*P + px (Conv2d weight flattening, vit.py:233-240; cat at mask_tracker.py:107-108).  Optional
+// (x-0.45)/0.225 on the rgb channels only (vision_tf.py:81-89).
+template <typename T>
+__global__ void im2col_kernel(int B, int T_, int H, int W, int P, int Crgb, int Cq, const float* __restrict__ rgb, const float* __restrict__ qm, int norm,
+                              T* __restrict__ out) {
+    const int Hp = H / P, Wp = W / P, N = Hp * Wp, S = N + 1, C = Crgb + Cq;
+    const int Kc = C * P * P, q4 = Kc / 4;
+    const long total = (long)B * T_ * S * q4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long row = i / q4; const int k = (int)(i - row * q4) * 4;
+        const int s = (int)(row % S); const long bt = row / S; const int t = (int)(bt % T_); const int b = (int)(bt / T_);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (s > 0) {
+            const int n = s - 1, hp = n / Wp, wp = n - hp * Wp;
+            const int c = k / (P * P), rem = k - c * P * P, py = rem / P, px = rem - py * P;
+            const int y = hp * P + py, x = wp * P + px;
+            if (c < Crgb) {
+                v = ld4(rgb + ((((size_t)b * Crgb + c) * T_ + t) * H + y) * W + x);
+                if (norm) { v.x = (v.x - 0.45f) / 0.225f; v.y = (v.y - 0.45f) / 0.225f; v.z = (v.z - 0.45f) / 0.225f; v.w = (v.w - 0.45f) / 0.225f; }
+            } else {
+                v = ld4(qm + ((((size_t)b * Cq + (c - Crgb)) * T_ + t) * H + y) * W + x);
+            }
+        }
+        st4(out + row * Kc + k, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ embeddings
+// x[b,t,s,:] = (s == 0) ? cls + pos[0] : x + pos[s] + time[t]      (vision_tf.py:99-138; f32 residual stream)
+__global__ void embed_fwd_kernel(int B, int T_, int S, int D, float* __restrict__ x, const float* __restrict__ cls, const float* __restrict__ pos,
+                                 const float* __restrict__ time) {
+    const int d4 = D / 4;
+    const long total = (long)B * T_ * S * d4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long row = i / d4; const int c = (int)(i - row * d4) * 4;
+        const int s = (int)(row % S); const int t = (int)((row / S) % T_);
+        const float4 p = ld4(pos + (size_t)s * D + c);
+        float4 o;
+        if (s == 0) { const float4 cv = ld4(cls + c); o = make_float4(cv.x + p.x, cv.y + p.y, cv.z + p.z, cv.w + p.w); }
+        else {
+            const float4 v = ld4(x + row * D + c), te = ld4(time + (size_t)t * D + c);
+            o = make_float4(v.x + p.x + te.x, v.y + p.y + te.y, v.z + p.z + te.z, v.w + p.w + te.w);
+        }
+        st4(x + row * D + c, o);
+    }
+}
+// dpos[s] = sum_{b,t} g[b,t,s];  one thread per (s, channel quad)
+__global__ void embed_bwd_pos_kernel(int B, int T_, int S, int D, const float* __restrict__ g, float* __restrict__ dpos, int accumulate) {
+    const int d4 = D / 4;
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= (long)S * d4) return;
+    const int s = (int)(i / d4), c = (int)(i - (long)s * d4) * 4;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int bt = 0; bt < B * T_; ++bt) { const float4 v = ld4(g + ((size_t)bt * S + s) * D + c); a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+    float* o = dpos + (size_t)s * D + c;
+    if (accumulate) { const float4 p = ld4(o); a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w; }
+    st4(o, a);
+}
+// dtime[t] = sum_{b, s>=1} g[b,t,s];  one workgroup per (t, 64-channel-quad group): threads split s, reduce in LDS
+__global__ __launch_bounds__(256) void embed_bwd_time_kernel(int B, int T_, int S, int D, const float* __restrict__ g, float* __restrict__ dtime, int accumulate) {
+    __shared__ float4 red[256];
+    const int t = blockIdx.x, cq = blockIdx.y * 16 + (threadIdx.x & 15), part = threadIdx.x >> 4;  // 16 channel quads x 16 row slices
+    const int d4 = D / 4;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (cq < d4) {
+        for (int b = 0; b < B; ++b)
+            for (int s = 1 + part; s < S; s += 16) {
+                const float4 v = ld4(g + (((size_t)b * T_ + t) * S + s) * D + cq * 4); a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+            }
+    }
+    red[threadIdx.x] = a;
+    __syncthreads();
+    if (part == 0 && cq < d4) {
+        for (int p = 1; p < 16; ++p) { const float4 v = red[p * 16 + (threadIdx.x & 15)]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+        float* o = dtime + (size_t)t * D + cq * 4;
+        if (accumulate) { const float4 p = ld4(o); a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w; }
+        st4(o, a);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ cls merge
+// After the spatial projection every frame's slot 0 holds cls + attn_out(frame).  The reference keeps ONE cls per
+// clip: frame 0's row for causal_attention == 1, the mean over frames for 0 (vit.py:189-198,215).  Write that row
+// back to every frame's slot 0.  mode: 1 -> frame 0, 0 -> mean.  Backward: sum of the replicas' gradients goes to
+// frame 0 (mode 1, others get zero) or is spread as mean (mode 0).
+__global__ void cls_merge_kernel(int B, int T_, int S, int D, float* __restrict__ x, int mode, int backward) {
+    const int d4 = D / 4;
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= (long)B * d4) return;
+    const int b = (int)(i / d4), c = (int)(i - (long)b * d4) * 4;
+    float* base = x + (size_t)b * T_ * S * D + c;
+    const size_t fs = (size_t)S * D;
+    if (!backward) {
+        float4 a;
+        if (mode == 1) a = ld4(base);
+        else {
+            a = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int t = 0; t < T_; ++t) { const float4 v = ld4(base + t * fs); a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+            const float inv = 1.0f / (float)T_; a.x *= inv; a.y *= inv; a.z *= inv; a.w *= inv;
+        }
+        for (int t = 0; t < T_; ++t) st4(base + t * fs, a);
+    } else {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int t = 0; t < T_; ++t) { const float4 v = ld4(base + t * fs); a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+        if (mode == 1) {
+            st4(base, a);
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int t = 1; t < T_; ++t) st4(base + t * fs, z);
+        } else {
+            const float inv = 1.0f / (float)T_; a.x *= inv; a.y *= inv; a.z *= inv; a.w *= inv;
+            for (int t = 0; t < T_; ++t) st4(base + t * fs, a);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ mask head re-layout + avg-pool
+// pm rows (b,t,1+n) hold C*P*P outputs in (c, py, px) order (mask_tracker.py:114-115); pooled[bt][c][Y][X] is the
+// mean over the st x st pixel block (mask_tracker.py:121-122), Y = hp*(P/st) + py/st.
+template <typename T>
+__global__ void unpatchify_pool_fwd_kernel(int BT, int Hp, int Wp, int P, int C, int st, const T* __restrict__ pm, float* __restrict__ pooled) {
+    const int S = Hp * Wp + 1, Ps = P / st, Ho = Hp * Ps, Wo = Wp * Ps, K = C * P * P;
+    const long total = (long)BT * C * Ho * Wo;
+    const float inv = 1.0f / (float)(st * st);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int X = (int)(i % Wo); const int Y = (int)((i / Wo) % Ho); const int c = (int)((i / ((long)Wo * Ho)) % C); const long bt = i / ((long)Wo * Ho * C);
+        const int hp = Y / Ps, py0 = (Y - hp * Ps) * st, wp = X / Ps, px0 = (X - wp * Ps) * st;
+        const T* src = pm + ((size_t)bt * S + 1 + hp * Wp + wp) * K + (size_t)c * P * P;
+        float a = 0.f;
+        for (int dy = 0; dy < st; ++dy)
+            for (int dx = 0; dx < st; ++dx) a += Elem<T>::ld(src + (py0 + dy) * P + px0 + dx);
+        pooled[i] = a * inv;
+    }
+}
+template <typename T>
+__global__ void unpatchify_pool_bwd_kernel(int BT, int Hp, int Wp, int P, int C, int st, const float* __restrict__ dpooled, T* __restrict__ dpm) {
+    const int S = Hp * Wp + 1, Ps = P / st, Ho = Hp * Ps, Wo = Wp * Ps, K = C * P * P;
+    const long total = (long)BT * S * K;
+    const float inv = 1.0f / (float)(st * st);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % K); const long row = i / K; const int s = (int)(row % S); const long bt = row / S;
+        float v = 0.f;
+        if (s > 0) {
+            const int n = s - 1, hp = n / Wp, wp = n - hp * Wp;
+            const int c = k / (P * P), rem = k - c * P * P, py = rem / P, px = rem - py * P;
+            const int Y = hp * Ps + py / st, X = wp * Ps + px / st;
+            v = dpooled[(((size_t)bt * C + c) * Ho + Y) * Wo + X] * inv;
+        }
+        Elem<T>::st(dpm + i, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ upsample
+// F.interpolate(scale_factor=st, mode='bilinear', align_corners=True) or 'nearest' (mask_tracker.py:124-130),
+// fused with the '(B T) C H W -> B C T H W' re-layout (mask_tracker.py:132).  Source index rule of ATen:
+// align_corners: src = dst * (in-1)/(out-1); i0 = (int)src; i1 = i0 + (i0 < in-1); w1 = src - i0.
+__device__ __forceinline__ void bil_src(int dst, int in, int out, int& i0, int& i1, float& w0, float& w1) {
+    const float scale = (out > 1) ? (float)(in - 1) / (float)(out - 1) : 0.f;
+    const float src = scale * (float)dst;
+    i0 = (int)src; if (i0 > in - 1) i0 = in - 1;
+    i1 = i0 + ((i0 < in - 1) ? 1 : 0);
+    w1 = src - (float)i0; w0 = 1.0f - w1;
+}
+__global__ void upsample_fwd_kernel(int B, int T_, int C, int h, int w, int st, int bilinear, const float* __restrict__ pooled, float* __restrict__ out) {
+    const int H = h * st, W = w * st;
+    const long total = (long)B * C * T_ * H * W;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W); const int y = (int)((i / W) % H); const int t = (int)((i / ((long)W * H)) % T_);
+        const int c = (int)((i / ((long)W * H * T_)) % C); const int b = (int)(i / ((long)W * H * T_ * C));
+        const float* src = pooled + (((size_t)(b * T_ + t)) * C + c) * h * w;
+        float v;
+        if (bilinear) {
+            int y0, y1, x0, x1; float wy0, wy1, wx0, wx1;
+            bil_src(y, h, H, y0, y1, wy0, wy1); bil_src(x, w, W, x0, x1, wx0, wx1);
+            v = wy0 * (wx0 * src[y0 * w + x0] + wx1 * src[y0 * w + x1]) + wy1 * (wx0 * src[y1 * w + x0] + wx1 * src[y1 * w + x1]);
+        } else {
+            v = src[(y / st) * w + (x / st)];
+        }
+        out[i] = v;
+    }
+}
+// gather-form backward: one thread per pooled pixel sums the output pixels that read it
+__global__ void upsample_bwd_kernel(int B, int T_, int C, int h, int w, int st, int bilinear, const float* __restrict__ dout, float* __restrict__ dpooled) {
+    const int H = h * st, W = w * st;
+    const long total = (long)B * T_ * C * h * w;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int X = (int)(i % w); const int Y = (int)((i / w) % h); const int c = (int)((i / ((long)w * h)) % C); const long bt = i / ((long)w * h * C);
+        const int b = (int)(bt / T_), t = (int)(bt - (long)b * T_);
+        const float* g = dout + (((size_t)b * C + c) * T_ + t) * H * W;
+        float a = 0.f;
+        if (bilinear) {
+            // candidate output rows: those whose i0 or i1 can equal Y
+            int ylo = (Y - 1) * st - st, yhi = (Y + 1) * st + st; if (ylo < 0) ylo = 0; if (yhi > H - 1) yhi = H - 1;
+            int xlo = (X - 1) * st - st, xhi = (X + 1) * st + st; if (xlo < 0) xlo = 0; if (xhi > W - 1) xhi = W - 1;
+            for (int y = ylo; y <= yhi; ++y) {
+                int y0, y1; float wy0, wy1; bil_src(y, h, H, y0, y1, wy0, wy1);
+                float wy = 0.f; if (y0 == Y) wy += wy0; if (y1 == Y) wy += wy1;
+                if (wy == 0.f) continue;
+                for (int x = xlo; x <= xhi; ++x) {
+                    int x0, x1; float wx0, wx1; bil_src(x, w, W, x0, x1, wx0, wx1);
+                    float wx = 0.f; if (x0 == X) wx += wx0; if (x1 == X) wx += wx1;
+                    if (wx != 0.f) a += wy * wx * g[(size_t)y * W + x];
+                }
+            }
+        } else {
+            for (int dy = 0; dy < st; ++dy)
+                for (int dx = 0; dx < st; ++dx) a += g[(size_t)(Y * st + dy) * W + X * st + dx];
+        }
+        dpooled[i] = a;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ flags
+// flags[b,t,f] = mean_n (Wf . x[b,t,1+n] + bf) = Wf . mean_n x + bf   (mask_tracker.py:135-137)
+__global__ __launch_bounds__(256) void flags_fwd_kernel(int S, int D, int F, const float* __restrict__ x, const float* __restrict__ Wf, const float* __restrict__ bf,
+                                                        float* __restrict__ flags) {
+    extern __shared__ float mean[];  // [D]
+    const int bt = blockIdx.x;
+    const float inv = 1.0f / (float)(S - 1);
+    for (int d = threadIdx.x; d < D; d += 256) {
+        float a = 0.f;
+        for (int s = 1; s < S; ++s) a += x[((size_t)bt * S + s) * D + d];
+        mean[d] = a * inv;
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int f = wave; f < F; f += 4) {
+        float a = 0.f;
+        for (int d = lane; d < D; d += 64) a += mean[d] * Wf[(size_t)f * D + d];
+        a = wave_sum(a);
+        if (lane == 0) flags[(size_t)bt * F + f] = a + bf[f];
+    }
+}
+
+// ------------------------------------------------------------------------------------------ casts
+// dst = T(src * row_scale[row])  (f32 -> T), used to turn residual-stream gradients into GEMM operands
+template <typename T>
+__global__ void scale_cast_kernel(long rows, int D, const float* __restrict__ src, long lds_, const float* __restrict__ row_scale, T* __restrict__ dst, long ldd) {
+    const int d4 = D / 4;
+    const long total = rows * d4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long row = i / d4; const int c = (int)(i - row * d4) * 4;
+        float4 v = ld4(src + row * lds_ + c);
+        if (row_scale) { const float s = row_scale[row]; v.x *= s; v.y *= s; v.z *= s; v.w *= s; }
+        st4(dst + row * ldd + c, v);
+    }
+}
+// W [N,K] f32 -> Wc [N,K] (T, optional) and Wt [K,N] (T, optional): 32x32 tile transpose through LDS
+template <typename T>
+__global__ __launch_bounds__(256) void cast_transpose_kernel(int N, int K, const float* __restrict__ Wsrc, T* __restrict__ Wc, T* __restrict__ Wt) {
+    __shared__ float tile[32][33];
+    const int n0 = blockIdx.y * 32, k0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int n = n0 + r, k = k0 + tx;
+        float v = 0.f;
+        if (n < N && k < K) { v = Wsrc[(size_t)n * K + k]; if (Wc) Elem<T>::st(Wc + (size_t)n * K + k, v); }
+        tile[r][tx] = v;
+    }
+    __syncthreads();
+    if (Wt)
+        for (int r = ty; r < 32; r += 8) {
+            const int k = k0 + r, n = n0 + tx;
+            if (n < N && k < K) Elem<T>::st(Wt + (size_t)k * N + n, tile[tx][r]);
+        }
+}
+
+}  // namespace
+
+static inline int gs_blocks(long total, int per_block = 256) { long b = (total + per_block - 1) / per_block; return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); }
+
+extern "C" {
+
+int tcow_im2col(void* stream, int dtype, int B, int T_, int H, int W, int P, const float* rgb, const float* query, int pretrained_norm, void* out) {
+    TCOW_CHECK_ARG(B > 0 && T_ > 0 && P > 0 && P % 4 == 0 && H % P == 0 && W % P == 0, "tcow_im2col: bad geometry B=%d T=%d H=%d W=%d P=%d", B, T_, H, W, P);
+    TCOW_CHECK_ARG(rgb && query && out, "tcow_im2col: null pointer");
+    const long total = (long)B * T_ * ((H / P) * (W / P) + 1) * (4 * P * P / 4);
+    if (dtype == TCOW_BF16) hipLaunchKernelGGL(im2col_kernel<bf16_t>, dim3(gs_blocks(total)), dim3(256), 0, (hipStream_t)stream, B, T_, H, W, P, 3, 1, rgb, query, pretrained_norm, (bf16_t*)out);
+    else if (dtype == TCOW_F32) hipLaunchKernelGGL(im2col_kernel<float>, dim3(gs_blocks(total)), dim3(256), 0, (hipStream_t)stream, B, T_, H, W, P, 3, 1, rgb, query, pretrained_norm, (float*)out);
+    else { tcow_set_error("tcow_im2col: unknown dtype %d", dtype); return TCOW_ERR_INVALID_ARG; }
+    TCOW_CHECK_LAUNCH();
+    return TCOW_OK;
+}
+
+int tcow_embed_fwd(void* stream, int B, int T_, int S, int D, float* x, const float* cls, const float* pos, const float* time_embed) {
+    TCOW_CHECK_ARG(B > 0 && T_ > 0 && S > 1 && D % 4 == 0 && x && cls && pos && time_embed, "tcow_embed_fwd: bad arguments");
+    hipLaunchKernelGGL(embed_fwd_kernel, dim3(gs_blocks((long)B * T_ * S * D / 4)), dim3(256), 0, (hipStream_t)stream, B, T_, S, D, x, cls, pos, time_embed);
+    TCOW_CHECK_LAUNCH();
+    return TCOW_OK;
+}
+
+int tcow_embed_bwd(void* stream, int B, int T_, int S, int D, const float* g, float* dpos, float* dtime, int accumulate) {
+    TCOW_CHECK_ARG(B > 0 && T_ > 0 && S > 1 && D % 4 == 0 && g && dpos && dtime, "tcow_embed_bwd: bad arguments");
+    hipLaunchKernelGGL(embed_bwd_pos_kernel, dim3(cdiv((long)S * D / 4, 256)), dim3(256), 0, (hipStream_t)stream, B, T_, S, D, g, dpos, accumulate);
+    TCOW_CHECK_LAUNCH();
+    hipLaunchKernelGGL(embed_bwd_time_kernel, dim3(T_, cdiv(D / 4, 16)), dim3(256), 0, (hipStream_t)stream, B, T_, S, D, g, dtime, accumulate);
+    TCOW_CHECK_LAUNCH();
+    return TCOW_OK;
+}
+
+int tcow_cls_merge(void* stream, int B, int T_, int S, int D, float* x, int mode, int backward) {
+    TCOW_CHECK_ARG(B > 0 && T_ > 0 && S > 1 && D % 4 == 0 && x && (mode == 0 || mode == 1), "tcow_cls_merge: bad arguments");
+    hipLaunchKernelGGL(cls_merge_kernel, dim3(cdiv((long)B * D / 4, 256)), dim3(256), 0, (hipStream_t)stream, B, T_, S, D, x, mode, backward);
+    TCOW_CHECK_LAUNCH();
+    return TCOW_OK;
+}
+
+int tcow_unpatchify_pool_fwd(void* stream, int dtype, int BT, int Hp, int Wp, int P, int C, int st, const void* pm, float* pooled) {
+    TCOW_CHECK_ARG(BT > 0 && Hp > 0 && Wp > 0 && P > 0 && C > 0 && st > 0 && P % st == 0 && pm && pooled, "tcow_unpatchify_pool_fwd: bad arguments");
+    const long total = (long)BT * C * Hp * Wp * (P / st) * (P / st);
+    if (dtype == TCOW_BF16) hipLaunchKernelGGL(unpatchify_pool_fwd_kernel<bf16_t>, dim3(gs_blocks(total)), dim3(256), 0, (hipStream_t)stream, BT, Hp, Wp, P, C, st, (const bf16_t*)pm, pooled);
+    else if (dtype == TCOW_F32) hipLaunchKernelGGL(unpatchify_pool_fwd_kernel<float>, dim3(gs_blocks(total)), dim3(256), 0, (hipStream_t)stream, BT, Hp, Wp, P, C, st, (const float*)pm, pooled);
+    else { tcow_set_error("tcow_unpatchify_pool_fwd: unknown dtype %d", dtype); return TCOW_ERR_INVALID_ARG; }
+    TCOW_CHECK_LAUNCH();
+    return TCOW_OK;
+}
+
+int tcow_unpatchify_pool_bwd(void* stream, int dtype, int BT, int Hp, int Wp, int P, int C, int st, const float* dpooled, void* dpm) {
+    TCOW_CHECK_ARG(BT > 0 && Hp > 0 && Wp > 0 && P > 0 && C > 0 && st > 0 && P % st == 0 && dpooled && dpm, "tcow_unpatchify_pool_bwd: bad arguments");
+    const long total = (long)BT * (Hp * Wp + 1) * C * P * P;
+    if (dtype == TCOW_BF16) hipLaunchKernelGGL(unpatchify_pool_bwd_kernel<bf16_t>, dim3(gs_blocks(total)), dim3(256), 0, (hipStream_t)stream, BT, Hp, Wp, P, C, st, dpooled, (bf16_t*)dpm);
+    else if (dtype == TCOW_F32) hipLaunchKernelGGL(unpatchify_pool_bwd_kernel<float>, dim3(gs_blocks(total)), dim3(256), 0, (hipStream_t)stream, BT, Hp, Wp, P, C, st, dpooled, (float*)dpm);
+    else { tcow_set_error("tcow_unpatchify_pool_bwd: unknown dtype %d", dtype); return TCOW_ERR_INVALID_ARG; }
+    TCOW_CHECK_LAUNCH();
+    return TCOW_OK;
+}
+
+int tcow_upsample_fwd(void* stream, int B, int T_, int C, int h, int w, int st, int bilinear, const float* pooled, float* out) {
+    TCOW_CHECK_ARG(B > 0 && T_ > 0 && C > 0 && h > 0 && w > 0 && st > 0 && pooled && out, "tcow_upsample_fwd: bad arguments");
+    hipLaunchKernelGGL(upsample_fwd_kernel, dim3(gs_blocks((long)B * C * T_ * h * w * st * st)), dim3(256), 0, (hipStream_t)stream, B, T_, C, h, w, st, bilinear, pooled, out);
+    TCOW_CHECK_LAUNCH();
+    return TCOW_OK;
+}
+
+int tcow_upsample_bwd(void* stream, int B, int T_, int C, int h, int w, int st, int bilinear, const float* dout, float* dpooled) {
+    TCOW_CHECK_ARG(B > 0 && T_ > 0 && C > 0 && h > 0 && w > 0 && st > 0 && dout && dpooled, "tcow_upsample_bwd: bad arguments");
+    hipLaunchKernelGGL(upsample_bwd_kernel, dim3(gs_blocks((long)B * C * T_ * h * w)), dim3(256), 0, (hipStream_t)stream, B, T_, C, h, w, st, bilinear, dout, dpooled);
+    TCOW_CHECK_LAUNCH();
+    return TCOW_OK;
+}
+
+int tcow_flags_fwd(void* stream, int BT, int S, int D, int F, const float* x, const float* Wf, const float* bf, float* flags) {
+    TCOW_CHECK_ARG(BT > 0 && S > 1 && D > 0 && F > 0 && x && Wf && bf && flags, "tcow_flags_fwd: bad arguments");
+    hipLaunchKernelGGL(flags_fwd_kernel, dim3(BT), dim3(256), (size_t)D * 4, (hipStream_t)stream, S, D, F, x, Wf, bf, flags);
+    TCOW_CHECK_LAUNCH();
+    return TCOW_OK;
+}
+
+int tcow_scale_cast(void* stream, int dtype, long rows, int D, const float* src, long ld_src, const float* row_scale, void* dst, long ld_dst) {
+    TCOW_CHECK_ARG(rows > 0 && D > 0 && D % 4 == 0 && src && dst && ld_src % 4 == 0 && ld_dst % 4 == 0, "tcow_scale_cast: bad arguments");
+    if (dtype == TCOW_BF16) hipLaunchKernelGGL(scale_cast_kernel<bf16_t>, dim3(gs_blocks(rows * D / 4)), dim3(256), 0, (hipStream_t)stream, rows, D, src, ld_src, row_scale, (bf16_t*)dst, ld_dst);
+    else if (dtype == TCOW_F32) hipLaunchKernelGGL(scale_cast_kernel<float>, dim3(gs_blocks(rows * D / 4)), dim3(256), 0, (hipStream_t)stream, rows, D, src, ld_src, row_scale, (float*)dst, ld_dst);
+    else { tcow_set_error("tcow_scale_cast: unknown dtype %d", dtype); return TCOW_ERR_INVALID_ARG; }
+    TCOW_CHECK_LAUNCH();
+    return TCOW_OK;
+}
+
+int tcow_cast_transpose(void* stream, int dtype, int N, int K, const float* W, void* Wc, void* Wt) {
+    TCOW_CHECK_ARG(N > 0 && K > 0 && W && (Wc || Wt), "tcow_cast_transpose: bad arguments");
+    const dim3 grid(cdiv(K, 32), cdiv(N, 32));
+    if (dtype == TCOW_BF16) hipLaunchKernelGGL(cast_transpose_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, N, K, W, (bf16_t*)Wc, (bf16_t*)Wt);
+    else if (dtype == TCOW_F32) hipLaunchKernelGGL(cast_transpose_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, N, K, W, (float*)Wc, (float*)Wt);
+    else { tcow_set_error("tcow_cast_transpose: unknown dtype %d", dtype); return TCOW_ERR_INVALID_ARG; }
+    TCOW_CHECK_LAUNCH();
+    return TCOW_OK;
+}
+
+}  // extern "C"

@@ -107,12 +107,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(F32Params p) {
 }
 
 // out[i] (+)= sum_z slab[z][i]   and optional column sums for the bias gradient are handled elsewhere
-__global__ void slab_reduce_kernel(const float* __restrict__ slab, int nz, long n, float* __restrict__ out, long rows, long cols, long ldo, int accumulate) {
+__global__ void slab_reduce_kernel(const float* __restrict__ slab, int nz, long slab_stride, long n, float* __restrict__ out, long rows, long cols, long ldo, int accumulate) {
     long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
     const long stride = (long)gridDim.x * blockDim.x;
     for (; i < n; i += stride) {
         float s = 0.f;
-        for (int z = 0; z < nz; ++z) s += slab[(size_t)z * n + i];
+        for (int z = 0; z < nz; ++z) s += slab[(size_t)z * slab_stride + i];
         const long r = i / cols, c = i - r * cols;
         float* o = out + r * ldo + c;
         *o = accumulate ? (*o + s) : s;
@@ -160,10 +160,10 @@ int tcow_tn_splits(int M, int N, int K, int tile_outputs) {
     return s;
 }
 
-int tcow_launch_slab_reduce(hipStream_t stream, const float* slab, int nz, long rows, long cols, float* out, long ldo, int accumulate) {
+int tcow_launch_slab_reduce(hipStream_t stream, const float* slab, int nz, long slab_stride, long rows, long cols, float* out, long ldo, int accumulate) {
     const long n = rows * cols;
     int blocks = cdiv(n, 256); if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, stream, slab, nz, n, out, rows, cols, ldo, accumulate);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, stream, slab, nz, slab_stride, n, out, rows, cols, ldo, accumulate);
     TCOW_CHECK_LAUNCH();
     return TCOW_OK;
 }
@@ -177,7 +177,7 @@ int tcow_launch_colsum(hipStream_t stream, int dtype, const void* Y, long ldy, i
     else
         hipLaunchKernelGGL(colsum_partial_kernel<float>, dim3(cdiv(N, 64), parts), dim3(256), 0, stream, (const float*)Y, ldy, M, N, rpb, part);
     TCOW_CHECK_LAUNCH();
-    return tcow_launch_slab_reduce(stream, part, parts, 1, N, out, N, accumulate);
+    return tcow_launch_slab_reduce(stream, part, parts, N, 1, N, out, N, accumulate);
 }
 
 int tcow_gemm_tn_f32(hipStream_t stream, int M, int N, int K, const float* dY, long ldy, const float* X, long ldx, float* dW, long lddw,
@@ -192,5 +192,5 @@ int tcow_gemm_tn_f32(hipStream_t stream, int M, int N, int K, const float* dY, l
     p.kps = kps; p.slab = slab;
     hipLaunchKernelGGL(gemm_f32_kernel, dim3(cdiv(K, FT), cdiv(N, FT), nz), dim3(256), 0, stream, p);
     TCOW_CHECK_LAUNCH();
-    return tcow_launch_slab_reduce(stream, slab, nz, N, K, dW, lddw, accumulate);
+    return tcow_launch_slab_reduce(stream, slab, nz, (long)N * K, N, K, dW, lddw, accumulate);
 }

@@ -1,0 +1,174 @@
+// LayerNorm over the channel dimension of the f32 residual stream (nn.LayerNorm(D, eps=1e-6):
+// vit.py:135 norm1, :142 temporal_norm1, :150 norm2, :283 norm; eps from vit.py:428).
+// One wave per token row, the row lives in registers (D <= 2048), statistics by wavefront reduction.
+// Memory-bound: reads 4*D bytes and writes sizeof(T)*D bytes per row.
+#include "common.h"
+
+namespace {
+
+constexpr int LN_MAXV = 8;  // float4 per lane -> D <= 64*4*8 = 2048
+
+template <typename T>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(int rows, int D, const float* __restrict__ x, long ldx, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float eps, T* __restrict__ y, long ldy,
+                                                     float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nv = D >> 2;  // float4 count
+    const float* xr = x + (size_t)row * ldx;
+    float4 v[LN_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) { v[i] = ld4(xr + c * 4); s += (v[i].x + v[i].y) + (v[i].z + v[i].w); }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+            const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+            q += (a * a + b * b) + (cc * cc + d * d);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+    if (lane == 0) {
+        if (mean_out) mean_out[row] = mean;
+        if (rstd_out) rstd_out[row] = rstd;
+    }
+    T* yr = y + (size_t)row * ldy;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+            const float4 g = ld4(gamma + c * 4), b = ld4(beta + c * 4);
+            float4 o;
+            o.x = (v[i].x - mean) * rstd * g.x + b.x; o.y = (v[i].y - mean) * rstd * g.y + b.y;
+            o.z = (v[i].z - mean) * rstd * g.z + b.z; o.w = (v[i].w - mean) * rstd * g.w + b.w;
+            st4(yr + c * 4, o);
+        }
+    }
+}
+
+// Backward: dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma, xhat = (x - mean) * rstd;
+// dx_out = dres + dx (the gradient arriving through the residual connection is added here).
+// dgamma / dbeta partial sums: each wave keeps per-column partials over the rows it visits, the block folds its
+// 4 waves through LDS and writes one partial row per block; tcow_launch_slab_reduce finishes the sum.
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int D, const T* __restrict__ dy, long lddy, const float* __restrict__ x, long ldx,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     const float* __restrict__ gamma, const float* __restrict__ dres, long lddres,
+                                                     float* __restrict__ dx, long lddx, float* __restrict__ part /* [grid][2][D] or NULL */) {
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [4][2*D]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nv = D >> 2;
+    float4 gsum[LN_MAXV], bsum[LN_MAXV], gam[LN_MAXV];
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        gsum[i] = make_float4(0.f, 0.f, 0.f, 0.f); bsum[i] = gsum[i];
+        const int c = lane + i * 64;
+        gam[i] = (c < nv) ? ld4(gamma + c * 4) : gsum[i];
+    }
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+        const float mu = mean[row], rs = rstd[row];
+        const float* xr = x + (size_t)row * ldx;
+        const T* dyr = dy + (size_t)row * lddy;
+        float4 xh[LN_MAXV], g[LN_MAXV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int c = lane + i * 64;
+            if (c < nv) {
+                const float4 xv = ld4(xr + c * 4), d = ld4(dyr + c * 4);
+                xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+                g[i] = make_float4(d.x * gam[i].x, d.y * gam[i].y, d.z * gam[i].z, d.w * gam[i].w);
+                s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
+                s2 += (g[i].x * xh[i].x + g[i].y * xh[i].y) + (g[i].z * xh[i].z + g[i].w * xh[i].w);
+                gsum[i].x += d.x * xh[i].x; gsum[i].y += d.y * xh[i].y; gsum[i].z += d.z * xh[i].z; gsum[i].w += d.w * xh[i].w;
+                bsum[i].x += d.x; bsum[i].y += d.y; bsum[i].z += d.z; bsum[i].w += d.w;
+            }
+        }
+        const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
+        float* dxr = dx + (size_t)row * lddx;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int c = lane + i * 64;
+            if (c < nv) {
+                float4 o = make_float4(rs * (g[i].x - m1 - xh[i].x * m2), rs * (g[i].y - m1 - xh[i].y * m2), rs * (g[i].z - m1 - xh[i].z * m2),
+                                       rs * (g[i].w - m1 - xh[i].w * m2));
+                if (dres) { const float4 r = ld4(dres + (size_t)row * lddres + c * 4); o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
+                st4(dxr + c * 4, o);
+            }
+        }
+    }
+    if (!part) return;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+            *reinterpret_cast<float4*>(red + (size_t)wave * 2 * D + c * 4) = gsum[i];
+            *reinterpret_cast<float4*>(red + (size_t)wave * 2 * D + D + c * 4) = bsum[i];
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * D; i += 256) {
+        part[(size_t)blockIdx.x * 2 * D + i] = (red[i] + red[2 * D + i]) + (red[4 * D + i] + red[6 * D + i]);
+    }
+}
+
+}  // namespace
+
+int tcow_launch_slab_reduce(hipStream_t stream, const float* slab, int nz, long slab_stride, long rows, long cols, float* out, long ldo, int accumulate);
+
+static const int kLnBwdBlocks = 512;
+
+extern "C" {
+
+int tcow_layernorm_fwd(void* stream, int dtype, int rows, int D, const float* x, long ldx, const float* gamma, const float* beta, float eps, void* y,
+                       long ldy, float* mean, float* rstd) {
+    TCOW_CHECK_ARG(rows > 0 && D > 0 && D % 4 == 0 && D <= 64 * 4 * LN_MAXV, "tcow_layernorm_fwd: D=%d must be a multiple of 4 and <= %d", D, 64 * 4 * LN_MAXV);
+    TCOW_CHECK_ARG(x && gamma && beta && y && ldx % 4 == 0 && ldy % 4 == 0, "tcow_layernorm_fwd: bad pointers / strides");
+    const dim3 grid(cdiv(rows, 4)), block(256);
+    if (dtype == TCOW_BF16)
+        hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, rows, D, x, ldx, gamma, beta, eps, (bf16_t*)y, ldy, mean, rstd);
+    else if (dtype == TCOW_F32)
+        hipLaunchKernelGGL(ln_fwd_kernel<float>, grid, block, 0, (hipStream_t)stream, rows, D, x, ldx, gamma, beta, eps, (float*)y, ldy, mean, rstd);
+    else { tcow_set_error("tcow_layernorm_fwd: unknown dtype %d", dtype); return TCOW_ERR_INVALID_ARG; }
+    TCOW_CHECK_LAUNCH();
+    return TCOW_OK;
+}
+
+long tcow_layernorm_bwd_workspace_bytes(int D) { return (long)kLnBwdBlocks * 2 * D * 4; }
+
+int tcow_layernorm_bwd(void* stream, int dtype, int rows, int D, const void* dy, long lddy, const float* x, long ldx, const float* mean,
+                       const float* rstd, const float* gamma, const float* dres, long lddres, float* dx, long lddx, float* dgamma, float* dbeta,
+                       int accumulate, void* workspace, long workspace_bytes) {
+    TCOW_CHECK_ARG(rows > 0 && D > 0 && D % 4 == 0 && D <= 64 * 4 * LN_MAXV, "tcow_layernorm_bwd: bad D=%d", D);
+    TCOW_CHECK_ARG(dy && x && mean && rstd && gamma && dx, "tcow_layernorm_bwd: null pointer");
+    const bool want_param_grads = dgamma != nullptr || dbeta != nullptr;
+    TCOW_CHECK_ARG(!want_param_grads || (dgamma && dbeta && workspace && workspace_bytes >= tcow_layernorm_bwd_workspace_bytes(D)),
+                   "tcow_layernorm_bwd: parameter gradients need dgamma, dbeta and a workspace of %ld bytes", tcow_layernorm_bwd_workspace_bytes(D));
+    int blocks = cdiv(rows, 4); if (blocks > kLnBwdBlocks) blocks = kLnBwdBlocks;
+    float* part = want_param_grads ? (float*)workspace : nullptr;
+    const size_t lds = want_param_grads ? (size_t)8 * D * 4 : 0;
+    if (dtype == TCOW_BF16)
+        hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), lds, (hipStream_t)stream, rows, D, (const bf16_t*)dy, lddy, x, ldx, mean, rstd, gamma, dres,
+                           lddres, dx, lddx, part);
+    else if (dtype == TCOW_F32)
+        hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(blocks), dim3(256), lds, (hipStream_t)stream, rows, D, (const float*)dy, lddy, x, ldx, mean, rstd, gamma, dres,
+                           lddres, dx, lddx, part);
+    else { tcow_set_error("tcow_layernorm_bwd: unknown dtype %d", dtype); return TCOW_ERR_INVALID_ARG; }
+    TCOW_CHECK_LAUNCH();
+    if (want_param_grads) {
+        // part is [blocks][2][D]: slab stride 2*D, dgamma partials first, dbeta partials at +D
+        int rc = tcow_launch_slab_reduce((hipStream_t)stream, part, blocks, 2L * D, 1, D, dgamma, D, accumulate);
+        if (rc) return rc;
+        return tcow_launch_slab_reduce((hipStream_t)stream, part + D, blocks, 2L * D, 1, D, dbeta, D, accumulate);
+    }
+    return TCOW_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,402 @@
+"""Forward / backward schedule of the Seeker hot path on libtcow_hip, as one autograd.Function.
+
+Layout: residual stream R [M, D] f32 with M = B*T*S rows, row(b,t,s) = (b*T+t)*S + s, slot 0 = cls replica
+(see include/tcow_hip.h).  Per block (vit.py:155-217), with the reference lines each launch replaces:
+
+    U   = LN_t(R0)                                  temporal_norm1            vit.py:172
+    QKV = U Wqkv_t^T + b                            temporal_attn.qkv         vit.py:81
+    O   = attn_temporal(QKV)          causal mask   vit.py:88-109
+    Pj  = dp_t * (O Wproj_t^T + b)                  temporal_attn.proj + DropPath   vit.py:111,172
+    R1  = R0 + [s>=1] * (Pj Wfc^T + b)              temporal_fc + residual    vit.py:174-176
+    V   = LN_1(R1);  QKV = V Wqkv^T + b;  O = attn_spatial(QKV)               vit.py:184-186 / 206-208
+    R2  = R1 + dp_s * (O Wproj^T + b);  cls merge                             vit.py:189-215
+    H   = GELU(LN_2(R2) W1^T + b1);  R3 = R2 + dp_m * (H W2^T + b2)           vit.py:216, 55-61
+
+The backward below is the hand-derived adjoint of exactly this schedule; nothing goes through torch autograd.
+"""
+import torch
+
+from . import ops
+from .ops import ACT_DGELU, ACT_GELU
+
+_BLOCK_PARAMS = 20   # parameters per block in QueryMaskTracker.param_list()
+
+
+def _w2d(p):
+    return p.reshape(p.shape[0], -1)
+
+
+def _get_weight(module, p, train):
+    """Operand copies of a weight: (Wc [N,K] in the mode's dtype, Wt [K,N] or None), cached per parameter version."""
+    mode = module.mode
+    key = id(p)
+    ent = module._wcache.get(key)
+    if ent is not None and ent[0] == p._version and ent[1] == mode and (ent[3] is not None or not train):
+        return ent[2], ent[3]
+    w = _w2d(p.detach())
+    N, K = w.shape
+    dt = ops.tdtype(mode)
+    if mode == ops.BF16:
+        Wc = torch.empty(N, K, dtype=dt, device=w.device)
+        Wt = torch.empty(K, N, dtype=dt, device=w.device) if train else None
+        ops.cast_transpose(mode, w.contiguous(), Wc, Wt)
+    else:
+        Wc = w.contiguous()
+        Wt = None
+        if train:
+            Wt = torch.empty(K, N, dtype=dt, device=w.device)
+            ops.cast_transpose(mode, Wc, None, Wt)
+    module._wcache[key] = (p._version, mode, Wc, Wt)
+    return Wc, Wt
+
+
+def _row_vectors(module, g, train):
+    """mask0 [M] (0 on slot 0) and the DropPath row scales of every block (None in eval)."""
+    B, T, S, N = g['B'], g['T'], g['S'], g['N']
+    dev = module.vit.pos_embed.device
+    key = ('mask0', B, str(dev))
+    mask0 = module._wcache.get(key)
+    if mask0 is None:
+        mask0 = torch.ones(B, T, S, dtype=torch.float32, device=dev)
+        mask0[:, :, 0] = 0
+        mask0 = mask0.reshape(-1).contiguous()
+        module._wcache[key] = mask0
+    depth = module.network_depth
+    rates = torch.linspace(0, module.drop_path_rate, depth).tolist() if depth > 1 else [0.0]   # vit.py:272
+    scales = []
+    forced = module.forced_drop_masks
+    for i in range(depth):
+        r = rates[i]
+        ent = {'t': None, 's': None, 'm': None}
+        if forced is not None or (train and r > 0.):
+            def draw(kind, shape):
+                if forced is not None:
+                    if (i, kind) not in forced:
+                        return None
+                    keep, rate = forced[(i, kind)]
+                    return keep.to(dev, torch.float32).reshape(shape) / (1.0 - rate)
+                keep = (torch.rand(shape, device=dev) + (1.0 - r)).floor_()           # vit_utils.py:150-152
+                return keep / (1.0 - r)
+            kt = draw('temporal', (B, N))
+            if kt is not None:
+                rs = torch.ones(B, T, S, dtype=torch.float32, device=dev)
+                rs[:, :, 1:] = kt[:, None, :]
+                ent['t'] = rs.reshape(-1).contiguous()
+            ks = draw('spatial', (B, T))
+            if ks is not None:
+                ent['s'] = ks[:, :, None].expand(B, T, S).reshape(-1).contiguous()
+            km = draw('mlp', (B,))
+            if km is not None:
+                ent['m'] = km[:, None].expand(B, T * S).reshape(-1).contiguous()
+        scales.append(ent)
+    return mask0, scales
+
+
+def _effective_embeddings(module, g):
+    """pos [S,D] / time [T,D] as used by the forward, with the nearest-neighbour resize of vision_tf.py:103-115,
+    127-132 when the stored tables do not match the clip; returns index maps for the backward."""
+    v = module.vit
+    pos = v.pos_embed.detach()[0]
+    S, T = g['S'], g['T']
+    pos_idx = None
+    if pos.shape[0] != S:
+        n_old = pos.shape[0] - 1
+        Pold = int(n_old ** 0.5)
+        Hn = S // g['Wp']                       # vision_tf.py:108: H = x.size(1) // W
+        ys = (torch.arange(Hn, device=pos.device).float() * (Pold / Hn)).floor().long().clamp_(max=Pold - 1)
+        xs = (torch.arange(g['Wp'], device=pos.device).float() * (Pold / g['Wp'])).floor().long().clamp_(max=Pold - 1)
+        grid = (ys[:, None] * Pold + xs[None, :]).reshape(-1) + 1
+        pos_idx = torch.cat([torch.zeros(1, dtype=torch.long, device=pos.device), grid])
+        pos = pos[pos_idx].contiguous()
+    te = v.time_embed.detach()[0]
+    time_idx = None
+    if te.shape[0] != T:
+        time_idx = (torch.arange(T, device=te.device).float() * (te.shape[0] / T)).floor().long().clamp_(max=te.shape[0] - 1)
+        te = te[time_idx].contiguous()
+    return pos.contiguous(), te.contiguous(), pos_idx, time_idx
+
+
+def run_forward(module, rgb, qm, params, save):
+    mode = module.mode
+    dt = ops.tdtype(mode)
+    dev = rgb.device
+    B = rgb.shape[0]
+    g = module.geometry(B)
+    T, S, D, M, P, heads = g['T'], g['S'], g['D'], g['M'], g['P'], g['heads']
+    ca = module.causal_attention
+    use_cls = ca in (0, 1)
+    train = save
+    f32 = torch.float32
+
+    def E(*shape, dtype=dt):
+        return torch.empty(*shape, dtype=dtype, device=dev)
+
+    W = lambda p: _get_weight(module, p, train)[0]
+    mask0, dps = _row_vectors(module, g, module.training)
+    sv = {'g': g, 'blocks': [], 'mask0': mask0, 'dps': dps} if save else None
+
+    # ---- patch embed (vit.py:233-241) + embeddings (vision_tf.py:99-138)
+    Kpe = module.input_channels * P * P
+    A_pe = E(M, Kpe)
+    ops.im2col(mode, rgb, qm, P, module.tracker_pretrained, A_pe)
+    X = E(M, D, dtype=f32)
+    ops.gemm_nt(mode, A_pe, W(params[3]), X, bias=params[4].detach())
+    pos, te, pos_idx, time_idx = _effective_embeddings(module, g)
+    ops.embed_fwd(X, B, T, S, params[0].detach().reshape(-1), pos, te)
+    if save:
+        sv.update(A_pe=A_pe, pos_idx=pos_idx, time_idx=time_idx)
+
+    shape_attn = ops.attn_shape(mode, B, T, S, D, heads, ca)
+    for i in range(module.network_depth):
+        q = params[5 + i * _BLOCK_PARAMS: 5 + (i + 1) * _BLOCK_PARAMS]
+        (tn_w, tn_b, tqkv_w, tqkv_b, tproj_w, tproj_b, tfc_w, tfc_b, n1_w, n1_b, qkv_w, qkv_b, proj_w, proj_b,
+         n2_w, n2_b, fc1_w, fc1_b, fc2_w, fc2_b) = [t.detach() for t in q]
+        dp = dps[i]
+        st = {}
+        R0 = X
+        # temporal
+        U = E(M, D); mu0 = E(M, dtype=f32) if save else None; rs0 = E(M, dtype=f32) if save else None
+        ops.layernorm_fwd(mode, R0, tn_w, tn_b, U, mu0, rs0)
+        QKV = E(M, 3 * D)
+        ops.gemm_nt(mode, U, W(q[2]), QKV, bias=tqkv_b)
+        O = E(M, D); lse_t = E(M, heads, dtype=f32) if save else None
+        ops.attn_fwd(shape_attn, False, QKV, O, lse_t)
+        Pj = E(M, D)
+        ops.gemm_nt(mode, O, W(q[4]), Pj, bias=tproj_b, row_scale=dp['t'])
+        R1 = E(M, D, dtype=f32) if save else R0
+        ops.gemm_nt(mode, Pj, W(q[6]), R1, bias=tfc_b, row_scale=mask0, resid=R0)
+        if save:
+            st.update(R0=R0, mu0=mu0, rs0=rs0, U=U, QKV_t=QKV, O_t=O, lse_t=lse_t, Pj=Pj)
+        # spatial
+        V = E(M, D); mu1 = E(M, dtype=f32) if save else None; rs1 = E(M, dtype=f32) if save else None
+        ops.layernorm_fwd(mode, R1, n1_w, n1_b, V, mu1, rs1)
+        QKV2 = E(M, 3 * D)
+        ops.gemm_nt(mode, V, W(q[10]), QKV2, bias=qkv_b)
+        O2 = E(M, D); lse_s = E(M, heads, dtype=f32) if save else None
+        ops.attn_fwd(shape_attn, True, QKV2, O2, lse_s)
+        rs_s = dp['s']
+        if not use_cls:
+            rs_s = mask0 if rs_s is None else rs_s * mask0
+        R2 = E(M, D, dtype=f32) if save else R1
+        ops.gemm_nt(mode, O2, W(q[12]), R2, bias=proj_b, row_scale=rs_s, resid=R1)
+        if use_cls:
+            ops.cls_merge(R2, B, T, S, 1 if ca == 1 else 0)
+        if save:
+            st.update(R1=R1, mu1=mu1, rs1=rs1, V=V, QKV_s=QKV2, O_s=O2, lse_s=lse_s, rs_s=rs_s)
+        # mlp
+        Wn = E(M, D); mu2 = E(M, dtype=f32) if save else None; rs2 = E(M, dtype=f32) if save else None
+        ops.layernorm_fwd(mode, R2, n2_w, n2_b, Wn, mu2, rs2)
+        Hd = fc1_w.shape[0]
+        pre = E(M, Hd) if save else None
+        H = E(M, Hd)
+        ops.gemm_nt(mode, Wn, W(q[16]), H, bias=fc1_b, act=ACT_GELU, aux=pre)
+        R3 = E(M, D, dtype=f32) if save else R2
+        ops.gemm_nt(mode, H, W(q[18]), R3, bias=fc2_b, row_scale=dp['m'], resid=R2)
+        if save:
+            st.update(R2=R2, mu2=mu2, rs2=rs2, Wn=Wn, pre=pre, H=H)
+            sv['blocks'].append(st)
+        X = R3
+
+    # ---- output heads
+    nb = 5 + module.network_depth * _BLOCK_PARAMS
+    norm_w, norm_b, head_w, head_b = params[nb], params[nb + 1], params[nb + 2], params[nb + 3]
+    feat32 = X
+    if module.norm_embeddings:                                            # vision_tf.py:152-153
+        Fm = E(M, D); muf = E(M, dtype=f32) if save else None; rsf = E(M, dtype=f32) if save else None
+        ops.layernorm_fwd(mode, X, norm_w.detach(), norm_b.detach(), Fm, muf, rsf)
+        if module.flag_channels > 0 and mode != ops.F32:
+            feat32 = E(M, D, dtype=f32)
+            ops.layernorm_fwd(ops.F32, X, norm_w.detach(), norm_b.detach(), feat32)
+        elif mode == ops.F32:
+            feat32 = Fm
+        if save:
+            sv.update(muf=muf, rsf=rsf)
+    elif mode == ops.F32:
+        Fm = X
+    else:
+        Fm = E(M, D)
+        ops.scale_cast(mode, X, None, Fm)
+    Co = module.output_channels
+    Pm = E(M, Co * P * P)
+    ops.gemm_nt(mode, Fm, W(head_w), Pm, bias=head_b.detach())           # mask_tracker.py:113
+    stp = module.track_map_stride if module.track_map_stride > 1 else 1
+    h, w = module.frame_height // stp, module.frame_width // stp
+    pooled = E(B * T, Co, h, w, dtype=f32)
+    ops.unpatchify_pool_fwd(mode, Pm, B * T, g['Hp'], g['Wp'], P, Co, stp, pooled)
+    out_mask = E(B, Co, T, module.frame_height, module.frame_width, dtype=f32)
+    bilinear = (module.track_map_resize == 'bilinear') and stp > 1
+    ops.upsample_fwd(pooled, B, T, Co, h, w, stp, bilinear, out_mask)
+    if module.flag_channels > 0:
+        flags = E(B, T, module.flag_channels, dtype=f32)
+        ops.flags_fwd(feat32, B * T, S, params[nb + 4].detach(), params[nb + 5].detach(), flags)   # mask_tracker.py:135-137
+    else:
+        flags = torch.zeros(0, device=dev)
+    if save:
+        sv.update(X_final=X, Fm=Fm, feat32=feat32, stp=stp, bilinear=bilinear, h=h, w=w)
+    return out_mask, flags, sv
+
+
+def run_backward(module, sv, params, d_mask, d_flags):
+    mode = module.mode
+    dt = ops.tdtype(mode)
+    g = sv['g']
+    B, T, S, D, M, P, heads = g['B'], g['T'], g['S'], g['D'], g['M'], g['P'], g['heads']
+    dev = sv['X_final'].device
+    ca = module.causal_attention
+    use_cls = ca in (0, 1)
+    f32 = torch.float32
+    mask0 = sv['mask0']
+
+    def E(*shape, dtype=dt):
+        return torch.empty(*shape, dtype=dtype, device=dev)
+
+    Wt = lambda p: _get_weight(module, p, True)[1]
+    grads = [None] * len(params)
+
+    def galloc(idx):
+        grads[idx] = torch.empty_like(params[idx], dtype=f32)
+        return grads[idx]
+
+    def linear_bwd(idx_w, dY, Xin):
+        """dW, db of a Linear whose output-gradient operand is dY [M,N] and input operand Xin [M,K]."""
+        dW = galloc(idx_w); db = galloc(idx_w + 1)
+        ops.gemm_tn(mode, dY, Xin, dW.reshape(dW.shape[0], -1), bias_grad=db)
+
+    nb = 5 + module.network_depth * _BLOCK_PARAMS
+    Co = module.output_channels
+    # ---- mask head backward (mask_tracker.py:113-132)
+    if d_mask is None:
+        d_mask = torch.zeros(B, Co, T, module.frame_height, module.frame_width, dtype=f32, device=dev)
+    d_mask = d_mask.to(f32).contiguous()
+    dpooled = E(B * T, Co, sv['h'], sv['w'], dtype=f32)
+    ops.upsample_bwd(d_mask, B, T, Co, sv['h'], sv['w'], sv['stp'], sv['bilinear'], dpooled)
+    dPm = E(M, Co * P * P)
+    ops.unpatchify_pool_bwd(mode, dpooled, B * T, g['Hp'], g['Wp'], P, Co, sv['stp'], dPm)
+    linear_bwd(nb + 2, dPm, sv['Fm'])
+    have_flags = module.flag_channels > 0 and d_flags is not None and d_flags.numel() > 0
+    # gradient w.r.t. the features that feed both heads, always f32: dFeat = dPm . Whead (+ flags adjoint)
+    dFeat = E(M, D, dtype=f32)
+    ops.gemm_nt(mode, dPm, Wt(params[nb + 2]), dFeat)
+    if module.flag_channels > 0 and have_flags:
+        # flags head adjoint (F x D, once per step; only the plugin path ever asks for it, pipeline.py:238)
+        df = d_flags.to(f32).reshape(B * T, -1)
+        meanf = sv['feat32'].reshape(B * T, S, D)[:, 1:, :].float().mean(dim=1)
+        grads[nb + 4] = df.t() @ meanf
+        grads[nb + 5] = df.sum(0)
+        dmean = (df @ params[nb + 4].detach()) / float(S - 1)
+        dFeat.reshape(B * T, S, D)[:, 1:, :] += dmean[:, None, :]
+    # (without a flags gradient flag_post_linear.* keep grad None, like the reference where pipeline.py:157 drops them)
+    if module.norm_embeddings:
+        dX = E(M, D, dtype=f32)
+        ops.layernorm_bwd(ops.F32, dFeat, sv['X_final'], sv['muf'], sv['rsf'], params[nb].detach(), None, dX, galloc(nb), galloc(nb + 1))
+    else:
+        dX = dFeat     # model.norm takes no part when norm_embeddings is False (vision_tf.py:152): its grads stay None
+    if module.grad_hook is not None:
+        module.grad_hook('head', [grads[j] for j in range(nb, len(params))])
+
+    shape_attn = ops.attn_shape(mode, B, T, S, D, heads, ca)
+    dR3 = dX
+    for i in reversed(range(module.network_depth)):
+        o = 5 + i * _BLOCK_PARAMS
+        q = params[o: o + _BLOCK_PARAMS]
+        st = sv['blocks'][i]
+        dp = sv['dps'][i]
+        Hd = q[16].shape[0]
+        # ---- mlp
+        G3 = E(M, D)
+        ops.scale_cast(mode, dR3, dp['m'], G3)
+        dpre = E(M, Hd)
+        ops.gemm_nt(mode, G3, Wt(q[18]), dpre, act=ACT_DGELU, aux=st['pre'])
+        linear_bwd(o + 18, G3, st['H'])
+        dWn = E(M, D)
+        ops.gemm_nt(mode, dpre, Wt(q[16]), dWn)
+        linear_bwd(o + 16, dpre, st['Wn'])
+        dR2 = E(M, D, dtype=f32)
+        ops.layernorm_bwd(mode, dWn, st['R2'], st['mu2'], st['rs2'], q[14].detach(), dR3, dR2, galloc(o + 14), galloc(o + 15))
+        del G3, dpre, dWn
+        # ---- spatial
+        if use_cls:
+            ops.cls_merge(dR2, B, T, S, 1 if ca == 1 else 0, backward=True)
+        G2 = E(M, D)
+        ops.scale_cast(mode, dR2, st['rs_s'], G2)
+        dO2 = E(M, D)
+        ops.gemm_nt(mode, G2, Wt(q[12]), dO2)
+        linear_bwd(o + 12, G2, st['O_s'])
+        dQKV2 = E(M, 3 * D)
+        ops.attn_bwd(shape_attn, True, st['QKV_s'], st['O_s'], dO2, st['lse_s'], dQKV2)
+        dV = E(M, D)
+        ops.gemm_nt(mode, dQKV2, Wt(q[10]), dV)
+        linear_bwd(o + 10, dQKV2, st['V'])
+        dR1 = E(M, D, dtype=f32)
+        ops.layernorm_bwd(mode, dV, st['R1'], st['mu1'], st['rs1'], q[8].detach(), dR2, dR1, galloc(o + 8), galloc(o + 9))
+        del G2, dO2, dQKV2, dV
+        # ---- temporal
+        G1 = E(M, D)
+        ops.scale_cast(mode, dR1, mask0, G1)
+        dPj = E(M, D)
+        ops.gemm_nt(mode, G1, Wt(q[6]), dPj, row_scale=dp['t'])
+        linear_bwd(o + 6, G1, st['Pj'])
+        dO = E(M, D)
+        ops.gemm_nt(mode, dPj, Wt(q[4]), dO)
+        linear_bwd(o + 4, dPj, st['O_t'])
+        dQKV = E(M, 3 * D)
+        ops.attn_bwd(shape_attn, False, st['QKV_t'], st['O_t'], dO, st['lse_t'], dQKV)
+        dU = E(M, D)
+        ops.gemm_nt(mode, dQKV, Wt(q[2]), dU)
+        linear_bwd(o + 2, dQKV, st['U'])
+        dR0 = E(M, D, dtype=f32)
+        ops.layernorm_bwd(mode, dU, st['R0'], st['mu0'], st['rs0'], q[0].detach(), dR1, dR0, galloc(o), galloc(o + 1))
+        dR3 = dR0
+        sv['blocks'][i] = None   # free this block's activations
+        if module.grad_hook is not None:
+            module.grad_hook(i, [grads[j] for j in range(o, o + _BLOCK_PARAMS)])
+
+    # ---- embeddings + patch embed backward
+    gX = dR3
+    dpos_eff = E(S, D, dtype=f32); dtime_eff = E(T, D, dtype=f32)
+    ops.embed_bwd(gX, B, T, S, dpos_eff, dtime_eff)
+    grads[0] = dpos_eff[0].reshape(1, 1, D).clone()
+    if sv['pos_idx'] is None:
+        grads[1] = dpos_eff.reshape(1, S, D)
+    else:
+        gp = torch.zeros_like(params[1], dtype=f32)
+        gp[0].index_add_(0, sv['pos_idx'], dpos_eff)
+        grads[1] = gp
+    if sv['time_idx'] is None:
+        grads[2] = dtime_eff.reshape(1, T, D)
+    else:
+        gt = torch.zeros_like(params[2], dtype=f32)
+        gt[0].index_add_(0, sv['time_idx'], dtime_eff)
+        grads[2] = gt
+    Gpe = E(M, D)
+    ops.scale_cast(mode, gX, mask0, Gpe)
+    dWpe = galloc(3)
+    ops.gemm_tn(mode, Gpe, sv['A_pe'], dWpe.reshape(D, -1))
+    grads[4] = dtime_eff.sum(0)            # bias gradient = sum over all patch rows
+    if module.grad_hook is not None:
+        module.grad_hook('embed', [grads[j] for j in range(0, 5)])
+    return grads
+
+
+class SeekerFunction(torch.autograd.Function):
+    """(module, rgb, query_mask, *params) -> (output_mask, output_flags)."""
+
+    @staticmethod
+    def forward(ctx, module, rgb, qm, *params):
+        need = any(ctx.needs_input_grad[3:])
+        out_mask, flags, sv = run_forward(module, rgb, qm, params, save=need)
+        ctx.module = module
+        ctx.sv = sv
+        ctx.params = params
+        return out_mask, flags
+
+    @staticmethod
+    def backward(ctx, d_mask, d_flags):
+        if ctx.sv is None:
+            raise ops.L.TcowError('backward called on a forward that did not save activations')
+        grads = run_backward(ctx.module, ctx.sv, ctx.params, d_mask, d_flags)
+        ctx.sv = None
+        out = []
+        for p, gr, need in zip(ctx.params, grads, ctx.needs_input_grad[3:]):
+            out.append(gr.reshape(p.shape) if (need and gr is not None) else None)
+        return (None, None, None, *out)

@@ -1,0 +1,162 @@
+"""Thin tensor-level wrappers over the libtcow_hip C ABI (include/tcow_hip.h).
+
+PyTorch is used here only for device memory and streams: every function takes CUDA(HIP) tensors, passes raw
+device pointers plus the current stream to the library and returns.  There is no fallback path: a missing or
+failing library raises TcowError.
+"""
+import ctypes
+
+import torch
+
+from . import _lib as L
+
+F32, BF16 = L.TCOW_F32, L.TCOW_BF16
+ACT_NONE, ACT_GELU, ACT_DGELU = L.ACT_NONE, L.ACT_GELU, L.ACT_DGELU
+
+
+def tdtype(mode):
+    return torch.bfloat16 if mode == BF16 else torch.float32
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return t.data_ptr() if t is not None else None
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise L.TcowError('libtcow_hip kernels need CUDA/HIP tensors (no CPU fallback on this path)')
+
+
+def gemm_nt(mode, A, W, out, bias=None, row_scale=None, resid=None, act=ACT_NONE, aux=None):
+    """out[M,N] = epilogue(A[M,K] @ W[N,K]^T); see tcow_gemm_nt. `out` dtype f32 or the mode's dtype."""
+    _need_cuda(A, W, out)
+    M, K = A.shape
+    N = W.shape[0]
+    a = L.GemmArgs(M, N, K, mode, A.data_ptr(), A.stride(0), W.data_ptr(), W.stride(0), out.data_ptr(), out.stride(0),
+                   1 if out.dtype == torch.float32 else 0, _p(bias), _p(row_scale), _p(resid),
+                   resid.stride(0) if resid is not None else 0, act, _p(aux), aux.stride(0) if aux is not None else 0)
+    L.check(L.lib().tcow_gemm_nt(_stream(), ctypes.byref(a)), 'tcow_gemm_nt')
+    return out
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes, device, tag='default'):
+    """Grow-only scratch buffer per (device, tag); kernels on one stream run in order so reuse is safe."""
+    key = (str(device), tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def gemm_tn(mode, dY, X, dW, bias_grad=None, accumulate=False):
+    """dW[N,K] (+)= dY[M,N]^T @ X[M,K]; bias_grad[N] (+)= column sums of dY."""
+    _need_cuda(dY, X, dW)
+    M, N = dY.shape
+    K = X.shape[1]
+    lib = L.lib()
+    nbytes = lib.tcow_gemm_tn_workspace_bytes(M, N, K)
+    ws = workspace(nbytes, dY.device, 'tn')
+    L.check(lib.tcow_gemm_tn(_stream(), mode, M, N, K, dY.data_ptr(), dY.stride(0), X.data_ptr(), X.stride(0), dW.data_ptr(),
+                             dW.stride(0), _p(bias_grad), int(accumulate), ws.data_ptr(), ws.numel()), 'tcow_gemm_tn')
+    return dW
+
+
+def layernorm_fwd(mode, x, gamma, beta, out, mean=None, rstd=None, eps=1e-6):
+    rows, D = x.shape
+    L.check(L.lib().tcow_layernorm_fwd(_stream(), mode, rows, D, x.data_ptr(), x.stride(0), gamma.data_ptr(), beta.data_ptr(), eps,
+                                       out.data_ptr(), out.stride(0), _p(mean), _p(rstd)), 'tcow_layernorm_fwd')
+    return out
+
+
+def layernorm_bwd(mode, dy, x, mean, rstd, gamma, dres, dx, dgamma=None, dbeta=None, accumulate=False):
+    rows, D = x.shape
+    lib = L.lib()
+    ws = workspace(lib.tcow_layernorm_bwd_workspace_bytes(D), x.device, 'ln')
+    L.check(lib.tcow_layernorm_bwd(_stream(), mode, rows, D, dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), mean.data_ptr(),
+                                   rstd.data_ptr(), gamma.data_ptr(), _p(dres), dres.stride(0) if dres is not None else 0, dx.data_ptr(),
+                                   dx.stride(0), _p(dgamma), _p(dbeta), int(accumulate), ws.data_ptr(), ws.numel()), 'tcow_layernorm_bwd')
+    return dx
+
+
+def attn_shape(mode, B, T, S, D, heads, causal):
+    return L.AttnShape(B, T, S, D, heads, int(causal), mode)
+
+
+def attn_fwd(shape, spatial, qkv, out, lse=None):
+    fn = L.lib().tcow_attn_spatial_fwd if spatial else L.lib().tcow_attn_temporal_fwd
+    L.check(fn(_stream(), ctypes.byref(shape), qkv.data_ptr(), out.data_ptr(), _p(lse)), 'tcow_attn_fwd')
+    return out
+
+
+def attn_bwd(shape, spatial, qkv, out, dout, lse, dqkv):
+    lib = L.lib()
+    ws = workspace(lib.tcow_attn_bwd_workspace_bytes(ctypes.byref(shape)), qkv.device, 'attn')
+    fn = lib.tcow_attn_spatial_bwd if spatial else lib.tcow_attn_temporal_bwd
+    L.check(fn(_stream(), ctypes.byref(shape), qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(),
+               ws.data_ptr(), ws.numel()), 'tcow_attn_bwd')
+    return dqkv
+
+
+def im2col(mode, rgb, query, P, pretrained_norm, out):
+    B, _, T, H, W = rgb.shape
+    L.check(L.lib().tcow_im2col(_stream(), mode, B, T, H, W, P, rgb.data_ptr(), query.data_ptr(), int(pretrained_norm), out.data_ptr()), 'tcow_im2col')
+    return out
+
+
+def embed_fwd(x, B, T, S, cls, pos, time_embed):
+    L.check(L.lib().tcow_embed_fwd(_stream(), B, T, S, x.shape[1], x.data_ptr(), cls.data_ptr(), pos.data_ptr(), time_embed.data_ptr()), 'tcow_embed_fwd')
+    return x
+
+
+def embed_bwd(g, B, T, S, dpos, dtime, accumulate=False):
+    L.check(L.lib().tcow_embed_bwd(_stream(), B, T, S, g.shape[1], g.data_ptr(), dpos.data_ptr(), dtime.data_ptr(), int(accumulate)), 'tcow_embed_bwd')
+
+
+def cls_merge(x, B, T, S, mode, backward=False):
+    L.check(L.lib().tcow_cls_merge(_stream(), B, T, S, x.shape[1], x.data_ptr(), mode, int(backward)), 'tcow_cls_merge')
+    return x
+
+
+def unpatchify_pool_fwd(mode, pm, BT, Hp, Wp, P, C, st, pooled):
+    L.check(L.lib().tcow_unpatchify_pool_fwd(_stream(), mode, BT, Hp, Wp, P, C, st, pm.data_ptr(), pooled.data_ptr()), 'tcow_unpatchify_pool_fwd')
+    return pooled
+
+
+def unpatchify_pool_bwd(mode, dpooled, BT, Hp, Wp, P, C, st, dpm):
+    L.check(L.lib().tcow_unpatchify_pool_bwd(_stream(), mode, BT, Hp, Wp, P, C, st, dpooled.data_ptr(), dpm.data_ptr()), 'tcow_unpatchify_pool_bwd')
+    return dpm
+
+
+def upsample_fwd(pooled, B, T, C, h, w, st, bilinear, out):
+    L.check(L.lib().tcow_upsample_fwd(_stream(), B, T, C, h, w, st, int(bilinear), pooled.data_ptr(), out.data_ptr()), 'tcow_upsample_fwd')
+    return out
+
+
+def upsample_bwd(dout, B, T, C, h, w, st, bilinear, dpooled):
+    L.check(L.lib().tcow_upsample_bwd(_stream(), B, T, C, h, w, st, int(bilinear), dout.data_ptr(), dpooled.data_ptr()), 'tcow_upsample_bwd')
+    return dpooled
+
+
+def flags_fwd(x, BT, S, Wf, bf, flags):
+    L.check(L.lib().tcow_flags_fwd(_stream(), BT, S, x.shape[1], Wf.shape[0], x.data_ptr(), Wf.data_ptr(), bf.data_ptr(), flags.data_ptr()), 'tcow_flags_fwd')
+    return flags
+
+
+def scale_cast(mode, src, row_scale, dst):
+    rows, D = src.shape
+    L.check(L.lib().tcow_scale_cast(_stream(), mode, rows, D, src.data_ptr(), src.stride(0), _p(row_scale), dst.data_ptr(), dst.stride(0)), 'tcow_scale_cast')
+    return dst
+
+
+def cast_transpose(mode, W, Wc=None, Wt=None):
+    N, K = W.shape
+    L.check(L.lib().tcow_cast_transpose(_stream(), mode, N, K, W.data_ptr(), _p(Wc), _p(Wt)), 'tcow_cast_transpose')

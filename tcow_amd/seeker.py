@@ -1,0 +1,256 @@
+"""Drop-in `Seeker` / `QueryMaskTracker` for the TCOW hot path, running on libtcow_hip (gfx950).
+
+Mirrors the nn.Module surface of the reference (model/seeker.py:17-25, model/mask_tracker.py:24-142):
+same constructor keywords, `forward(input_frames, query_mask) -> (output_mask, output_flags)`, and the same
+251 state-dict keys / shapes (seeker.tracker_backbone.timesformer.model.*, seeker.tracker_post_linear.*,
+seeker.flag_post_linear.*), so checkpoints (`net_seeker`, train.py:281 / eval/inference.py:52) load with
+strict=True.  The stock nn.Linear / nn.Conv2d / nn.LayerNorm objects below are parameter containers only:
+their forward is never called; all arithmetic runs in the HIP kernels through one autograd.Function whose
+backward is hand-written (no autograd graph inside the model).
+
+precision:
+  'bf16' (default)  bf16 GEMM/attention operands, f32 accumulation, f32 residual stream / LayerNorm / softmax.
+  'fp32'            everything f32 on the exact-f32 MFMA/FMA kernels: the parity mode (mask logits within 1e-3
+                    of the fp32 reference; measured ~1e-5).
+"""
+import math
+from functools import partial
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import TcowError
+
+TIMESFORMER_MEAN = 0.45
+TIMESFORMER_STD = 0.225
+
+
+# ----------------------------------------------------------------------------------------------- containers
+
+def _trunc_normal_(t, std=.02):
+    with torch.no_grad():
+        return nn.init.trunc_normal_(t, mean=0., std=std, a=-2., b=2.)   # vit_utils.py:25-76 defaults a=-2,b=2
+
+
+class _Attention(nn.Module):                     # vit.py:64-76
+    def __init__(self, dim):
+        super().__init__()
+        self.qkv = nn.Linear(dim, dim * 3, bias=True)
+        self.proj = nn.Linear(dim, dim)
+
+
+class _Mlp(nn.Module):                           # vit.py:45-53
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.fc2 = nn.Linear(hidden, dim)
+
+
+class _Block(nn.Module):                         # vit.py:126-153 (divided_space_time)
+    def __init__(self, dim, mlp_ratio):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=1e-6)
+        self.attn = _Attention(dim)
+        self.temporal_norm1 = nn.LayerNorm(dim, eps=1e-6)
+        self.temporal_attn = _Attention(dim)
+        self.temporal_fc = nn.Linear(dim, dim)
+        self.norm2 = nn.LayerNorm(dim, eps=1e-6)
+        self.mlp = _Mlp(dim, int(dim * mlp_ratio))
+
+
+class _PatchEmbed(nn.Module):                    # vit.py:220-233
+    def __init__(self, patch, in_chans, dim):
+        super().__init__()
+        self.proj = nn.Conv2d(in_chans, dim, kernel_size=patch, stride=patch)
+
+
+class _VisionTransformer(nn.Module):             # vit.py:244-306
+    def __init__(self, img_size, patch, in_chans, dim, depth, mlp_ratio, num_frames):
+        super().__init__()
+        self.embed_dim = dim
+        self.patch_embed = _PatchEmbed(patch, in_chans, dim)
+        n_patches = (img_size[0] // patch) * (img_size[1] // patch)
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, n_patches + 1, dim))
+        self.time_embed = nn.Parameter(torch.zeros(1, num_frames, dim))      # stays zero at init (vit.py:268)
+        self.blocks = nn.ModuleList([_Block(dim, mlp_ratio) for _ in range(depth)])
+        self.norm = nn.LayerNorm(dim, eps=1e-6)
+        _trunc_normal_(self.pos_embed)
+        _trunc_normal_(self.cls_token)
+        for m in self.modules():                                             # vit.py:299-306
+            if isinstance(m, nn.Linear):
+                _trunc_normal_(m.weight)
+                nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.LayerNorm):
+                nn.init.constant_(m.bias, 0)
+                nn.init.constant_(m.weight, 1.0)
+        # vit.py:289-297: the loop counts the ModuleList itself as "Block 0", so every real block is zeroed.
+        for blk in self.blocks:
+            nn.init.constant_(blk.temporal_fc.weight, 0)
+            nn.init.constant_(blk.temporal_fc.bias, 0)
+
+
+class _TimeSformer(nn.Module):                   # vit.py:416-459
+    def __init__(self, **kw):
+        super().__init__()
+        self.model = _VisionTransformer(**kw)
+
+
+class _Backbone(nn.Module):                      # vision_tf.py:27-66
+    def __init__(self, **kw):
+        super().__init__()
+        self.timesformer = _TimeSformer(**kw)
+        self.output_feature_dim = self.timesformer.model.embed_dim
+
+
+_DEPTH_GEOMETRY = {12: (768, 12), 18: (896, 14), 24: (1024, 16)}      # vit.py:424-449
+
+
+# ----------------------------------------------------------------------------------------------- the module
+
+class QueryMaskTracker(nn.Module):
+    """mask_tracker.py:24-142.  Extra keywords (not in the reference): `embed_dim`, `num_heads` to build
+    geometries other than depth 12/18/24 (the reference raises for those, vit.py:449), `precision`."""
+
+    def __init__(self, logger, num_total_frames=24, num_visible_frames=16, frame_height=224, frame_width=288,
+                 tracker_pretrained=False, attention_type='divided_space_time', patch_size=16, causal_attention=False,
+                 norm_embeddings=False, drop_path_rate=0.1, network_depth=12, track_map_stride=4,
+                 track_map_resize='bilinear', query_channels=1, output_channels=3, flag_channels=3,
+                 embed_dim=None, num_heads=None, precision='bf16'):
+        super().__init__()
+        self.logger = logger
+        self.num_total_frames = num_total_frames
+        self.num_visible_frames = num_visible_frames
+        self.frame_height = frame_height
+        self.frame_width = frame_width
+        self.attention_type = attention_type
+        self.patch_size = patch_size
+        self.causal_attention = int(causal_attention)
+        self.norm_embeddings = bool(norm_embeddings)
+        self.drop_path_rate = drop_path_rate
+        self.network_depth = network_depth
+        self.track_map_stride = track_map_stride
+        self.track_map_resize = track_map_resize
+        self.query_channels = query_channels
+        self.output_channels = output_channels
+        self.flag_channels = flag_channels
+        self.input_channels = 3 + query_channels
+        self.set_precision(precision)
+
+        self.pretrained_path = ''                                         # mask_tracker.py:55-67
+        if isinstance(tracker_pretrained, bool):
+            self.tracker_pretrained = tracker_pretrained
+        elif isinstance(tracker_pretrained, str):
+            if tracker_pretrained.lower() in ['1', 'y', 'yes', 't', 'true']:
+                self.tracker_pretrained = True
+            elif len(tracker_pretrained) <= 5:
+                self.tracker_pretrained = False
+            else:
+                self.tracker_pretrained = True
+                self.pretrained_path = tracker_pretrained
+        else:
+            raise ValueError(f'Invalid tracker_pretrained value: {tracker_pretrained}.')
+        if logger is not None:
+            logger.info(f'(QueryMaskTracker) tracker_pretrained: {self.tracker_pretrained} '
+                        f'pretrained_path: {self.pretrained_path}')
+
+        if attention_type != 'divided_space_time':
+            raise TcowError(f"attention_type='{attention_type}' is not on the MI355X hot path "
+                            "(only divided_space_time; vit.py:159-163 is out of scope)")
+        if query_channels != 1:
+            raise TcowError('query_channels must be 1 (mask_tracker.py:105)')
+        if embed_dim is None or num_heads is None:
+            if network_depth not in _DEPTH_GEOMETRY:
+                raise ValueError(f'Invalid network depth {network_depth}, must be one of 12, 18, 24.')  # vit.py:449
+            embed_dim, num_heads = _DEPTH_GEOMETRY[network_depth]
+        if embed_dim != num_heads * 64:
+            raise TcowError(f'head_dim must be 64 (embed_dim={embed_dim}, num_heads={num_heads})')
+        self.embed_dim, self.num_heads = embed_dim, num_heads
+        assert frame_height % patch_size == 0                             # mask_tracker.py:89-90
+        assert frame_width % patch_size == 0
+        if track_map_stride > 1 and patch_size % track_map_stride != 0:
+            raise TcowError('track_map_stride must divide patch_size')
+        if track_map_resize not in ('bilinear', 'nearest'):
+            raise TcowError(f'unsupported track_map_resize {track_map_resize}')
+
+        self.tracker_backbone = _Backbone(img_size=(frame_height, frame_width), patch=patch_size,
+                                          in_chans=self.input_channels, dim=embed_dim, depth=network_depth,
+                                          mlp_ratio=4, num_frames=num_total_frames)
+        self.use_feature_dim = embed_dim
+        self.tracker_post_linear = nn.Linear(embed_dim, output_channels * patch_size * patch_size)
+        if flag_channels > 0:
+            self.flag_post_linear = nn.Linear(embed_dim, flag_channels)
+        if self.tracker_pretrained:
+            from .checkpoint import load_pretrained_vit
+            load_pretrained_vit(self, self.pretrained_path, logger)
+        self._wcache = {}
+        self.forced_drop_masks = None     # tests can inject explicit DropPath keep masks
+        self.grad_hook = None             # optional callable(bucket_name, tensors) fired during backward (DDP)
+
+    # ---- configuration helpers
+    def set_precision(self, precision):
+        if precision not in ('bf16', 'fp32'):
+            raise ValueError("precision must be 'bf16' or 'fp32'")
+        self.precision = precision
+        self.mode = ops.BF16 if precision == 'bf16' else ops.F32
+        self._wcache = {}
+        return self
+
+    def _apply(self, fn, *a, **k):
+        self._wcache = {}
+        return super()._apply(fn, *a, **k)
+
+    @property
+    def vit(self):
+        return self.tracker_backbone.timesformer.model
+
+    def geometry(self, B):
+        P = self.patch_size
+        Hp, Wp = self.frame_height // P, self.frame_width // P
+        N = Hp * Wp
+        return dict(B=B, T=self.num_total_frames, Hp=Hp, Wp=Wp, N=N, S=N + 1, D=self.embed_dim, heads=self.num_heads,
+                    P=P, M=B * self.num_total_frames * (N + 1))
+
+    def param_list(self):
+        """Fixed order of the parameters the autograd.Function sees."""
+        v = self.vit
+        ps = [v.cls_token, v.pos_embed, v.time_embed, v.patch_embed.proj.weight, v.patch_embed.proj.bias]
+        for b in v.blocks:
+            ps += [b.temporal_norm1.weight, b.temporal_norm1.bias, b.temporal_attn.qkv.weight, b.temporal_attn.qkv.bias,
+                   b.temporal_attn.proj.weight, b.temporal_attn.proj.bias, b.temporal_fc.weight, b.temporal_fc.bias,
+                   b.norm1.weight, b.norm1.bias, b.attn.qkv.weight, b.attn.qkv.bias, b.attn.proj.weight, b.attn.proj.bias,
+                   b.norm2.weight, b.norm2.bias, b.mlp.fc1.weight, b.mlp.fc1.bias, b.mlp.fc2.weight, b.mlp.fc2.bias]
+        ps += [v.norm.weight, v.norm.bias, self.tracker_post_linear.weight, self.tracker_post_linear.bias]
+        if self.flag_channels > 0:
+            ps += [self.flag_post_linear.weight, self.flag_post_linear.bias]
+        return ps
+
+    # ---- forward
+    def forward(self, input_frames, query_mask):
+        """mask_tracker.py:92-142: (B,3,T,Hf,Wf), (B,1,T,Hf,Wf) -> (B,C,T,Hf,Wf) logits, (B,T,F) flags."""
+        (B, _, T, Hf, Wf) = input_frames.shape
+        assert query_mask.shape[1] == 1                                   # mask_tracker.py:105
+        assert T == self.num_total_frames                                 # vision_tf.py:96
+        assert Hf == self.frame_height and Wf == self.frame_width         # vision_tf.py:97 (W' check)
+        if not input_frames.is_cuda:
+            raise TcowError('Seeker (tcow_amd) runs on the GPU only: move inputs and module to cuda')
+        rgb = input_frames.to(torch.float32).contiguous()                 # mask_tracker.py:103-104 (inputs not mutated)
+        qm = query_mask.to(torch.float32).contiguous()
+        from .engine import SeekerFunction
+        out_mask, out_flags = SeekerFunction.apply(self, rgb, qm, *self.param_list())
+        if self.flag_channels <= 0:
+            out_flags = None
+        return (out_mask, out_flags)
+
+
+class Seeker(nn.Module):
+    """model/seeker.py:17-25."""
+
+    def __init__(self, logger, **kwargs):
+        super().__init__()
+        self.logger = logger
+        self.seeker = QueryMaskTracker(logger, **kwargs)
+
+    def forward(self, *args):
+        return self.seeker(*args)
