@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""Benchmark of the TCOW Seeker training step on MI355X (contract: see the build prompt / DESIGN.md section 4).
+
+  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" on a rank = one synthetic clip (T=30, 240x320, BASELINE.json configs[1]) x num_queries=3 query forwards
+(batched), the mask loss, one backward, gradient all-reduce (RCCL, overlapped with backward), grad-clip 0.3 and
+an AdamW step -- mirroring pipeline.py:134-174 + train.py:89-102.  value = world_size * clips_per_rank / step time.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+PEAK_BF16_TFLOPS = 2500.0     # dense MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_F32_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=8)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--queries', type=int, default=3)
+    ap.add_argument('--frames', type=int, default=30)
+    ap.add_argument('--height', type=int, default=240)
+    ap.add_argument('--width', type=int, default=320)
+    ap.add_argument('--depth', type=int, default=12)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-budget-s', type=float, default=25.0)
+    return ap.parse_args()
+
+
+class KernelTimer:
+    """HIP-event timing of every GEMM launch (the dominant kernel) on the stream it is launched on."""
+
+    def __init__(self):
+        self.recs = []
+        self.enabled = False
+
+    def wrap(self, ops):
+        orig = ops.gemm_nt
+        timer = self
+
+        def timed(mode, A, W, out, **kw):
+            if not timer.enabled:
+                return orig(mode, A, W, out, **kw)
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = orig(mode, A, W, out, **kw)
+            e1.record()
+            timer.recs.append((e0, e1, 2.0 * A.shape[0] * W.shape[0] * A.shape[1]))
+            return r
+        ops.gemm_nt = timed
+
+    def summary(self):
+        if not self.recs:
+            return None
+        ms = sum(a.elapsed_time(b) for a, b, _ in self.recs)
+        fl = sum(f for _, _, f in self.recs)
+        return dict(launches=len(self.recs), avg_us=ms * 1e3 / len(self.recs), flops_per_launch=fl / len(self.recs), tflops=fl / (ms * 1e-3) / 1e12)
+
+
+def cpu_baseline(cfg, budget_s):
+    """Times the oracle (our CPU port of the reference path, oracle/seeker_oracle.py) on this host's cores:
+    one query forward at the benchmark geometry; if it fits the budget also one forward+backward."""
+    from oracle import seeker_oracle as so
+    from tcow_amd import synth
+    cores = os.cpu_count() or 1
+    threads = min(cores, 64)
+    torch.set_num_threads(threads)
+    sd = so.to_torch_state_dict(synth.make_state_dict(cfg, 900))
+    T, H, W = cfg['num_total_frames'], cfg['frame_height'], cfg['frame_width']
+    clip = synth.make_clip(1, T, H, W, seed=900)
+    rgb = torch.from_numpy(clip['rgb']); qm = torch.from_numpy(synth.make_query_mask(clip, 0, 0))
+    with torch.no_grad():
+        t0 = time.time(); so.seeker_forward(sd, cfg, rgb, qm); t_fwd = time.time() - t0
+    sample = f'1 query forward (B=1) = {t_fwd:.2f} s'
+    t_fb = None
+    if t_fwd * 4 < budget_s:
+        for v in sd.values():
+            v.requires_grad_(True)
+        t0 = time.time()
+        om, fl = so.seeker_forward(sd, cfg, rgb, qm)
+        (om.square().mean() + fl.square().mean()).backward()
+        t_fb = time.time() - t0
+        sample += f', 1 query forward+backward = {t_fb:.2f} s'
+    per_query = t_fb if t_fb is not None else 3.0 * t_fwd     # bwd ~ 2x fwd when not measured
+    nq = 3
+    return dict(value=1.0 / (nq * per_query), unit='clips/s', cores=threads, kind='port',
+                sample=sample + f'; clips/s = 1 / ({nq} queries x {"measured" if t_fb else "3 x forward"} per-query time); '
+                f'optimizer step not included')
+
+
+def main():
+    args = parse()
+    from tcow_amd import ddp, flops, ops, synth
+    from tcow_amd.seeker import Seeker
+    rank, local_rank, world = ddp.init_distributed()
+    assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+
+    cfg = synth.seeker_config(num_total_frames=args.frames, frame_height=args.height, frame_width=args.width,
+                              depth=args.depth, causal_attention=1)
+    net = Seeker(None, num_total_frames=args.frames, frame_height=args.height, frame_width=args.width,
+                 tracker_pretrained=False, causal_attention=1, drop_path_rate=0.1, network_depth=args.depth,
+                 precision=args.precision)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg, 900).items()}, strict=True)
+    net = net.to(dev).train()
+    ddp.broadcast_parameters(net)
+    params = [p for p in net.parameters()]
+    try:
+        opt = torch.optim.AdamW(params, lr=1e-4, fused=True)               # train.py:239-241, args.py:108
+    except Exception:
+        opt = torch.optim.AdamW(params, lr=1e-4, foreach=True)
+    sync = ddp.GradSync(world)
+    net.seeker.grad_hook = sync
+
+    # synthetic Kubric-shaped clip for this rank: 1 clip, Qs queries (instances 0..Qs-1), query_time 0
+    Qs = args.queries
+    clip = synth.make_clip(1, args.frames, args.height, args.width, seed=ddp.shard_seed(900, rank), n_objects=max(Qs, 4))
+    rgb = torch.from_numpy(clip['rgb']).to(dev).expand(Qs, -1, -1, -1, -1).contiguous()
+    qm = torch.cat([torch.from_numpy(synth.make_query_mask(clip, q, 0)) for q in range(Qs)], 0).to(dev)
+    div = torch.from_numpy(clip['div_segm']).to(dev).float()               # (1, K, T, H, W) amodal masks
+    target = torch.zeros(Qs, 3, args.frames, args.height, args.width, device=dev)
+    for q in range(Qs):
+        target[q, 0] = div[0, q]                                           # snitch channel; occluder / container empty
+    from tcow_amd.loss import mask_loss
+
+    timer = KernelTimer(); timer.wrap(ops)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out_mask, _ = net(rgb, qm)                                         # (Qs,3,T,H,W): the Qs sequential forwards of pipeline.py:134, batched
+        loss = mask_loss(out_mask, target)
+        loss.backward()
+        sync.finish()
+        torch.nn.utils.clip_grad_norm_(params, 0.3)                        # train.py:99-101
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = tt.item()
+    ms_per_step = dt / args.steps * 1e3
+    clips_per_s = world * 1.0 / (dt / args.steps)
+
+    if rank == 0:
+        g = net.seeker.geometry(Qs)
+        fl = flops.seeker_forward_flops(1, g['T'], g['Hp'], g['Wp'], g['D'], g['heads'], args.depth)
+        ks = timer.summary()
+        peak = PEAK_BF16_TFLOPS if args.precision == 'bf16' else PEAK_F32_TFLOPS
+        roof = dict(bound='mfma', kernel='gemm_nt_bf16_kernel' if args.precision == 'bf16' else 'gemm_f32_kernel',
+                    achieved=ks['tflops'], peak=peak, unit='TFLOP/s', frac=ks['tflops'] / peak, traffic=None,
+                    launches_per_step=ks['launches'] / args.steps, avg_launch_us=ks['avg_us'], flops_per_launch=ks['flops_per_launch'])
+        step_tflops = 3.0 * Qs * fl['total'] / (ms_per_step * 1e-3) / 1e12
+        res = dict(metric='train clips/sec (T=30, 240x320)', value=clips_per_s, unit='clips/s', n_gpus=world, steps=args.steps,
+                   warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True, scaling='weak', vs_baseline=None,
+                   dtype='bf16' if args.precision == 'bf16' else 'f32', data='synthetic',
+                   config=dict(workload=f'TCOW Seeker train step: T={args.frames} {args.height}x{args.width} patch16, {args.depth}-layer divided '
+                               f'space-time ViT (D={g["D"]}), num_queries={Qs}, causal_attention=1, 1 clip/GPU',
+                               clips_per_gpu=1, num_queries=Qs, parallelism=f'dp{world}', optimizer='AdamW lr 1e-4, clip 0.3',
+                               loss='weighted BCE on 3 mask channels'),
+                   query_forwards_per_s=clips_per_s * Qs, step_model_tflops=step_tflops, step_mfma_frac=step_tflops / peak,
+                   final_loss=float(loss.detach()), roofline=roof)
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                res['cpu_baseline'] = cpu_baseline(cfg, args.cpu_budget_s)
+            except Exception as e:  # the baseline is a reported aside; never fail the bench line over it
+                res['cpu_baseline'] = dict(value=None, unit='clips/s', cores=os.cpu_count(), kind='port', sample=f'failed: {e}')
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -78,6 +78,9 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise TcowError(f'{LIB_PATH} not found: build it with `make` (or __graft_entry__.build()); '
                             'the Seeker HIP path has no fallback')
+        # torch bundles its own libamdhip64; it must be in the process first so that this library binds to the
+        # SAME HIP runtime (otherwise device pointers / streams of one runtime are foreign to the other).
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         L.tcow_last_error.restype = ctypes.c_char_p
         L.tcow_version.restype = ctypes.c_int

@@ -1,0 +1,77 @@
+"""One-process-per-GPU data parallelism for the Seeker step: gradient all-reduce over RCCL (xGMI), overlapped
+with the backward pass.
+
+The reference uses single-process torch.nn.DataParallel (train.py:222-223): per step it re-broadcasts all
+122 M parameters, gathers every replica's (B,Qs,3,T,H,W) outputs to GPU 0 and reduces gradients there.  Clips
+are independent through the model and the per-example loss (pipeline.py:50-83), and the batch loss is the mean
+over replicas (loss.py:356-369), so the MI355X counterpart is plain gradient averaging:
+
+  * each rank owns B clips (1 in BASELINE configs[2]) and runs forward / loss / backward locally;
+  * the hand-written backward (engine.run_backward) finishes one gradient bucket at a time -- the output heads,
+    then transformer blocks depth-1 .. 0 (20 tensors, ~9.45 M f32 = 37.8 MB each at ViT-B), then the embeddings --
+    each as ONE flat f32 buffer; `GradSync` launches an asynchronous all-reduce on the bucket the moment it is
+    complete, so communication of block i overlaps the backward compute of blocks i-1 .. 0;
+  * xGMI is point-to-point (7 links x ~153 GB/s per GPU): 37.8 MB buckets keep every ring step well above the
+    latency floor while leaving 13 collectives in flight behind ~2/3 of the backward;
+  * parameters the step does not touch (model.norm.*, flag_post_linear.* in Kubric training) have no gradient on
+    any rank and are simply not part of any bucket -- no unused-parameter handshake is needed.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend=None):
+    """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run contract). Returns (rank, local_rank, world)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'     # 'nccl' is RCCL on ROCm
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        if backend == 'nccl':
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+class GradSync:
+    """Bucketed, overlapped gradient averaging. Attach with `module.grad_hook = sync`; call `finish()` after
+    backward (before clipping / the optimizer step)."""
+
+    def __init__(self, world_size=None, group=None):
+        self.group = group
+        self.world = world_size if world_size is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
+        self.pending = []
+        self.bytes = 0
+        self.launched = []
+
+    def __call__(self, name, flat):
+        if self.world <= 1 or flat.numel() == 0:
+            return
+        self.launched.append(name)
+        self.bytes += flat.numel() * flat.element_size()
+        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.pending.append((work, flat))
+
+    def finish(self):
+        for work, flat in self.pending:
+            work.wait()                      # makes the current stream wait for the collective
+            flat.mul_(1.0 / self.world)      # sum -> mean (loss.py:356-369 averages the per-replica losses)
+        self.pending = []
+
+
+def broadcast_parameters(module, src=0):
+    """One-time weight sync at start (DataParallel re-broadcasts every step; DDP does not need to)."""
+    if not dist.is_initialized() or dist.get_world_size() <= 1:
+        return
+    for p in module.parameters():
+        dist.broadcast(p.data, src=src)
+
+
+def shard_seed(base_seed, rank):
+    """Per-rank data seed (train.py:170-174 seeds 900; each rank draws different clips)."""
+    return int(base_seed) + int(rank)

@@ -253,8 +253,19 @@ def run_backward(module, sv, params, d_mask, d_flags):
     Wt = lambda p: _get_weight(module, p, True)[1]
     grads = [None] * len(params)
 
+    def bucket(indices):
+        """One flat f32 buffer per gradient bucket (a transformer block, the heads, the embeddings): the views
+        become the parameters' gradients and the flat buffer is what the data-parallel all-reduce moves."""
+        total = sum(params[j].numel() for j in indices)
+        flat = torch.empty(total, dtype=f32, device=dev)
+        off = 0
+        for j in indices:
+            n = params[j].numel()
+            grads[j] = flat[off:off + n].view(params[j].shape)
+            off += n
+        return flat
+
     def galloc(idx):
-        grads[idx] = torch.empty_like(params[idx], dtype=f32)
         return grads[idx]
 
     def linear_bwd(idx_w, dY, Xin):
@@ -264,6 +275,9 @@ def run_backward(module, sv, params, d_mask, d_flags):
 
     nb = 5 + module.network_depth * _BLOCK_PARAMS
     Co = module.output_channels
+    have_flags = module.flag_channels > 0 and d_flags is not None and d_flags.numel() > 0
+    head_idx = ([nb, nb + 1] if module.norm_embeddings else []) + [nb + 2, nb + 3] + ([nb + 4, nb + 5] if have_flags else [])
+    head_flat = bucket(head_idx)
     # ---- mask head backward (mask_tracker.py:113-132)
     if d_mask is None:
         d_mask = torch.zeros(B, Co, T, module.frame_height, module.frame_width, dtype=f32, device=dev)
@@ -273,7 +287,6 @@ def run_backward(module, sv, params, d_mask, d_flags):
     dPm = E(M, Co * P * P)
     ops.unpatchify_pool_bwd(mode, dpooled, B * T, g['Hp'], g['Wp'], P, Co, sv['stp'], dPm)
     linear_bwd(nb + 2, dPm, sv['Fm'])
-    have_flags = module.flag_channels > 0 and d_flags is not None and d_flags.numel() > 0
     # gradient w.r.t. the features that feed both heads, always f32: dFeat = dPm . Whead (+ flags adjoint)
     dFeat = E(M, D, dtype=f32)
     ops.gemm_nt(mode, dPm, Wt(params[nb + 2]), dFeat)
@@ -281,8 +294,8 @@ def run_backward(module, sv, params, d_mask, d_flags):
         # flags head adjoint (F x D, once per step; only the plugin path ever asks for it, pipeline.py:238)
         df = d_flags.to(f32).reshape(B * T, -1)
         meanf = sv['feat32'].reshape(B * T, S, D)[:, 1:, :].float().mean(dim=1)
-        grads[nb + 4] = df.t() @ meanf
-        grads[nb + 5] = df.sum(0)
+        grads[nb + 4].copy_(df.t() @ meanf)
+        grads[nb + 5].copy_(df.sum(0))
         dmean = (df @ params[nb + 4].detach()) / float(S - 1)
         dFeat.reshape(B * T, S, D)[:, 1:, :] += dmean[:, None, :]
     # (without a flags gradient flag_post_linear.* keep grad None, like the reference where pipeline.py:157 drops them)
@@ -292,7 +305,7 @@ def run_backward(module, sv, params, d_mask, d_flags):
     else:
         dX = dFeat     # model.norm takes no part when norm_embeddings is False (vision_tf.py:152): its grads stay None
     if module.grad_hook is not None:
-        module.grad_hook('head', [grads[j] for j in range(nb, len(params))])
+        module.grad_hook('head', head_flat)
 
     shape_attn = ops.attn_shape(mode, B, T, S, D, heads, ca)
     dR3 = dX
@@ -302,6 +315,7 @@ def run_backward(module, sv, params, d_mask, d_flags):
         st = sv['blocks'][i]
         dp = sv['dps'][i]
         Hd = q[16].shape[0]
+        blk_flat = bucket(range(o, o + _BLOCK_PARAMS))
         # ---- mlp
         G3 = E(M, D)
         ops.scale_cast(mode, dR3, dp['m'], G3)
@@ -349,32 +363,29 @@ def run_backward(module, sv, params, d_mask, d_flags):
         dR3 = dR0
         sv['blocks'][i] = None   # free this block's activations
         if module.grad_hook is not None:
-            module.grad_hook(i, [grads[j] for j in range(o, o + _BLOCK_PARAMS)])
+            module.grad_hook(i, blk_flat)
 
     # ---- embeddings + patch embed backward
     gX = dR3
-    dpos_eff = E(S, D, dtype=f32); dtime_eff = E(T, D, dtype=f32)
+    emb_flat = bucket(range(0, 5))
+    resized = sv['pos_idx'] is not None or sv['time_idx'] is not None
+    dpos_eff = grads[1][0] if sv['pos_idx'] is None else E(S, D, dtype=f32)
+    dtime_eff = grads[2][0] if sv['time_idx'] is None else E(T, D, dtype=f32)
     ops.embed_bwd(gX, B, T, S, dpos_eff, dtime_eff)
-    grads[0] = dpos_eff[0].reshape(1, 1, D).clone()
-    if sv['pos_idx'] is None:
-        grads[1] = dpos_eff.reshape(1, S, D)
-    else:
-        gp = torch.zeros_like(params[1], dtype=f32)
-        gp[0].index_add_(0, sv['pos_idx'], dpos_eff)
-        grads[1] = gp
-    if sv['time_idx'] is None:
-        grads[2] = dtime_eff.reshape(1, T, D)
-    else:
-        gt = torch.zeros_like(params[2], dtype=f32)
-        gt[0].index_add_(0, sv['time_idx'], dtime_eff)
-        grads[2] = gt
+    grads[0].copy_(dpos_eff[0].reshape(1, 1, D))
+    if sv['pos_idx'] is not None:        # nearest-resized tables (vision_tf.py:103-115): scatter back to the stored rows
+        grads[1].zero_()
+        grads[1][0].index_add_(0, sv['pos_idx'], dpos_eff)
+    if sv['time_idx'] is not None:
+        grads[2].zero_()
+        grads[2][0].index_add_(0, sv['time_idx'], dtime_eff)
     Gpe = E(M, D)
     ops.scale_cast(mode, gX, mask0, Gpe)
     dWpe = galloc(3)
     ops.gemm_tn(mode, Gpe, sv['A_pe'], dWpe.reshape(D, -1))
-    grads[4] = dtime_eff.sum(0)            # bias gradient = sum over all patch rows
+    grads[4].copy_(dtime_eff.sum(0))       # bias gradient = sum over all patch rows
     if module.grad_hook is not None:
-        module.grad_hook('embed', [grads[j] for j in range(0, 5)])
+        module.grad_hook('embed', emb_flat)
     return grads
 
 
