@@ -1,0 +1,434 @@
+// bf16 MFMA flash-style attention for the divided space-time blocks (gfx950), forward and backward.
+//
+// Replaces softmax(q k^T / 8 [causal]) v of Attention.forward (vit.py:88-109) without materialising the
+// (T,T) / (S,S) score matrices the reference builds (13 MB + 130 MB f32 per block at the default config).
+//
+// Work unit = one 32-query tile against 32-key tiles, d = 64, on v_mfma_f32_32x32x16_bf16:
+//   S^T = K Q^T    (A = K rows from LDS, B = Q rows)      -> lane (q = lane&31, hi) holds 16 keys of its query, so the
+//                                                             softmax row statistics are lane-local (+1 exchange with lane^32)
+//   O^T += V^T P^T (A = V gathered with ds_read_b64_tr_b16, B = P straight from the S^T accumulator registers)
+// Token rows come straight from the qkv GEMM output [rows, 3D] (128-byte head slices, 1 cache line each) through
+// direct-to-LDS loads.  LDS tiles are [32 rows][64 bf16]; 16-byte chunk c of row r is stored at chunk position
+// c ^ g(r), g(r) = ((r>>1)&1)<<2 | ((r>>2)&3), which is conflict-free for both the ds_read_b128 row fragments and
+// the transpose reads (applied on the SOURCE address: the LDS image of a direct-to-LDS load stays lane-linear).
+//
+//   SHARED = true  (spatial):  one 256-thread workgroup per (clip, frame, head); all K/V (or Q/dO) tiles of the
+//                              sequence resident in LDS (S <= 320: 80 KiB -> 2 workgroups per CU); waves take query
+//                              (or key) tiles round-robin.
+//   SHARED = false (temporal): one wave per (clip, slot, head) with wave-private LDS tiles (T <= 64), no barriers.
+// Longer sequences use the f32 kernels of attention_simple.hip.
+//
+// Backward (recompute from the saved log-sum-exp, delta = rowsum(dO * O) precomputed):
+//   dkv kernel: a wave owns key tile j: S = Q K^T and dP = dO V^T in the (rows = q in registers, cols = key in lanes)
+//               orientation, so P and dS feed dV += P^T dO, dK += dS^T Q as A operands without any shuffle.
+//   dq  kernel: a wave owns query tile i: S^T, dP^T in the forward orientation, dQ += dS K.
+#include "attention_common.h"
+
+namespace {
+
+constexpr int TILE_B = 4096;                 // 32 rows x 128 B
+constexpr float kScale = 0.125f;             // head_dim^-0.5 (vit.py:70)
+constexpr float kLog2e = 1.4426950408889634f;
+
+__device__ __forceinline__ int swz_g(int r) { return (((r >> 1) & 1) << 2) | ((r >> 2) & 3); }
+
+__device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((GLB_PTR(const uint32_t))gsrc, (LDS_PTR(uint32_t))lds_wave_base, 16, 0, 0);
+}
+
+// one wave loads a [32][64] bf16 tile: positions p0..p0+31 (clamped to L-1 so that padding rows hold finite data)
+__device__ __forceinline__ void load_tile(const bf16_t* src, long pse, int p0, int L, char* tile, int lane) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = 8 * j + (lane >> 3);
+        const int c = (lane & 7) ^ swz_g(r);
+        int pos = p0 + r; pos = pos < L ? pos : L - 1;
+        glds16(src + (size_t)pos * pse + c * 8, tile + j * 1024);
+    }
+}
+
+// A/B fragment of a row-major tile for a contraction over d: lane (row = lane&31, hi) gets d = 16*ks + 8*hi .. +7
+__device__ __forceinline__ bf16x8 frag_row(const char* tile, int row, int ks, int hi) {
+    const int c = (2 * ks + hi) ^ swz_g(row);
+    return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(tile + row * 128 + (c << 4)));
+}
+// the same fragment straight from global memory (rows at stride pse elements)
+__device__ __forceinline__ bf16x8 frag_row_global(const bf16_t* src, long pse, int pos, int ks, int hi) {
+    return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(src + (size_t)pos * pse + 16 * ks + 8 * hi));
+}
+// fragment for a contraction over the tile's ROWS: lane (col = 32*dt + (lane&31), hi) gets rows crow32(8*s + j, hi), j = 0..7,
+// i.e. rows {16s + 4hi + 0..3} and {16s + 8 + 4hi + 0..3}: two transpose reads of [4 rows][16 cols] blocks.
+__device__ __forceinline__ bf16x8 frag_tr(const char* tile, int s, int dt, int lane) {
+    const int q16 = lane & 15, g16 = (lane >> 4) & 1, hi = lane >> 5;
+    const int chunk = 4 * dt + 2 * g16 + ((q16 & 3) >> 1);
+    const int r0 = 16 * s + 4 * hi + (q16 >> 2), r1 = r0 + 8;
+    const int o0 = r0 * 128 + ((chunk ^ swz_g(r0)) << 4) + (q16 & 1) * 8;
+    const int o1 = r1 * 128 + ((chunk ^ swz_g(r1)) << 4) + (q16 & 1) * 8;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(tile + o0));
+    const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(tile + o1));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    return __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+// registers 8s..8s+7 of a C-layout accumulator as a bf16 operand (contraction slot j <-> row crow32(8s+j, hi))
+__device__ __forceinline__ bf16x8 pack8(const float* v) {
+    typedef __attribute__((ext_vector_type(8))) float f32x8;
+    f32x8 t = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
+    return __builtin_convertvector(t, bf16x8);
+}
+
+struct WorkId { int item, head; bool valid; };
+template <bool SHARED>
+__device__ __forceinline__ WorkId work_id(const SeqDesc& sd, int wave) {
+    const int items = sd.n_outer * sd.n_inner;
+    const int idx = SHARED ? blockIdx.x : blockIdx.x * 4 + wave;
+    WorkId w; w.valid = idx < items * sd.heads; w.item = idx / sd.heads; w.head = idx - w.item * sd.heads;
+    return w;
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+template <bool SHARED>
+__global__ __launch_bounds__(256) void attn_fwd_mfma(SeqDesc sd, int nt, const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const WorkId w = work_id<SHARED>(sd, wave);
+    if (!SHARED && !w.valid) return;
+    const long base = seq_base(sd, w.item);
+    const long ld3 = 3L * sd.D, pse = sd.pos_stride * ld3;
+    const bf16_t* qh = qkv + base * ld3 + w.head * ATT_HD;
+    char* kt = SHARED ? smem : smem + wave * (2 * nt * TILE_B);
+    char* vt = kt + nt * TILE_B;
+    if (SHARED) {
+        for (int t = wave; t < nt; t += 4) {
+            load_tile(qh + sd.D, pse, 32 * t, sd.L, kt + t * TILE_B, lane);
+            load_tile(qh + 2 * sd.D, pse, 32 * t, sd.L, vt + t * TILE_B, lane);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    } else {
+        for (int t = 0; t < nt; ++t) {
+            load_tile(qh + sd.D, pse, 32 * t, sd.L, kt + t * TILE_B, lane);
+            load_tile(qh + 2 * sd.D, pse, 32 * t, sd.L, vt + t * TILE_B, lane);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    const float sc = kScale * kLog2e;
+    for (int qt = SHARED ? wave : 0; qt < nt; qt += SHARED ? 4 : 1) {
+        const int q = 32 * qt + l31;
+        const int qc = q < sd.L ? q : sd.L - 1;
+        bf16x8 qf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = frag_row_global(qh, pse, qc, ks, hi);
+        f32x16 o0, o1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+        float m = -1e30f, l = 0.f;
+        const long klim = (long)32 * qt + 31 + sd.diag;            // last key any query of this tile may see
+        const int kt_end = klim >= (long)sd.L - 1 ? nt : (int)(klim / 32) + 1;
+        for (int j = 0; j < kt_end; ++j) {
+            const char* ktile = kt + j * TILE_B;
+            const char* vtile = vt + j * TILE_B;
+            f32x16 s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(ktile, l31, ks, hi), qf[ks], s, 0, 0, 0);
+            const bool need_mask = (32 * j + 31 >= sd.L) || ((long)32 * j + 31 > (long)32 * qt + sd.diag);
+            float mx = -1e30f;
+            float p[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = s[r] * sc;
+                if (need_mask) {
+                    const int key = 32 * j + crow32(r, hi);
+                    if (key >= sd.L || (long)key > (long)q + sd.diag) v = -1e30f;
+                }
+                p[r] = v; mx = fmaxf(mx, v);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mn = fmaxf(m, mx);
+            const float alpha = exp2f(m - mn);
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float e = (p[r] <= -1e29f) ? 0.f : exp2f(p[r] - mn); p[r] = e; ps += e; }
+            l = l * alpha + ps;
+            m = mn;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+            const bf16x8 pb0 = pack8(p), pb1 = pack8(p + 8);
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(vtile, 0, 0, lane), pb0, o0, 0, 0, 0);
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(vtile, 1, 0, lane), pb1, o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(vtile, 0, 1, lane), pb0, o1, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(vtile, 1, 1, lane), pb1, o1, 0, 0, 0);
+        }
+        l += __shfl_xor(l, 32, 64);
+        if (q < sd.L) {
+            const float inv = 1.0f / l;
+            const long row = base + (long)q * sd.pos_stride;
+            bf16_t* orow = out + row * sd.D + w.head * ATT_HD;
+            // O^T C layout: register r of lane (q, hi) holds d = 32*dt + 8*(r>>2) + 4*hi + (r&3): 4 consecutive d per group
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                st4(orow + 8 * gq + 4 * hi, make_float4(o0[4 * gq] * inv, o0[4 * gq + 1] * inv, o0[4 * gq + 2] * inv, o0[4 * gq + 3] * inv));
+                st4(orow + 32 + 8 * gq + 4 * hi, make_float4(o1[4 * gq] * inv, o1[4 * gq + 1] * inv, o1[4 * gq + 2] * inv, o1[4 * gq + 3] * inv));
+            }
+            if (lse && hi == 0) lse[row * sd.heads + w.head] = (m + log2f(l)) * 0.6931471805599453f;   // natural-log LSE of the scaled scores
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward prep
+// ld[(item*heads + h)*Lp + q] = (lse, delta), delta = sum_d dO*O  -- packed per sequence so the kernels read it contiguously
+__global__ void attn_bwd_prep_kernel(SeqDesc sd, int Lp, const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                     float2* __restrict__ ld) {
+    const int items = sd.n_outer * sd.n_inner;
+    const long total = (long)items * sd.heads * Lp;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int q = (int)(i % Lp); const long ih = i / Lp; const int h = (int)(ih % sd.heads); const int item = (int)(ih / sd.heads);
+        float2 v = make_float2(0.f, 0.f);
+        if (q < sd.L) {
+            const long row = seq_base(sd, item) + (long)q * sd.pos_stride;
+            const bf16_t* a = o + row * sd.D + h * ATT_HD; const bf16_t* b = dout + row * sd.D + h * ATT_HD;
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < ATT_HD; d += 4) { const float4 x = ld4(a + d), y = ld4(b + d); s += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w; }
+            v = make_float2(lse[row * sd.heads + h], s);
+        }
+        ld[i] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward: dK, dV
+template <bool SHARED>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_mfma(SeqDesc sd, int nt, const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                         const float2* __restrict__ ld, bf16_t* __restrict__ dqkv) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const WorkId w = work_id<SHARED>(sd, wave);
+    if (!SHARED && !w.valid) return;
+    const long base = seq_base(sd, w.item);
+    const long ld3 = 3L * sd.D, pse = sd.pos_stride * ld3, pso = sd.pos_stride * sd.D;
+    const bf16_t* qh = qkv + base * ld3 + w.head * ATT_HD;
+    const bf16_t* doh = dout + base * sd.D + w.head * ATT_HD;
+    const float2* ldh = ld + ((size_t)w.item * sd.heads + w.head) * (nt * 32);
+    char* qt_ = SHARED ? smem : smem + wave * (2 * nt * TILE_B);
+    char* dot_ = qt_ + nt * TILE_B;
+    if (SHARED) {
+        for (int t = wave; t < nt; t += 4) {
+            load_tile(qh, pse, 32 * t, sd.L, qt_ + t * TILE_B, lane);
+            load_tile(doh, pso, 32 * t, sd.L, dot_ + t * TILE_B, lane);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    } else {
+        for (int t = 0; t < nt; ++t) {
+            load_tile(qh, pse, 32 * t, sd.L, qt_ + t * TILE_B, lane);
+            load_tile(doh, pso, 32 * t, sd.L, dot_ + t * TILE_B, lane);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    for (int j = SHARED ? wave : 0; j < nt; j += SHARED ? 4 : 1) {
+        const int key = 32 * j + l31;
+        const int kc = key < sd.L ? key : sd.L - 1;
+        bf16x8 kf[4], vf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { kf[ks] = frag_row_global(qh + sd.D, pse, kc, ks, hi); vf[ks] = frag_row_global(qh + 2 * sd.D, pse, kc, ks, hi); }
+        f32x16 dk0, dk1, dv0, dv1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk0[r] = 0.f; dk1[r] = 0.f; dv0[r] = 0.f; dv1[r] = 0.f; }
+        // first query tile that can see any key of this tile: q >= 32*j - diag
+        const long qlo = (long)32 * j - sd.diag;
+        const int i0 = qlo > 0 ? (int)(qlo / 32) : 0;
+        for (int i = i0; i < nt; ++i) {
+            const char* qtile = qt_ + i * TILE_B;
+            const char* dotile = dot_ + i * TILE_B;
+            f32x16 s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(qtile, l31, ks, hi), kf[ks], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(dotile, l31, ks, hi), vf[ks], dp, 0, 0, 0);
+            }
+            // rows of the accumulators are queries q = 32*i + 8*(r>>2) + 4*hi + (r&3); lse/delta for 4 consecutive q per group
+            float pv[16], dsv[16];
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const float4* p4 = reinterpret_cast<const float4*>(ldh + 32 * i + 8 * gq + 4 * hi);
+                const float4 a = p4[0], b = p4[1];   // (lse0, d0, lse1, d1), (lse2, d2, lse3, d3)
+                const float ls[4] = {a.x, a.z, b.x, b.z}, dl[4] = {a.y, a.w, b.y, b.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * gq + e;
+                    const int q = 32 * i + 8 * gq + 4 * hi + e;
+                    const bool ok = q < sd.L && key < sd.L && (long)key <= (long)q + sd.diag;
+                    const float p = ok ? exp2f(s[r] * (kScale * kLog2e) - ls[e] * kLog2e) : 0.f;
+                    pv[r] = p;
+                    dsv[r] = p * (dp[r] - dl[e]) * kScale;
+                }
+            }
+            const bf16x8 pa0 = pack8(pv), pa1 = pack8(pv + 8), da0 = pack8(dsv), da1 = pack8(dsv + 8);
+            dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa0, frag_tr(dotile, 0, 0, lane), dv0, 0, 0, 0);
+            dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa1, frag_tr(dotile, 1, 0, lane), dv0, 0, 0, 0);
+            dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa0, frag_tr(dotile, 0, 1, lane), dv1, 0, 0, 0);
+            dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa1, frag_tr(dotile, 1, 1, lane), dv1, 0, 0, 0);
+            dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da0, frag_tr(qtile, 0, 0, lane), dk0, 0, 0, 0);
+            dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da1, frag_tr(qtile, 1, 0, lane), dk0, 0, 0, 0);
+            dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da0, frag_tr(qtile, 0, 1, lane), dk1, 0, 0, 0);
+            dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da1, frag_tr(qtile, 1, 1, lane), dk1, 0, 0, 0);
+        }
+        // C layout: lane (col = d = l31 (+32), hi), register r -> key row 32*j + crow32(r, hi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kr = 32 * j + crow32(r, hi);
+            if (kr < sd.L) {
+                bf16_t* drow = dqkv + (base + (long)kr * sd.pos_stride) * ld3 + w.head * ATT_HD;
+                drow[sd.D + l31] = f2bf(dk0[r]); drow[sd.D + 32 + l31] = f2bf(dk1[r]);
+                drow[2 * sd.D + l31] = f2bf(dv0[r]); drow[2 * sd.D + 32 + l31] = f2bf(dv1[r]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward: dQ
+template <bool SHARED>
+__global__ __launch_bounds__(256) void attn_bwd_dq_mfma(SeqDesc sd, int nt, const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                        const float2* __restrict__ ld, bf16_t* __restrict__ dqkv) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const WorkId w = work_id<SHARED>(sd, wave);
+    if (!SHARED && !w.valid) return;
+    const long base = seq_base(sd, w.item);
+    const long ld3 = 3L * sd.D, pse = sd.pos_stride * ld3, pso = sd.pos_stride * sd.D;
+    const bf16_t* qh = qkv + base * ld3 + w.head * ATT_HD;
+    const bf16_t* doh = dout + base * sd.D + w.head * ATT_HD;
+    const float2* ldh = ld + ((size_t)w.item * sd.heads + w.head) * (nt * 32);
+    char* kt = SHARED ? smem : smem + wave * (2 * nt * TILE_B);
+    char* vt = kt + nt * TILE_B;
+    if (SHARED) {
+        for (int t = wave; t < nt; t += 4) {
+            load_tile(qh + sd.D, pse, 32 * t, sd.L, kt + t * TILE_B, lane);
+            load_tile(qh + 2 * sd.D, pse, 32 * t, sd.L, vt + t * TILE_B, lane);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    } else {
+        for (int t = 0; t < nt; ++t) {
+            load_tile(qh + sd.D, pse, 32 * t, sd.L, kt + t * TILE_B, lane);
+            load_tile(qh + 2 * sd.D, pse, 32 * t, sd.L, vt + t * TILE_B, lane);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    for (int qt = SHARED ? wave : 0; qt < nt; qt += SHARED ? 4 : 1) {
+        const int q = 32 * qt + l31;
+        const int qc = q < sd.L ? q : sd.L - 1;
+        bf16x8 qf[4], dof[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { qf[ks] = frag_row_global(qh, pse, qc, ks, hi); dof[ks] = frag_row_global(doh, pso, qc, ks, hi); }
+        const float2 lq = ldh[32 * qt + l31];
+        const float ls = lq.x * kLog2e, dl = lq.y;
+        f32x16 dq0, dq1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dq0[r] = 0.f; dq1[r] = 0.f; }
+        const long klim = (long)32 * qt + 31 + sd.diag;
+        const int kt_end = klim >= (long)sd.L - 1 ? nt : (int)(klim / 32) + 1;
+        for (int j = 0; j < kt_end; ++j) {
+            const char* ktile = kt + j * TILE_B;
+            const char* vtile = vt + j * TILE_B;
+            f32x16 s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(ktile, l31, ks, hi), qf[ks], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(vtile, l31, ks, hi), dof[ks], dp, 0, 0, 0);
+            }
+            float dsv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = 32 * j + crow32(r, hi);
+                const bool ok = q < sd.L && key < sd.L && (long)key <= (long)q + sd.diag;
+                const float p = ok ? exp2f(s[r] * (kScale * kLog2e) - ls) : 0.f;
+                dsv[r] = p * (dp[r] - dl) * kScale;
+            }
+            const bf16x8 da0 = pack8(dsv), da1 = pack8(dsv + 8);
+            dq0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da0, frag_tr(ktile, 0, 0, lane), dq0, 0, 0, 0);
+            dq0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da1, frag_tr(ktile, 1, 0, lane), dq0, 0, 0, 0);
+            dq1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da0, frag_tr(ktile, 0, 1, lane), dq1, 0, 0, 0);
+            dq1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da1, frag_tr(ktile, 1, 1, lane), dq1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qr = 32 * qt + crow32(r, hi);
+            if (qr < sd.L) {
+                bf16_t* drow = dqkv + (base + (long)qr * sd.pos_stride) * ld3 + w.head * ATT_HD;
+                drow[l31] = f2bf(dq0[r]); drow[32 + l31] = f2bf(dq1[r]);
+            }
+        }
+    }
+}
+
+template <typename K>
+static void set_lds_attr(K kernel, int bytes) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+}  // namespace
+
+// nt = number of 32-position tiles; returns false when the MFMA kernels do not cover this shape
+bool tcow_attn_mfma_supported(const SeqDesc& d, bool shared) {
+    const int nt = (d.L + 31) / 32;
+    return shared ? nt <= 10 : nt <= 2;
+}
+
+int tcow_attn_mfma_fwd(hipStream_t st, const SeqDesc& d, bool shared, const void* qkv, void* out, float* lse) {
+    const int nt = (d.L + 31) / 32;
+    const int pairs = d.n_outer * d.n_inner * d.heads;
+    if (shared) {
+        const int lds = 2 * nt * TILE_B;
+        set_lds_attr(attn_fwd_mfma<true>, lds);
+        hipLaunchKernelGGL(attn_fwd_mfma<true>, dim3(pairs), dim3(256), lds, st, d, nt, (const bf16_t*)qkv, (bf16_t*)out, lse);
+    } else {
+        const int lds = 4 * 2 * nt * TILE_B;
+        set_lds_attr(attn_fwd_mfma<false>, lds);
+        hipLaunchKernelGGL(attn_fwd_mfma<false>, dim3(cdiv(pairs, 4)), dim3(256), lds, st, d, nt, (const bf16_t*)qkv, (bf16_t*)out, lse);
+    }
+    TCOW_CHECK_LAUNCH();
+    return TCOW_OK;
+}
+
+long tcow_attn_mfma_bwd_workspace_bytes(const SeqDesc& d) {
+    const int nt = (d.L + 31) / 32;
+    return (long)d.n_outer * d.n_inner * d.heads * nt * 32 * 8;
+}
+
+int tcow_attn_mfma_bwd(hipStream_t st, const SeqDesc& d, bool shared, const void* qkv, const void* out, const void* dout, const float* lse, void* ws,
+                       void* dqkv) {
+    const int nt = (d.L + 31) / 32;
+    const int pairs = d.n_outer * d.n_inner * d.heads;
+    float2* ld = (float2*)ws;
+    const long total = (long)pairs * nt * 32;
+    int blocks = cdiv(total, 256); if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3(blocks), dim3(256), 0, st, d, nt * 32, (const bf16_t*)out, (const bf16_t*)dout, lse, ld);
+    TCOW_CHECK_LAUNCH();
+    if (shared) {
+        const int lds = 2 * nt * TILE_B;
+        set_lds_attr(attn_bwd_dkv_mfma<true>, lds); set_lds_attr(attn_bwd_dq_mfma<true>, lds);
+        hipLaunchKernelGGL(attn_bwd_dkv_mfma<true>, dim3(pairs), dim3(256), lds, st, d, nt, (const bf16_t*)qkv, (const bf16_t*)dout, ld, (bf16_t*)dqkv);
+        TCOW_CHECK_LAUNCH();
+        hipLaunchKernelGGL(attn_bwd_dq_mfma<true>, dim3(pairs), dim3(256), lds, st, d, nt, (const bf16_t*)qkv, (const bf16_t*)dout, ld, (bf16_t*)dqkv);
+    } else {
+        const int lds = 4 * 2 * nt * TILE_B;
+        set_lds_attr(attn_bwd_dkv_mfma<false>, lds); set_lds_attr(attn_bwd_dq_mfma<false>, lds);
+        hipLaunchKernelGGL(attn_bwd_dkv_mfma<false>, dim3(cdiv(pairs, 4)), dim3(256), lds, st, d, nt, (const bf16_t*)qkv, (const bf16_t*)dout, ld, (bf16_t*)dqkv);
+        TCOW_CHECK_LAUNCH();
+        hipLaunchKernelGGL(attn_bwd_dq_mfma<false>, dim3(cdiv(pairs, 4)), dim3(256), lds, st, d, nt, (const bf16_t*)qkv, (const bf16_t*)dout, ld, (bf16_t*)dqkv);
+    }
+    TCOW_CHECK_LAUNCH();
+    return TCOW_OK;
+}

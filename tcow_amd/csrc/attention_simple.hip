@@ -7,26 +7,14 @@
 // No score matrix is materialised: one thread per query walks the keys 32 at a time through LDS with an online
 // softmax.  The backward recomputes probabilities from the saved log-sum-exp.
 // These kernels do all arithmetic in f32 on the VALU; the bf16 MFMA kernels live in attention_bf16.hip.
-#include "common.h"
+#include <stdlib.h>
+
+#include "attention_common.h"
 
 namespace {
 
-constexpr int HD = 64;    // head dim (all reference geometries: 768/12, 896/14, 1024/16)
+constexpr int HD = ATT_HD;
 constexpr int KC = 32;    // keys (or queries) per LDS chunk
-
-struct SeqDesc {
-    int n_outer, n_inner;          // items = n_outer * n_inner
-    long outer_stride, inner_stride, offset;   // base_row = outer*outer_stride + inner*inner_stride + offset
-    long pos_stride;               // rows between consecutive sequence positions
-    int L;                         // sequence length
-    int diag;                      // key allowed iff key_pos <= query_pos + diag (large = no mask)
-    int heads, D;
-};
-
-__device__ __forceinline__ long seq_base(const SeqDesc& s, int item) {
-    const int o = item / s.n_inner, i = item - o * s.n_inner;
-    return o * s.outer_stride + i * s.inner_stride + s.offset;
-}
 
 template <typename T>
 __device__ __forceinline__ void load_row64(const T* p, float* dst) {
@@ -285,27 +273,6 @@ __global__ void zero_rows_kernel(T* p, long ld, int n_outer, long outer_stride, 
 
 }  // namespace
 
-static int diag_from_causal(int ca) {
-    // vit.py:93-99: ca in {1,2}: tril(); ca >= 3: tril(diagonal=ca-2); ca <= 0: no mask.
-    if (ca <= 0) return 1 << 28;
-    return ca <= 2 ? 0 : ca - 2;
-}
-
-static SeqDesc temporal_desc(const tcow_attn_shape* s) {
-    SeqDesc d;
-    d.n_outer = s->B; d.n_inner = s->S - 1; d.outer_stride = (long)s->T * s->S; d.inner_stride = 1; d.offset = 1;
-    d.pos_stride = s->S; d.L = s->T; d.diag = diag_from_causal(s->causal); d.heads = s->heads; d.D = s->D;
-    return d;
-}
-static SeqDesc spatial_desc(const tcow_attn_shape* s) {
-    // cls slot takes part iff causal_attention in {0,1} (vit.py:180-186 vs :202-208)
-    const int s0 = (s->causal == 0 || s->causal == 1) ? 0 : 1;
-    SeqDesc d;
-    d.n_outer = s->B * s->T; d.n_inner = 1; d.outer_stride = s->S; d.inner_stride = 0; d.offset = s0;
-    d.pos_stride = 1; d.L = s->S - s0; d.diag = 1 << 28; d.heads = s->heads; d.D = s->D;
-    return d;
-}
-
 template <typename T>
 static int launch_fwd(hipStream_t st, const SeqDesc& d, const void* qkv, void* out, float* lse) {
     const dim3 grid(d.n_outer * d.n_inner * d.heads, cdiv(d.L, 64));
@@ -340,18 +307,43 @@ static int check_shape(const tcow_attn_shape* s, const char* who) {
     return TCOW_OK;
 }
 
-int tcow_attn_simple_fwd(hipStream_t st, const tcow_attn_shape* s, int spatial, const void* qkv, void* out, float* lse) {
+bool tcow_attn_mfma_supported(const SeqDesc& d, bool shared);
+int tcow_attn_mfma_fwd(hipStream_t st, const SeqDesc& d, bool shared, const void* qkv, void* out, float* lse);
+long tcow_attn_mfma_bwd_workspace_bytes(const SeqDesc& d);
+int tcow_attn_mfma_bwd(hipStream_t st, const SeqDesc& d, bool shared, const void* qkv, const void* out, const void* dout, const float* lse, void* ws,
+                       void* dqkv);
+
+// TCOW_ATTN_SIMPLE=1 forces the f32-arithmetic kernels for bf16 storage as well (A/B checks of the MFMA kernels)
+static bool use_mfma(const tcow_attn_shape* s, const SeqDesc& d, int spatial) {
+    static const bool force_simple = getenv("TCOW_ATTN_SIMPLE") != nullptr && getenv("TCOW_ATTN_SIMPLE")[0] == '1';
+    return s->dtype == TCOW_BF16 && !force_simple && tcow_attn_mfma_supported(d, spatial != 0);
+}
+
+int tcow_attn_fwd_dispatch(hipStream_t st, const tcow_attn_shape* s, int spatial, const void* qkv, void* out, float* lse) {
     const SeqDesc d = spatial ? spatial_desc(s) : temporal_desc(s);
     int rc;
     if (!spatial || d.offset == 1) {   // slot-0 rows are not produced by the kernels: define them as zero
         rc = (s->dtype == TCOW_BF16) ? zero_slot0<bf16_t>(st, out, s->D, s, s->D) : zero_slot0<float>(st, out, s->D, s, s->D);
         if (rc) return rc;
     }
+    if (use_mfma(s, d, spatial)) return tcow_attn_mfma_fwd(st, d, spatial != 0, qkv, out, lse);
     return (s->dtype == TCOW_BF16) ? launch_fwd<bf16_t>(st, d, qkv, out, lse) : launch_fwd<float>(st, d, qkv, out, lse);
 }
 
-int tcow_attn_simple_bwd(hipStream_t st, const tcow_attn_shape* s, int spatial, const void* qkv, const void* out, const void* dout, const float* lse,
-                         float* delta, void* dqkv) {
+static long bwd_ws_bytes(const tcow_attn_shape* s) {
+    const long simple = (long)s->B * s->T * s->S * s->heads * 4;
+    const SeqDesc dt = temporal_desc(s), ds = spatial_desc(s);
+    long m = simple;
+    if (s->dtype == TCOW_BF16) {
+        const long a = tcow_attn_mfma_bwd_workspace_bytes(dt), b = tcow_attn_mfma_bwd_workspace_bytes(ds);
+        if (a > m) m = a;
+        if (b > m) m = b;
+    }
+    return m + 256;
+}
+
+int tcow_attn_bwd_dispatch(hipStream_t st, const tcow_attn_shape* s, int spatial, const void* qkv, const void* out, const void* dout, const float* lse,
+                           void* ws, void* dqkv) {
     const SeqDesc d = spatial ? spatial_desc(s) : temporal_desc(s);
     const long rows = (long)s->B * s->T * s->S;
     int rc;
@@ -359,8 +351,9 @@ int tcow_attn_simple_bwd(hipStream_t st, const tcow_attn_shape* s, int spatial, 
         rc = (s->dtype == TCOW_BF16) ? zero_slot0<bf16_t>(st, dqkv, 3L * s->D, s, 3 * s->D) : zero_slot0<float>(st, dqkv, 3L * s->D, s, 3 * s->D);
         if (rc) return rc;
     }
-    return (s->dtype == TCOW_BF16) ? launch_bwd<bf16_t>(st, d, rows, qkv, out, dout, lse, delta, dqkv)
-                                   : launch_bwd<float>(st, d, rows, qkv, out, dout, lse, delta, dqkv);
+    if (use_mfma(s, d, spatial)) return tcow_attn_mfma_bwd(st, d, spatial != 0, qkv, out, dout, lse, ws, dqkv);
+    return (s->dtype == TCOW_BF16) ? launch_bwd<bf16_t>(st, d, rows, qkv, out, dout, lse, (float*)ws, dqkv)
+                                   : launch_bwd<float>(st, d, rows, qkv, out, dout, lse, (float*)ws, dqkv);
 }
 
 extern "C" {
@@ -368,25 +361,25 @@ extern "C" {
 int tcow_attn_temporal_fwd(void* stream, const tcow_attn_shape* s, const void* qkv, void* out, float* lse) {
     int rc = check_shape(s, "tcow_attn_temporal_fwd"); if (rc) return rc;
     TCOW_CHECK_ARG(qkv && out, "tcow_attn_temporal_fwd: null pointer");
-    return tcow_attn_simple_fwd((hipStream_t)stream, s, 0, qkv, out, lse);
+    return tcow_attn_fwd_dispatch((hipStream_t)stream, s, 0, qkv, out, lse);
 }
 int tcow_attn_spatial_fwd(void* stream, const tcow_attn_shape* s, const void* qkv, void* out, float* lse) {
     int rc = check_shape(s, "tcow_attn_spatial_fwd"); if (rc) return rc;
     TCOW_CHECK_ARG(qkv && out, "tcow_attn_spatial_fwd: null pointer");
-    return tcow_attn_simple_fwd((hipStream_t)stream, s, 1, qkv, out, lse);
+    return tcow_attn_fwd_dispatch((hipStream_t)stream, s, 1, qkv, out, lse);
 }
-long tcow_attn_bwd_workspace_bytes(const tcow_attn_shape* s) { return s ? (long)s->B * s->T * s->S * s->heads * 4 : 0; }
+long tcow_attn_bwd_workspace_bytes(const tcow_attn_shape* s) { return s ? bwd_ws_bytes(s) : 0; }
 int tcow_attn_temporal_bwd(void* stream, const tcow_attn_shape* s, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
                            void* workspace, long workspace_bytes) {
     int rc = check_shape(s, "tcow_attn_temporal_bwd"); if (rc) return rc;
     TCOW_CHECK_ARG(qkv && out && dout && lse && dqkv && workspace && workspace_bytes >= tcow_attn_bwd_workspace_bytes(s), "tcow_attn_temporal_bwd: bad pointers / workspace");
-    return tcow_attn_simple_bwd((hipStream_t)stream, s, 0, qkv, out, dout, lse, (float*)workspace, dqkv);
+    return tcow_attn_bwd_dispatch((hipStream_t)stream, s, 0, qkv, out, dout, lse, workspace, dqkv);
 }
 int tcow_attn_spatial_bwd(void* stream, const tcow_attn_shape* s, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
                           void* workspace, long workspace_bytes) {
     int rc = check_shape(s, "tcow_attn_spatial_bwd"); if (rc) return rc;
     TCOW_CHECK_ARG(qkv && out && dout && lse && dqkv && workspace && workspace_bytes >= tcow_attn_bwd_workspace_bytes(s), "tcow_attn_spatial_bwd: bad pointers / workspace");
-    return tcow_attn_simple_bwd((hipStream_t)stream, s, 1, qkv, out, dout, lse, (float*)workspace, dqkv);
+    return tcow_attn_bwd_dispatch((hipStream_t)stream, s, 1, qkv, out, dout, lse, workspace, dqkv);
 }
 
 }  // extern "C"

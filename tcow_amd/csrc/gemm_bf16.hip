@@ -13,6 +13,8 @@
 //   lane-linear), which makes the ds_read_b128 fragment reads of the 32x32x16 MFMA conflict-free.  Accumulators
 //   are staged through LDS as f32 so that bias / residual loads and the C stores are full-row coalesced.
 //   blockIdx is remapped so that each XCD (private L2) owns a contiguous band of row tiles.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -34,6 +36,7 @@ struct NtParams {
     int act;
     bf16_t* aux; long ldaux;
     int tiles_m, tiles_n;
+    int dbg;   // profiling aid: 1 = skip epilogue, 2 = skip MFMAs, 3 = skip loads
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(NtParams p) {
 
     for (int kt = 0; kt < nk; ++kt) {
         const int stage = kt & 1;
-        if (kt + 1 < nk) issue(kt + 1, stage ^ 1);
+        if (kt + 1 < nk && p.dbg != 3) issue(kt + 1, stage ^ 1);
         const char* sa = smem + stage * STAGE_BYTES;
         const char* sw = sa + TILE_BYTES;
 #pragma unroll
@@ -124,10 +127,17 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(NtParams p) {
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fw[j], acc[i][j], 0, 0, 0);
+                    if (p.dbg != 2) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fw[j], acc[i][j], 0, 0, 0);
+                    else acc[i][j][0] += __builtin_bit_cast(float, (uint32_t)(fa[i][0] != fw[j][0]));
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+    }
+    if (p.dbg == 1) {
+        float t = 0.f;
+        for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) t += acc[i][j][r];
+        if (t == 123.456f) reinterpret_cast<float*>(p.C)[0] = t;
+        return;
     }
 
     // ---- epilogue: accumulators -> LDS (f32 [128][128]) -> coalesced row-wise stores
@@ -144,40 +154,42 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(NtParams p) {
             }
     __syncthreads();
 
-#pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
-        const int idx = it * 256 + tid;
-        const int row = idx >> 5, c4 = (idx & 31) * 4;
-        const int gm = m0 + row, gn = n0 + c4;
-        if (gm >= p.M || gn >= p.N) continue;
-        float4 v = *reinterpret_cast<const float4*>(ct + row * BN + c4);
-        float vv[4] = {v.x, v.y, v.z, v.w};
-        const int nv = (p.N - gn) < 4 ? (p.N - gn) : 4;
-        const float rs = p.row_scale ? p.row_scale[gm] : 1.0f;
+    // Column-dependent operands are the same for all 16 row passes of a thread; row-dependent ones (row scale,
+    // residual, GELU' input) are fetched 8 passes at a time BEFORE the arithmetic so that their latencies overlap.
+    const int c4 = (tid & 31) * 4, gn = n0 + c4;
+    if (gn >= p.N) return;                       // N % 4 == 0: a thread's 4 columns are all in or all out
+    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias) b4 = ld4(p.bias + gn);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if (e < nv) {
-                float x = vv[e];
-                if (p.bias) x += p.bias[gn + e];
-                x *= rs;
-                if (p.act == TCOW_ACT_GELU) {
-                    if (p.aux) p.aux[(size_t)gm * p.ldaux + gn + e] = f2bf(x);
-                    x = gelu_erf(x);
-                } else if (p.act == TCOW_ACT_DGELU) {
-                    x *= gelu_erf_grad(bf2f(p.aux[(size_t)gm * p.ldaux + gn + e]));
-                }
-                if (p.resid) x += p.resid[(size_t)gm * p.ldr + gn + e];
-                vv[e] = x;
+    for (int half = 0; half < 2; ++half) {
+        float4 res[8]; float rs[8]; float4 ax[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int row = (half * 8 + u) * 8 + (tid >> 5);
+            const int gm = m0 + row;
+            res[u] = make_float4(0.f, 0.f, 0.f, 0.f); ax[u] = res[u]; rs[u] = 1.0f;
+            if (gm < p.M) {
+                if (p.row_scale) rs[u] = p.row_scale[gm];
+                if (p.resid) res[u] = ld4(p.resid + (size_t)gm * p.ldr + gn);
+                if (p.act == TCOW_ACT_DGELU) ax[u] = ld4(p.aux + (size_t)gm * p.ldaux + gn);
             }
         }
-        if (nv == 4) {
-            if (p.out_f32) st4(reinterpret_cast<float*>(p.C) + (size_t)gm * p.ldc + gn, make_float4(vv[0], vv[1], vv[2], vv[3]));
-            else st4(reinterpret_cast<bf16_t*>(p.C) + (size_t)gm * p.ldc + gn, make_float4(vv[0], vv[1], vv[2], vv[3]));
-        } else {
-            for (int e = 0; e < nv; ++e) {
-                if (p.out_f32) reinterpret_cast<float*>(p.C)[(size_t)gm * p.ldc + gn + e] = vv[e];
-                else reinterpret_cast<bf16_t*>(p.C)[(size_t)gm * p.ldc + gn + e] = f2bf(vv[e]);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int row = (half * 8 + u) * 8 + (tid >> 5);
+            const int gm = m0 + row;
+            if (gm >= p.M) continue;
+            float4 v = *reinterpret_cast<const float4*>(ct + row * BN + c4);
+            v.x = (v.x + b4.x) * rs[u]; v.y = (v.y + b4.y) * rs[u]; v.z = (v.z + b4.z) * rs[u]; v.w = (v.w + b4.w) * rs[u];
+            if (p.act == TCOW_ACT_GELU) {
+                if (p.aux) st4(p.aux + (size_t)gm * p.ldaux + gn, v);
+                v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
+            } else if (p.act == TCOW_ACT_DGELU) {
+                v.x *= gelu_erf_grad(ax[u].x); v.y *= gelu_erf_grad(ax[u].y); v.z *= gelu_erf_grad(ax[u].z); v.w *= gelu_erf_grad(ax[u].w);
             }
+            v.x += res[u].x; v.y += res[u].y; v.z += res[u].z; v.w += res[u].w;
+            if (p.out_f32) st4(reinterpret_cast<float*>(p.C) + (size_t)gm * p.ldc + gn, v);
+            else st4(reinterpret_cast<bf16_t*>(p.C) + (size_t)gm * p.ldc + gn, v);
         }
     }
 }
@@ -187,13 +199,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(NtParams p) {
 int tcow_gemm_nt_bf16(hipStream_t stream, const tcow_gemm_args* a) {
     TCOW_CHECK_ARG(a->K % BK == 0, "tcow_gemm_nt(bf16): K=%d must be a multiple of %d", a->K, BK);
     TCOW_CHECK_ARG(a->lda % 8 == 0 && a->ldw % 8 == 0, "tcow_gemm_nt(bf16): lda/ldw must be multiples of 8 elements");
-    TCOW_CHECK_ARG(a->ldc % 4 == 0, "tcow_gemm_nt(bf16): ldc must be a multiple of 4");
+    TCOW_CHECK_ARG(a->ldc % 4 == 0 && a->N % 4 == 0, "tcow_gemm_nt(bf16): N and ldc must be multiples of 4");
+    TCOW_CHECK_ARG((!a->resid || a->ldr % 4 == 0) && (!a->aux || a->ldaux % 4 == 0), "tcow_gemm_nt(bf16): ldr / ldaux must be multiples of 4");
     NtParams p;
     p.M = a->M; p.N = a->N; p.K = a->K;
     p.A = (const bf16_t*)a->A; p.lda = a->lda; p.W = (const bf16_t*)a->W; p.ldw = a->ldw;
     p.C = a->C; p.ldc = a->ldc; p.out_f32 = a->out_f32; p.bias = a->bias; p.row_scale = a->row_scale;
     p.resid = a->resid; p.ldr = a->ldr; p.act = a->act; p.aux = (bf16_t*)a->aux; p.ldaux = a->ldaux;
     p.tiles_m = cdiv(a->M, BM); p.tiles_n = cdiv(a->N, BN);
+    { const char* e = getenv("TCOW_GEMM_DBG"); p.dbg = e ? atoi(e) : 0; }
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(F32Params p) {
     }
 }
 
-// out[i] (+)= sum_z slab[z][i]   and optional column sums for the bias gradient are handled elsewhere
+// out[i] (+)= sum_z slab[z][i]  (float4 lanes; cols, ldo and slab_stride multiples of 4 on the vector path)
 __global__ void slab_reduce_kernel(const float* __restrict__ slab, int nz, long slab_stride, long n, float* __restrict__ out, long rows, long cols, long ldo, int accumulate) {
     long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
     const long stride = (long)gridDim.x * blockDim.x;
@@ -118,21 +118,44 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slab, int nz, long 
         *o = accumulate ? (*o + s) : s;
     }
 }
+__global__ void slab_reduce4_kernel(const float* __restrict__ slab, int nz, long slab_stride, long n4, float* __restrict__ out, long cols4, long ldo, int accumulate) {
+    long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (; i < n4; i += stride) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int z = 0; z < nz; ++z) { const float4 v = ld4(slab + (size_t)z * slab_stride + i * 4); s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+        const long r = i / cols4, c = (i - r * cols4) * 4;
+        float* o = out + r * ldo + c;
+        if (accumulate) { const float4 p = ld4(o); s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w; }
+        st4(o, s);
+    }
+}
 
-// column sums of Y[M,N] (bias gradient): one workgroup per 64 columns x row-slice, two-stage through a slab
+// column sums of Y[M,N] (bias gradient): thread = 4 consecutive columns, a block covers 128 columns x a row slice with
+// 8 row groups folded through LDS; partial rows go to `part` and tcow_launch_slab_reduce finishes.
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ Y, long ldy, int M, int N, int rows_per_blk, float* __restrict__ part) {
-    __shared__ float red[4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int w = threadIdx.x >> 6;
+    __shared__ float4 red[8][32];
+    const int cq = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int c = blockIdx.x * 128 + cq * 4;
     const int r0 = blockIdx.y * rows_per_blk;
     const int r1 = (r0 + rows_per_blk < M) ? r0 + rows_per_blk : M;
-    float s = 0.f;
-    if (c < N)
-        for (int r = r0 + w; r < r1; r += 4) s += Elem<T>::ld(Y + (size_t)r * ldy + c);
-    red[w][threadIdx.x & 63] = s;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c + 3 < N) {
+        for (int r = r0 + rg; r < r1; r += 8) { const float4 v = ld4(Y + (size_t)r * ldy + c); s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+    } else if (c < N) {
+        for (int r = r0 + rg; r < r1; r += 8) {
+            const T* p = Y + (size_t)r * ldy + c;
+            s.x += Elem<T>::ld(p); if (c + 1 < N) s.y += Elem<T>::ld(p + 1); if (c + 2 < N) s.z += Elem<T>::ld(p + 2);
+        }
+    }
+    red[rg][cq] = s;
     __syncthreads();
-    if (w == 0 && c < N) part[(size_t)blockIdx.y * N + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (rg == 0 && c < N) {
+        for (int g = 1; g < 8; ++g) { const float4 v = red[g][cq]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+        float* o = part + (size_t)blockIdx.y * N + c;
+        o[0] = s.x; if (c + 1 < N) o[1] = s.y; if (c + 2 < N) o[2] = s.z; if (c + 3 < N) o[3] = s.w;
+    }
 }
 
 }  // namespace
@@ -152,7 +175,7 @@ int tcow_gemm_nt_f32(hipStream_t stream, const tcow_gemm_args* a) {
 // number of token-dimension slices used by the weight-gradient GEMMs (both dtypes)
 int tcow_tn_splits(int M, int N, int K, int tile_outputs) {
     const int tiles = cdiv(N, tile_outputs) * cdiv(K, tile_outputs);
-    int s = cdiv(1024, tiles);                 // aim for ~4 workgroups per CU
+    int s = cdiv(512, tiles);                  // aim for ~2 workgroups per CU (slab traffic grows with the split count)
     const int max_s = cdiv(M, 512);            // at least 512 tokens per slice
     if (s > max_s) s = max_s;
     if (s < 1) s = 1;
@@ -162,8 +185,14 @@ int tcow_tn_splits(int M, int N, int K, int tile_outputs) {
 
 int tcow_launch_slab_reduce(hipStream_t stream, const float* slab, int nz, long slab_stride, long rows, long cols, float* out, long ldo, int accumulate) {
     const long n = rows * cols;
-    int blocks = cdiv(n, 256); if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, stream, slab, nz, slab_stride, n, out, rows, cols, ldo, accumulate);
+    const bool vec = (cols % 4 == 0) && (ldo % 4 == 0) && (slab_stride % 4 == 0) && ((reinterpret_cast<uintptr_t>(slab) | reinterpret_cast<uintptr_t>(out)) % 16 == 0);
+    if (vec) {
+        int blocks = cdiv(n / 4, 256); if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(slab_reduce4_kernel, dim3(blocks), dim3(256), 0, stream, slab, nz, slab_stride, n / 4, out, cols / 4, ldo, accumulate);
+    } else {
+        int blocks = cdiv(n, 256); if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, stream, slab, nz, slab_stride, n, out, rows, cols, ldo, accumulate);
+    }
     TCOW_CHECK_LAUNCH();
     return TCOW_OK;
 }
@@ -173,9 +202,9 @@ int tcow_launch_colsum(hipStream_t stream, int dtype, const void* Y, long ldy, i
     const int rpb = cdiv(M, parts);
     parts = cdiv(M, rpb);
     if (dtype == TCOW_BF16)
-        hipLaunchKernelGGL(colsum_partial_kernel<bf16_t>, dim3(cdiv(N, 64), parts), dim3(256), 0, stream, (const bf16_t*)Y, ldy, M, N, rpb, part);
+        hipLaunchKernelGGL(colsum_partial_kernel<bf16_t>, dim3(cdiv(N, 128), parts), dim3(256), 0, stream, (const bf16_t*)Y, ldy, M, N, rpb, part);
     else
-        hipLaunchKernelGGL(colsum_partial_kernel<float>, dim3(cdiv(N, 64), parts), dim3(256), 0, stream, (const float*)Y, ldy, M, N, rpb, part);
+        hipLaunchKernelGGL(colsum_partial_kernel<float>, dim3(cdiv(N, 128), parts), dim3(256), 0, stream, (const float*)Y, ldy, M, N, rpb, part);
     TCOW_CHECK_LAUNCH();
     return tcow_launch_slab_reduce(stream, part, parts, N, 1, N, out, N, accumulate);
 }
