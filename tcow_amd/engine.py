@@ -395,6 +395,7 @@ class SeekerFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, rgb, qm, *params):
         need = any(ctx.needs_input_grad[3:])
+        ctx.set_materialize_grads(False)      # an unused output (e.g. output_flags in Kubric training) arrives as None, not zeros
         out_mask, flags, sv = run_forward(module, rgb, qm, params, save=need)
         ctx.module = module
         ctx.sv = sv

@@ -1,0 +1,54 @@
+"""CPU, world_size 2 over gloo: the bucketed gradient averaging used by the data-parallel step."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from tcow_amd import ddp, synth
+    r, lr, w = ddp.init_distributed(backend='gloo')
+    assert (r, w) == (rank, world)
+    sync = ddp.GradSync(world)
+    buckets = {name: torch.full((n,), float(rank + 1) * (i + 1)) for i, (name, n) in enumerate([('head', 7), (1, 1000), (0, 1000), ('embed', 33)])}
+    for name, flat in buckets.items():
+        sync(name, flat)                       # engine.run_backward fires the hook in exactly this way, bucket by bucket
+    sync.finish()
+    ok = all(torch.allclose(flat, torch.full_like(flat, 1.5 * (i + 1))) for i, flat in enumerate(buckets.values()))
+    lin = torch.nn.Linear(4, 4)
+    torch.manual_seed(rank); torch.nn.init.normal_(lin.weight)
+    ddp.broadcast_parameters(lin)
+    gathered = [torch.zeros_like(lin.weight) for _ in range(world)]
+    dist.all_gather(gathered, lin.weight.data)
+    ok = ok and torch.equal(gathered[0], gathered[1])
+    clip_a = synth.make_clip(1, 2, 16, 16, seed=ddp.shard_seed(900, rank))['rgb']
+    ok = ok and sync.launched == ['head', 1, 0, 'embed'] and sync.bytes == (7 + 2000 + 33) * 4
+    q.put((rank, bool(ok), float(clip_a.sum())))
+    dist.destroy_process_group()
+
+
+def test_gradsync_two_ranks_gloo():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs: p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs: p.join(timeout=60)
+    assert all(ok for _, ok, _ in res)
+    assert res[0][2] != res[1][2]              # ranks draw different clips (weak scaling: 1 clip per rank)
+
+
+def test_single_process_is_a_noop():
+    from tcow_amd import ddp
+    sync = ddp.GradSync(1)
+    t = torch.ones(5)
+    sync('x', t); sync.finish()
+    assert torch.equal(t, torch.ones(5)) and sync.pending == []

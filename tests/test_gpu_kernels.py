@@ -1,0 +1,235 @@
+"""GPU: every libtcow_hip entry point, called through the C ABI, against a plain PyTorch fp32 reference of the same op.
+Tolerances: f32 mode ~1e-5 relative (exact-f32 MFMA/FMA, different summation order); bf16 mode ~1e-2 relative of the
+tensor's max (bf16 operands, f32 accumulation)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = a.detach(), b.detach()
+    return float((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-12))
+
+
+@pytest.fixture(scope='module')
+def ops(cuda):
+    from tcow_amd import ops as o
+    return o
+
+
+MODES = [('f32', 2e-5), ('bf16', 2e-2)]
+
+
+def _mode(ops, name):
+    return (ops.F32, torch.float32) if name == 'f32' else (ops.BF16, torch.bfloat16)
+
+
+@pytest.mark.parametrize('mname,tol', MODES)
+@pytest.mark.parametrize('M,K,N', [(1, 64, 64), (300, 64, 192), (130, 128, 48), (1000, 1024, 256), (4097, 768, 768)])
+def test_gemm_nt_epilogues(ops, cuda, mname, tol, M, K, N):
+    mode, dt = _mode(ops, mname)
+    g = torch.Generator(device='cuda').manual_seed(M + N)
+    A = torch.randn(M, K, device=cuda, generator=g).to(dt); W = (torch.randn(N, K, device=cuda, generator=g) * 0.05).to(dt)
+    bias = torch.randn(N, device=cuda, generator=g); rs = torch.rand(M, device=cuda, generator=g) + 0.5; resid = torch.randn(M, N, device=cuda, generator=g)
+    ref0 = A.double() @ W.double().t()
+    C = ops.gemm_nt(mode, A, W, torch.empty(M, N, device=cuda, dtype=dt))
+    assert rel(C, ref0) < tol
+    C = ops.gemm_nt(mode, A, W, torch.empty(M, N, device=cuda), bias=bias, row_scale=rs, resid=resid)
+    assert rel(C, (ref0 + bias.double()) * rs.double()[:, None] + resid.double()) < tol
+    inplace = resid.clone()                                                   # residual may alias the f32 output
+    ops.gemm_nt(mode, A, W, inplace, bias=bias, resid=inplace)
+    assert rel(inplace, ref0 + bias.double() + resid.double()) < tol
+    aux = torch.empty(M, N, device=cuda, dtype=dt)
+    C = ops.gemm_nt(mode, A, W, torch.empty(M, N, device=cuda, dtype=dt), bias=bias, act=ops.ACT_GELU, aux=aux)
+    assert rel(C, F.gelu(ref0 + bias.double())) < tol and rel(aux, ref0 + bias.double()) < tol
+    pre = torch.randn(M, N, device=cuda, generator=g).to(dt)
+    x = pre.double().requires_grad_(True)
+    dg = torch.autograd.grad(F.gelu(x).sum(), x)[0]
+    C = ops.gemm_nt(mode, A, W, torch.empty(M, N, device=cuda, dtype=dt), act=ops.ACT_DGELU, aux=pre)
+    assert rel(C, ref0 * dg) < tol
+
+
+@pytest.mark.parametrize('mname,tol', MODES)
+@pytest.mark.parametrize('M,N,K', [(5, 64, 64), (300, 192, 256), (2057, 48, 1024), (9030, 768, 768)])
+def test_gemm_tn_weight_and_bias_grad(ops, cuda, mname, tol, M, N, K):
+    mode, dt = _mode(ops, mname)
+    g = torch.Generator(device='cuda').manual_seed(M)
+    dY = torch.randn(M, N, device=cuda, generator=g).to(dt); X = torch.randn(M, K, device=cuda, generator=g).to(dt)
+    dW = torch.empty(N, K, device=cuda); db = torch.empty(N, device=cuda)
+    ops.gemm_tn(mode, dY, X, dW, bias_grad=db)
+    ref = dY.double().t() @ X.double()
+    assert rel(dW, ref) < max(tol / 4, 1e-5) and rel(db, dY.double().sum(0)) < 1e-4
+    ops.gemm_tn(mode, dY, X, dW, bias_grad=db, accumulate=True)
+    assert rel(dW, 2 * ref) < max(tol / 4, 1e-5) and rel(db, 2 * dY.double().sum(0)) < 1e-4
+
+
+def test_gemm_rejects_bad_arguments(ops, cuda):
+    from tcow_amd._lib import TcowError
+    A = torch.zeros(8, 72, device=cuda, dtype=torch.bfloat16); W = torch.zeros(8, 72, device=cuda, dtype=torch.bfloat16)
+    with pytest.raises(TcowError):                                            # K not a multiple of 64 in bf16 mode
+        ops.gemm_nt(ops.BF16, A, W, torch.empty(8, 8, device=cuda, dtype=torch.bfloat16))
+    with pytest.raises(TcowError):                                            # no silent CPU fallback
+        ops.gemm_nt(ops.F32, torch.zeros(4, 4), torch.zeros(4, 4), torch.zeros(4, 4))
+
+
+@pytest.mark.parametrize('mname,tol', MODES)
+@pytest.mark.parametrize('rows,D', [(7, 64), (1000, 256), (9030, 768), (33, 1024)])
+def test_layernorm_fwd_bwd(ops, cuda, mname, tol, rows, D):
+    mode, dt = _mode(ops, mname)
+    g = torch.Generator(device='cuda').manual_seed(rows)
+    x = torch.randn(rows, D, device=cuda, generator=g) * 2 + 0.5
+    w = torch.rand(D, device=cuda, generator=g) + 0.5; b = torch.randn(D, device=cuda, generator=g)
+    y = torch.empty(rows, D, device=cuda, dtype=dt); mu = torch.empty(rows, device=cuda); rs = torch.empty(rows, device=cuda)
+    ops.layernorm_fwd(mode, x, w, b, y, mu, rs)
+    xd = x.double().requires_grad_(True); wd = w.double().requires_grad_(True); bd = b.double().requires_grad_(True)
+    ref = F.layer_norm(xd, (D,), wd, bd, 1e-6)
+    assert rel(y, ref) < tol and rel(mu, x.double().mean(1)) < 1e-5
+    dy = torch.randn(rows, D, device=cuda, generator=g).to(dt); dres = torch.randn(rows, D, device=cuda, generator=g)
+    gx, gw, gb = torch.autograd.grad((ref * dy.double()).sum(), [xd, wd, bd])
+    dx = torch.empty(rows, D, device=cuda); dg = torch.empty(D, device=cuda); db = torch.empty(D, device=cuda)
+    ops.layernorm_bwd(mode, dy, x, mu, rs, w, dres, dx, dg, db)
+    assert rel(dx, gx + dres.double()) < 1e-4 and rel(dg, gw) < 1e-4 and rel(db, gb) < 1e-4
+
+
+def _ref_attn(qkv, B, T, S, D, heads, ca, spatial):
+    x = qkv.float().reshape(B, T, S, 3, heads, 64)
+    out = torch.zeros(B, T, S, heads, 64, device=qkv.device)
+    if spatial:
+        s0 = 0 if ca in (0, 1) else 1
+        q, k, v = [x[:, :, s0:, i].permute(0, 1, 3, 2, 4) for i in range(3)]
+        out[:, :, s0:] = (((q @ k.transpose(-1, -2)) * 0.125).softmax(-1) @ v).permute(0, 1, 3, 2, 4)
+    else:
+        q, k, v = [x[:, :, 1:, i].permute(0, 2, 3, 1, 4) for i in range(3)]
+        a = (q @ k.transpose(-1, -2)) * 0.125
+        if ca > 0:                                                            # vit.py:93-99
+            keep = torch.ones(T, T, dtype=torch.bool, device=qkv.device).tril(0 if ca <= 2 else ca - 2)
+            a = a.masked_fill(~keep, -1e10)
+        out[:, :, 1:] = (a.softmax(-1) @ v).permute(0, 3, 1, 2, 4)
+    return out.reshape(B * T * S, D)
+
+
+@pytest.mark.parametrize('mname,tol', [('f32', 2e-5), ('bf16', 1.5e-2)])
+@pytest.mark.parametrize('spatial,B,T,S,heads,ca', [
+    (False, 1, 4, 17, 4, 1), (False, 2, 30, 21, 2, 1), (False, 1, 30, 9, 2, 0), (False, 1, 7, 9, 2, 3), (False, 1, 40, 9, 2, 1), (False, 1, 70, 5, 1, 2),
+    (True, 1, 2, 17, 4, 1), (True, 2, 3, 301, 2, 1), (True, 1, 2, 77, 2, 2), (True, 1, 1, 2, 1, 0), (True, 1, 1, 333, 1, 1)])
+def test_attention_fwd_bwd(ops, cuda, mname, tol, spatial, B, T, S, heads, ca):
+    """Empty / ragged cases included: S=2 (one patch), T not a multiple of 32, sequences longer than the MFMA limits
+    (T=70, S=333 take the f32-arithmetic kernels), causal windows 0 / 1 / look-ahead."""
+    mode, dt = _mode(ops, mname)
+    D = heads * 64; M = B * T * S
+    g = torch.Generator(device='cuda').manual_seed(S * T)
+    qkv = torch.randn(M, 3 * D, device=cuda, generator=g).to(dt)
+    shape = ops.attn_shape(mode, B, T, S, D, heads, ca)
+    out = torch.full((M, D), float('nan'), device=cuda, dtype=dt); lse = torch.empty(M, heads, device=cuda)
+    ops.attn_fwd(shape, spatial, qkv, out, lse)
+    q32 = qkv.float().requires_grad_(True)
+    ref = _ref_attn(q32, B, T, S, D, heads, ca, spatial)
+    assert torch.isfinite(out.float()).all()
+    assert rel(out, ref) < tol
+    dout = torch.randn(M, D, device=cuda, generator=g).to(dt)
+    (ref * dout.float()).sum().backward()
+    dqkv = torch.full((M, 3 * D), float('nan'), device=cuda, dtype=dt)
+    ops.attn_bwd(shape, spatial, qkv, out, dout, lse, dqkv)
+    assert torch.isfinite(dqkv.float()).all()
+    assert rel(dqkv, q32.grad) < tol * 1.5
+
+
+def test_im2col_matches_reference_patch_order(ops, cuda):
+    """Bit-exact: pixel order of the patch gather against the map pushed through a one-hot Conv2d (G6)."""
+    _, g6 = load_golden('g6_index_maps')
+    pat = g6['patchify_4_4_2_3']                                              # [n, k] -> flat index in a (4, 8, 12) image
+    img = torch.arange(4 * 8 * 12, dtype=torch.float32, device=cuda).reshape(1, 4, 1, 8, 12)
+    out = torch.empty(1 * 1 * 7, 64, device=cuda)
+    ops.im2col(ops.F32, img[:, :3].contiguous(), img[:, 3:].contiguous(), 4, False, out)
+    assert torch.equal(out[0], torch.zeros(64, device=cuda))                  # slot 0 = cls placeholder
+    assert np.array_equal(out[1:].cpu().numpy().astype(np.int32), pat)
+
+
+@pytest.mark.parametrize('mname', ['f32', 'bf16'])
+def test_im2col_normalisation_and_embeddings(ops, cuda, mname):
+    mode, dt = _mode(ops, mname)
+    B, T, H, W, P, D = 2, 3, 32, 48, 16, 64
+    g = torch.Generator(device='cuda').manual_seed(0)
+    rgb = torch.rand(B, 3, T, H, W, device=cuda, generator=g); qm = (torch.rand(B, 1, T, H, W, device=cuda, generator=g) > 0.5).float()
+    N = (H // P) * (W // P); S = N + 1
+    out = torch.empty(B * T * S, 4 * P * P, device=cuda, dtype=dt)
+    ops.im2col(mode, rgb, qm, P, True, out)
+    x = torch.cat([(rgb - 0.45) / 0.225, qm], 1)                              # vision_tf.py:81-89: query channel untouched
+    ref = x.reshape(B, 4, T, H // P, P, W // P, P).permute(0, 2, 3, 5, 1, 4, 6).reshape(B, T, N, -1)
+    got = out.float().reshape(B, T, S, -1)
+    assert float(got[:, :, 0].abs().max()) == 0.0 and rel(got[:, :, 1:], ref) < (1e-6 if mname == 'f32' else 8e-3)
+    tok = torch.randn(B * T * S, D, device=cuda, generator=g); cls = torch.randn(D, device=cuda, generator=g)
+    pos = torch.randn(S, D, device=cuda, generator=g); te = torch.randn(T, D, device=cuda, generator=g)
+    want = tok.reshape(B, T, S, D) + pos[None, None] + te[None, :, None]
+    want[:, :, 0] = cls + pos[0]
+    ops.embed_fwd(tok, B, T, S, cls, pos, te)
+    assert rel(tok.reshape(B, T, S, D), want) < 1e-6
+    gsrc = torch.randn(B * T * S, D, device=cuda, generator=g)
+    dpos = torch.empty(S, D, device=cuda); dtime = torch.empty(T, D, device=cuda)
+    ops.embed_bwd(gsrc, B, T, S, dpos, dtime)
+    g4 = gsrc.reshape(B, T, S, D)
+    assert rel(dpos, g4.sum((0, 1))) < 1e-5 and rel(dtime, g4[:, :, 1:].sum((0, 2))) < 1e-5
+
+
+def test_cls_merge_and_adjoint(ops, cuda):
+    B, T, S, D = 2, 5, 7, 64
+    x = torch.randn(B * T * S, D, device=cuda)
+    for mode in (1, 0):
+        y = x.clone(); ops.cls_merge(y, B, T, S, mode)
+        y4, x4 = y.reshape(B, T, S, D), x.reshape(B, T, S, D)
+        want = x4[:, 0:1, 0] if mode == 1 else x4[:, :, 0].mean(1, keepdim=True)
+        assert rel(y4[:, :, 0], want.expand(B, T, D)) < 1e-6 and torch.equal(y4[:, :, 1:], x4[:, :, 1:])
+        gy = torch.randn_like(x); gx = gy.clone(); ops.cls_merge(gx, B, T, S, mode, backward=True)
+        # adjoint identity <merge(x), gy> == <x, merge^T(gy)>
+        assert abs(float((y.double() * gy.double()).sum() - (x.double() * gx.double()).sum())) < 1e-3
+
+
+@pytest.mark.parametrize('st,bilinear', [(4, True), (4, False), (2, True), (1, False)])
+def test_mask_head_pool_upsample(ops, cuda, st, bilinear):
+    """mask_tracker.py:113-132 against F.avg_pool2d + F.interpolate(align_corners=True)."""
+    B, T, Hp, Wp, P, C = 2, 3, 3, 4, 16, 3
+    S = Hp * Wp + 1
+    pm = torch.randn(B * T * S, C * P * P, device=cuda)
+    x = pm.reshape(B, T, S, C, P, P)[:, :, 1:].reshape(B, T, Hp, Wp, C, P, P).permute(0, 4, 1, 2, 5, 3, 6).reshape(B, C, T, Hp * P, Wp * P)
+    xf = x.permute(0, 2, 1, 3, 4).reshape(B * T, C, Hp * P, Wp * P).double().requires_grad_(True)
+    ref = F.avg_pool2d(xf, st, st) if st > 1 else xf
+    pooled = torch.empty(B * T, C, Hp * P // st, Wp * P // st, device=cuda)
+    ops.unpatchify_pool_fwd(ops.F32, pm, B * T, Hp, Wp, P, C, st, pooled)
+    assert rel(pooled, ref) < 1e-6
+    if st > 1:
+        up = F.interpolate(ref, scale_factor=st, mode='bilinear', align_corners=True) if bilinear else F.interpolate(ref, scale_factor=st, mode='nearest')
+    else:
+        up = ref
+    out = torch.empty(B, C, T, Hp * P, Wp * P, device=cuda)
+    ops.upsample_fwd(pooled, B, T, C, Hp * P // st, Wp * P // st, st, bilinear and st > 1, out)
+    want = up.reshape(B, T, C, Hp * P, Wp * P).permute(0, 2, 1, 3, 4)
+    assert rel(out, want) < 1e-5
+    gout = torch.randn_like(out)
+    (up * gout.permute(0, 2, 1, 3, 4).reshape_as(up).double()).sum().backward()
+    dpooled = torch.empty_like(pooled)
+    ops.upsample_bwd(gout, B, T, C, Hp * P // st, Wp * P // st, st, bilinear and st > 1, dpooled)
+    dpm = torch.empty_like(pm)
+    ops.unpatchify_pool_bwd(ops.F32, dpooled, B * T, Hp, Wp, P, C, st, dpm)
+    gx = xf.grad.reshape(B, T, C, Hp, P, Wp, P).permute(0, 1, 3, 5, 2, 4, 6).reshape(B, T, Hp * Wp, C * P * P)
+    got = dpm.reshape(B, T, S, -1)
+    assert float(got[:, :, 0].abs().max()) == 0.0 and rel(got[:, :, 1:], gx) < 1e-5
+
+
+def test_flags_casts(ops, cuda):
+    BT, S, D, Fc = 6, 13, 128, 3
+    x = torch.randn(BT * S, D, device=cuda); Wf = torch.randn(Fc, D, device=cuda); bf = torch.randn(Fc, device=cuda)
+    fl = torch.empty(BT, Fc, device=cuda)
+    ops.flags_fwd(x, BT, S, Wf, bf, fl)
+    assert rel(fl, x.reshape(BT, S, D)[:, 1:].mean(1) @ Wf.t() + bf) < 1e-5
+    W = torch.randn(100, 72, device=cuda)
+    Wc = torch.empty(100, 72, device=cuda, dtype=torch.bfloat16); Wt = torch.empty(72, 100, device=cuda, dtype=torch.bfloat16)
+    ops.cast_transpose(ops.BF16, W, Wc, Wt)
+    assert torch.equal(Wc, W.bfloat16()) and torch.equal(Wt, W.bfloat16().t().contiguous())    # round-to-nearest-even like torch
+    rs = torch.rand(50, device=cuda); src = torch.randn(50, 64, device=cuda); dst = torch.empty(50, 64, device=cuda, dtype=torch.bfloat16)
+    ops.scale_cast(ops.BF16, src, rs, dst)
+    assert torch.equal(dst, (src * rs[:, None]).bfloat16())

@@ -1,0 +1,80 @@
+"""CPU: the oracle restatement (oracle/seeker_oracle.py) against the golden vectors produced by the real reference."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_inputs, load_golden
+from oracle import seeker_oracle as so
+from tcow_amd import synth
+
+TOL = 1e-5     # fp32 restatement vs fp32 reference, abs on mask logits / flags (measured <= 9e-7)
+
+
+def _run(meta, grad=False):
+    cfg, sd, rgb, qm = golden_inputs(meta)
+    tsd = so.to_torch_state_dict(sd)
+    if grad:
+        for v in tsd.values():
+            v.requires_grad_(True)
+        return cfg, tsd, so.seeker_forward(tsd, cfg, rgb, qm)
+    with torch.no_grad():
+        return cfg, tsd, so.seeker_forward(tsd, cfg, rgb, qm)
+
+
+@pytest.mark.parametrize('name', ['g1_cfg1_d64', 'g1_cfg1_d256', 'g2_ca0', 'g2_ca2', 'g2_ca3', 'g2_cam1', 'g2_normemb_nearest',
+                                  'g2_stride1_prenorm', 'g2_stride2'])
+def test_forward_matches_reference(name):
+    meta, g = load_golden(name)
+    _, _, (om, fl) = _run(meta)
+    assert om.shape == g['output_mask'].shape and om.dtype == torch.float32
+    assert np.abs(om.numpy() - g['output_mask']).max() < TOL
+    assert np.abs(fl.numpy() - g['output_flags']).max() < TOL
+
+
+@pytest.mark.parametrize('name', ['g1_cfg1_d64', 'g1_cfg1_d256'])
+def test_gradients_match_reference(name):
+    meta, g = load_golden(name)
+    cfg, tsd, (om, fl) = _run(meta, grad=True)
+    Gm = torch.from_numpy(synth._rng(meta['seed'], 'gradprobe_mask').standard_normal(size=tuple(om.shape), dtype=np.float32))
+    Gf = torch.from_numpy(synth._rng(meta['seed'], 'gradprobe_flags').standard_normal(size=tuple(fl.shape), dtype=np.float32))
+    ((om * Gm).sum() + (fl * Gf).sum()).backward()
+    for k, ref in g.items():
+        if not k.startswith('grad::'):
+            continue
+        got = tsd[k[6:]].grad.numpy()
+        assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max() + 1e-7, k
+    for k, n in meta['grad_norms'].items():
+        if n is None:
+            assert tsd[k].grad is None or float(tsd[k].grad.abs().max()) == 0.0, k   # unused params (model.norm.*)
+        else:
+            assert abs(float(tsd[k].grad.norm()) - n) <= 1e-3 * n + 1e-7, k
+
+
+def summarise(om):
+    """Compact summary of a full-resolution output_mask, as stored by oracle/make_golden.py for the large fixtures:
+    4x4 average-pooled logits (1/16 of the data) + per-frame sums and abs-max."""
+    B, C, T, H, W = om.shape
+    pooled = torch.nn.functional.avg_pool2d(om.permute(0, 2, 1, 3, 4).reshape(B * T, C, H, W), 4, 4).numpy()
+    return pooled, om.numpy().sum(axis=(3, 4)), np.abs(om.numpy()).max(axis=(3, 4))
+
+
+def _check_summary(name):
+    meta, g = load_golden(name)
+    cfg, sd, rgb, qm = golden_inputs(meta)
+    with torch.no_grad():
+        om, fl = so.seeker_forward(so.to_torch_state_dict(sd), cfg, rgb, qm)
+    pooled, fsum, fmax = summarise(om)
+    assert np.abs(pooled - g['pooled']).max() < TOL
+    assert np.abs(fl.numpy() - g['output_flags']).max() < TOL
+    assert np.abs(fsum - g['frame_sum']).max() < 5e-2          # sums over 76 800 pixels
+    assert np.abs(fmax - g['frame_absmax']).max() < TOL
+
+
+def test_mid_size_matches_reference():
+    _check_summary('g3_mid_T8_96x128')
+
+
+def test_config2_full_size_matches_reference():
+    """BASELINE configs[1] geometry (T=30, 240x320, 12 layers): ~15 s of CPU."""
+    torch.set_num_threads(8)
+    _check_summary('g4_cfg2_T30_240x320')
