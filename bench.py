@@ -125,27 +125,27 @@ def main():
     sync = ddp.GradSync(world)
     net.seeker.grad_hook = sync
 
-    # synthetic Kubric-shaped clip for this rank: 1 clip, Qs queries (instances 0..Qs-1), query_time 0
+    # synthetic Kubric-shaped batch for this rank: 1 clip, Qs queries chosen by desirability, query_time 0 (README.md:42)
+    from tcow_amd.pipeline import SeekerPipeline
+    from tcow_amd.tcow_loss import default_args
     Qs = args.queries
-    clip = synth.make_clip(1, args.frames, args.height, args.width, seed=ddp.shard_seed(900, rank), n_objects=max(Qs, 4))
-    rgb = torch.from_numpy(clip['rgb']).to(dev).expand(Qs, -1, -1, -1, -1).contiguous()
-    qm = torch.cat([torch.from_numpy(synth.make_query_mask(clip, q, 0)) for q in range(Qs)], 0).to(dev)
-    div = torch.from_numpy(clip['div_segm']).to(dev).float()               # (1, K, T, H, W) amodal masks
-    target = torch.zeros(Qs, 3, args.frames, args.height, args.width, device=dev)
-    for q in range(Qs):
-        target[q, 0] = div[0, q]                                           # snitch channel; occluder / container empty
-    from tcow_amd.loss import mask_loss
+    data = synth.to_torch_tree(synth.make_kubric_batch(1, args.frames, args.height, args.width, seed=ddp.shard_seed(900, rank), n_objects=5), dev)
+    pipe = SeekerPipeline(net, num_queries=Qs, train_args=default_args(), phase='train', device=dev,
+                          rng=__import__('numpy').random.default_rng(ddp.shard_seed(900, rank)))
 
     timer = KernelTimer(); timer.wrap(ops)
+    state = {'step': 0}
 
     def step():
         opt.zero_grad(set_to_none=True)
-        out_mask, _ = net(rgb, qm)                                         # (Qs,3,T,H,W): the Qs sequential forwards of pipeline.py:134, batched
-        loss = mask_loss(out_mask, target)
-        loss.backward()
+        model_retval = pipe.forward_kubric(data)                           # query sampling, query/target masks, ONE batched Seeker call (pipeline.py:85-200)
+        progress = state['step'] / 1000.0
+        loss = pipe.step_losses(data, model_retval, progress)['total_seeker']   # loss.py:238-421: weighted BCE + bootstrapped BCE + soft Jaccard
+        loss.backward()                                                    # train.py:98
         sync.finish()
         torch.nn.utils.clip_grad_norm_(params, 0.3)                        # train.py:99-101
         opt.step()
+        state['step'] += 1
         return loss
 
     for _ in range(args.warmup):
@@ -184,7 +184,7 @@ def main():
                    config=dict(workload=f'TCOW Seeker train step: T={args.frames} {args.height}x{args.width} patch16, {args.depth}-layer divided '
                                f'space-time ViT (D={g["D"]}), num_queries={Qs}, causal_attention=1, 1 clip/GPU',
                                clips_per_gpu=1, num_queries=Qs, parallelism=f'dp{world}', optimizer='AdamW lr 1e-4, clip 0.3',
-                               loss='weighted BCE on 3 mask channels'),
+                               loss='TCOW mask losses (loss.py:238-421): class-balanced BCE + bootstrapped BCE + soft Jaccard on 3 channels'),
                    query_forwards_per_s=clips_per_s * Qs, step_model_tflops=step_tflops, step_mfma_frac=step_tflops / peak,
                    final_loss=float(loss.detach()), roofline=roof)
         if not args.no_cpu_baseline and world == 1:

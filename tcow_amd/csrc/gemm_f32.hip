@@ -123,7 +123,14 @@ __global__ void slab_reduce4_kernel(const float* __restrict__ slab, int nz, long
     const long stride = (long)gridDim.x * blockDim.x;
     for (; i < n4; i += stride) {
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int z = 0; z < nz; ++z) { const float4 v = ld4(slab + (size_t)z * slab_stride + i * 4); s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+        // 8 independent loads in flight per thread: the slabs are streamed once, latency not bandwidth is the enemy
+        for (int z0 = 0; z0 < nz; z0 += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = (z0 + u < nz) ? ld4(slab + (size_t)(z0 + u) * slab_stride + i * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+        }
         const long r = i / cols4, c = (i - r * cols4) * 4;
         float* o = out + r * ldo + c;
         if (accumulate) { const float4 p = ld4(o); s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w; }
@@ -187,8 +194,8 @@ int tcow_launch_slab_reduce(hipStream_t stream, const float* slab, int nz, long 
     const long n = rows * cols;
     const bool vec = (cols % 4 == 0) && (ldo % 4 == 0) && (slab_stride % 4 == 0) && ((reinterpret_cast<uintptr_t>(slab) | reinterpret_cast<uintptr_t>(out)) % 16 == 0);
     if (vec) {
-        int blocks = cdiv(n / 4, 256); if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(slab_reduce4_kernel, dim3(blocks), dim3(256), 0, stream, slab, nz, slab_stride, n / 4, out, cols / 4, ldo, accumulate);
+        int blocks = cdiv(n / 4, 64); if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(slab_reduce4_kernel, dim3(blocks), dim3(64), 0, stream, slab, nz, slab_stride, n / 4, out, cols / 4, ldo, accumulate);
     } else {
         int blocks = cdiv(n, 256); if (blocks > 2048) blocks = 2048;
         hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, stream, slab, nz, slab_stride, n, out, rows, cols, ldo, accumulate);

@@ -1,0 +1,40 @@
+"""Caller row M: per-frame mask IoU metrics of eval/metrics.py:9-113, as tensor reductions.
+
+The reference binarises on the device, copies the (B,Q,3,T) area tables to the host and walks them in a Python triple
+loop; here the same 12 numbers come out of masked tensor reductions (no host loop, works on CPU or GPU tensors)."""
+import torch
+
+
+def calculate_metrics_mask_track(output_mask, target_mask, plugin=False):
+    """output_mask logits, target_mask in {0,1} (or -1 = unlabeled frame for plugin data), shape (B,Q,3,T,H,W)
+    ((B,3,T,H,W) when plugin=True).  Returns the reference's dict: mean_* (f32, -1 when empty) and count_* (int32)."""
+    out_b = output_mask > 0.0                                              # metrics.py:19
+    tgt_b = target_mask > 0.5                                              # metrics.py:20
+    if plugin:
+        out_b, tgt_b = out_b[:, None], tgt_b[:, None]                      # metrics.py:26-29
+    Cmt = tgt_b.shape[2]
+    t_area = tgt_b.sum(dim=(-1, -2)).to(torch.float64)                     # (B,Q,C,T)
+    inter = (out_b & tgt_b).sum(dim=(-1, -2)).to(torch.float64)
+    union = (out_b | tgt_b).sum(dim=(-1, -2)).to(torch.float64)
+    iou = inter / (union + 1e-7)                                           # metrics.py:55-66
+    has = t_area > 0
+    sn = has[:, :, 0]
+
+    def agg(sel, values):
+        n = int(sel.sum())
+        mean = float(values[sel].mean()) if n > 0 else -1.0
+        return mean, n
+
+    res = {}
+    res['snitch_iou'] = agg(sn, iou[:, :, 0])
+    res['occl_mask_iou'] = agg(has[:, :, 1], iou[:, :, 1]) if Cmt >= 2 else (-1.0, 0)
+    res['cont_mask_iou'] = agg(has[:, :, 2], iou[:, :, 2]) if Cmt >= 3 else (-1.0, 0)
+    res['snitch_during_vis_iou'] = agg(sn & ~has[:, :, 1], iou[:, :, 0]) if Cmt >= 2 else (-1.0, 0)      # metrics.py:70-72
+    res['snitch_during_occl_iou'] = agg(sn & has[:, :, 1], iou[:, :, 0]) if Cmt >= 2 else (-1.0, 0)      # metrics.py:74-76
+    res['snitch_during_cont_iou'] = agg(sn & has[:, :, 2], iou[:, :, 0]) if Cmt >= 3 else (-1.0, 0)      # metrics.py:78-80
+    dev = output_mask.device
+    out = {}
+    for k, (m, n) in res.items():
+        out['mean_' + k] = torch.tensor(m, dtype=torch.float32, device=dev)
+        out['count_' + k] = torch.tensor(n, dtype=torch.int32, device=dev)
+    return out

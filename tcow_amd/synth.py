@@ -125,3 +125,92 @@ def make_query_mask(clip, instance=0, query_time=0):
     q = np.zeros(segm.shape, np.float32)
     q[:, :, query_time] = (segm[:, :, query_time] == instance + 1).astype(np.float32)
     return q
+
+
+def make_kubric_batch(B, T, H, W, seed=900, n_objects=5, M=36):
+    """Synthetic Kubric-shaped `data_retval` (data/data_kubric.py:133-155,425-432,
+    data/data_utils.py:95-241): K moving rectangles in painter's order (later = in front), amodal masks padded to
+    M = 36 instances (data/data.py:101), occlusion fractions (occluded, visible-area, total-area fractions), an
+    occlusion / containment DAG [containee/occludee, container/occluder] with channels (containment, direct
+    occlusion, frontmost occlusion), and a desirability table whose column 0 ranks the queries."""
+    K = n_objects
+    r = _rng(seed, f'kubric{B}x{T}x{H}x{W}x{K}')
+    rgb = r.random(size=(B, 3, T, H, W), dtype=np.float32)
+    segm = np.zeros((B, 1, T, H, W), np.uint8)
+    div = np.zeros((B, M, T, H, W), np.uint8)
+    boxes = np.zeros((B, K, T, 4), np.int64)
+    for b in range(B):
+        # the last (frontmost) object is large: it acts as occluder / container; small objects start (mostly) outside it
+        # so that they are valid queries at t = 0, and object 0 drifts behind it so that occlusion / containment occur.
+        bh = int(r.integers(H // 2, 3 * H // 4)); bw = int(r.integers(W // 2, 3 * W // 4))
+        by0 = r.uniform(0, H - bh); bx0 = r.uniform(0, W - bw)
+        bvy = r.uniform(-1, 1) * H / (4.0 * T); bvx = r.uniform(-1, 1) * W / (4.0 * T)
+        params = []
+        for k in range(K - 1):
+            h = int(r.integers(max(H // 8, 2), max(H // 4, 3))); w = int(r.integers(max(W // 8, 2), max(W // 4, 3)))
+            for _ in range(200):
+                y0 = r.uniform(0, H - h); x0 = r.uniform(0, W - w)
+                oy = max(0.0, min(y0 + h, by0 + bh) - max(y0, by0)); ox = max(0.0, min(x0 + w, bx0 + bw) - max(x0, bx0))
+                if oy * ox < 0.5 * h * w:
+                    break
+            if k == 0:      # ends inside the big object's final box
+                ye = np.clip(by0 + bvy * (T - 1), 0, H - bh) + (bh - h) / 2.0; xe = np.clip(bx0 + bvx * (T - 1), 0, W - bw) + (bw - w) / 2.0
+                vy = (ye - y0) / max(T - 1, 1); vx = (xe - x0) / max(T - 1, 1)
+            else:
+                vy = r.uniform(-1, 1) * H / (2.0 * T); vx = r.uniform(-1, 1) * W / (2.0 * T)
+            params.append((h, w, y0, x0, vy, vx))
+        params.append((bh, bw, by0, bx0, bvy, bvx))
+        for k, (h, w, y0, x0, vy, vx) in enumerate(params):
+            col = r.random(size=3, dtype=np.float32)
+            for t in range(T):
+                y = int(np.clip(y0 + vy * t, 0, H - h)); x = int(np.clip(x0 + vx * t, 0, W - w))
+                boxes[b, k, t] = (y, x, h, w)
+                div[b, k, t, y:y + h, x:x + w] = 1
+                segm[b, 0, t, y:y + h, x:x + w] = k + 1
+                rgb[b, :, t, y:y + h, x:x + w] = 0.5 * rgb[b, :, t, y:y + h, x:x + w] + 0.5 * col[:, None, None]
+    occl_fracs = np.zeros((B, M, T, 3), np.float32)
+    dag = np.zeros((B, T, M, M, 3), np.float32)
+    for b in range(B):
+        for t in range(T):
+            for i in range(K):
+                am = div[b, i, t] == 1
+                area = float(am.sum())
+                vis = float(((segm[b, 0, t] == i + 1) & am).sum())
+                occl_fracs[b, i, t] = (1.0 - vis / max(area, 1.0), vis / (H * W), area / (H * W))
+                for j in range(K):
+                    if j == i:
+                        continue
+                    cover = float((am & (segm[b, 0, t] == j + 1)).sum()) / max(area, 1.0)     # j visibly in front of i
+                    dag[b, t, i, j, 1] = cover
+                    dag[b, t, i, j, 2] = cover
+                    yi, xi, hi, wi = boxes[b, i, t]; yj, xj, hj, wj = boxes[b, j, t]
+                    if j > i and yi >= yj and xi >= xj and yi + hi <= yj + hj and xi + wi <= xj + wj:
+                        dag[b, t, i, j, 0] = 1.0                                               # box of i inside box of j
+    des = -np.ones((B, M, 7), np.float64)
+    for b in range(B):
+        for k in range(K):
+            vis0 = float(occl_fracs[b, k, 0, 1])
+            des[b, k, 0] = (occl_fracs[b, k, :, 0].mean() + 0.1 * k) if vis0 > 0.002 else -1.0   # invisible at t=0 -> never sampled
+            des[b, k, 1:] = r.random(size=6)
+    return {
+        'source_name': ['kubric'] * B,
+        'within_batch_idx': np.arange(B, dtype=np.int64),
+        'scene_dp': ['synthetic'] * B,
+        'kubric_retval': {
+            'pv_rgb_tf': rgb, 'pv_segm_tf': segm, 'pv_div_segm_tf': div,
+            'pv_inst_count': np.full((B, 1), K, np.int32),
+            'traject_retval_tf': {'query_time': np.zeros((B,), np.int64), 'occl_fracs_tf': occl_fracs,
+                                  'occl_cont_dag_tf': dag, 'desirability_tf': des},
+        },
+    }
+
+
+def to_torch_tree(x, device=None):
+    """numpy leaves -> torch tensors (optionally on `device`), lists / strings untouched."""
+    import torch
+    if isinstance(x, dict):
+        return {k: to_torch_tree(v, device) for k, v in x.items()}
+    if isinstance(x, np.ndarray):
+        t = torch.from_numpy(x)
+        return t.to(device) if device is not None else t
+    return x

@@ -1,0 +1,130 @@
+"""Caller row L: the TCOW mask-tracking objective of loss.py:55-421 in tensor ops.
+
+Not a kernel target: it supplies grad_output for the hand-written Seeker backward and completes the training step.
+Every rule of the reference is kept, including its quirks (cited inline), so that the scalars match golden values
+captured from the reference (tests/golden/g5_*.npz)."""
+import math
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .metrics import calculate_metrics_mask_track
+
+DEFAULT_ARGS = dict(track_lw=1.0, occl_mask_lw=0.5, cont_mask_lw=0.5, occluded_weight=5, occl_cont_zero_weight=0.02,
+                    class_balancing=True, focal_loss=False, aot_loss=0.8, hard_negative_factor=3.0,
+                    front_occl_thres=0.95, outer_cont_thres=0.75)      # args.py:182-212
+
+
+def default_args(**over):
+    d = dict(DEFAULT_ARGS); d.update(over)
+    return SimpleNamespace(**d)
+
+
+def bootstrap_warmup_loss(loss_pixels, topk_frac):                         # loss.py:13-17
+    k = int(topk_frac * loss_pixels.numel())
+    return torch.topk(loss_pixels.flatten(), k=k)[0].mean()
+
+
+def tversky_loss(logits, target, alpha=1.0, beta=1.0, eps=0.1):            # loss.py:20-32
+    if target.mean() >= 1e-6:
+        p0 = torch.sigmoid(logits); p1 = 1.0 - p0
+        g0 = target; g1 = 1.0 - target
+        num = torch.sum(p0 * g0)
+        den = num + alpha * torch.sum(p0 * g1) + beta * torch.sum(p1 * g0)
+        return 1.0 - (num / (den + eps))
+    return torch.tensor(0.0, device=logits.device)
+
+
+def hard_negative_band(target, H, W):
+    """loss.py:136-146: gaussian_blur(target, k, sigma=k) > 0 with k = odd(int(sqrt(HW)/12)) is a k x k box dilation
+    (all Gaussian taps are > 0.89 and the reflect padding only mirrors pixels that are inside the window anyway)."""
+    k = int(np.sqrt(H * W) / 12.0)
+    if k % 2 == 0:
+        k += 1
+    shp = target.shape
+    d = F.max_pool2d(target.reshape(-1, 1, H, W), kernel_size=k, stride=1, padding=k // 2).reshape(shp) > 0.0
+    return d & ~(target >= 0.5)
+
+
+class TcowLosses:
+    def __init__(self, train_args=None, phase='train'):
+        self.args = train_args if train_args is not None else default_args()
+        self.phase = phase
+
+    def frame_weights(self, sel_occl_fracs, query_time):                   # loss.py:55-83
+        fw = (sel_occl_fracs[..., 0] * float(self.args.occluded_weight)).to(torch.float32).clip(min=1.0)
+        fw = fw.clone()
+        fw[-1, :, query_time] *= 0.2      # loss.py:79 indexes with the leaked loop variable b == B-1: only the last clip
+        return fw
+
+    def pixel_weights(self, target, snitch_occl_by_ptr, no_hard_negatives=False):   # loss.py:85-148
+        (B, Q, T, H, W) = snitch_occl_by_ptr.shape
+        pw = torch.ones((B, Q, T, H, W), dtype=torch.float32, device=target.device)
+        if self.args.class_balancing:
+            pos = target == 1.0; neg = target == 0.0
+            pos_frac = float((pos.sum() / pos.numel()).clip(min=0.05)); neg_frac = float((neg.sum() / neg.numel()).clip(min=0.05))
+            if pos_frac > neg_frac:
+                pos_corr = np.power(neg_frac / pos_frac, 0.7); neg_corr = np.power(neg_frac / pos_frac, -0.3)
+            else:
+                pos_corr = np.power(pos_frac / neg_frac, -0.3); neg_corr = np.power(pos_frac / neg_frac, 0.7)
+            pw = torch.where(neg, pw * float(neg_corr), pw)
+            pw = torch.where(pos, pw * float(pos_corr), pw)
+        pw = torch.where(snitch_occl_by_ptr != 0, pw * 2.0, pw)
+        if self.args.hard_negative_factor > 1.0 and not no_hard_negatives:
+            pw = torch.where(hard_negative_band(target, H, W), pw * float(self.args.hard_negative_factor), pw)
+        return pw
+
+    def mask_loss(self, logits, target, weights, progress, apply_weights_for_aot):   # loss.py:164-225
+        which = weights
+        while which.ndim > 3:
+            which = which.any(dim=-1)
+        which = which[..., None, None].expand_as(weights)
+        if bool(which.any()) and float(weights.mean()) >= 1e-4:
+            lo = logits[which]; tg = target[which]; fw = weights[which]
+            if self.args.focal_loss:
+                raise NotImplementedError('focal_loss needs torchvision.ops.sigmoid_focal_loss (loss.py:49-51); default is BCE')
+            bce = F.binary_cross_entropy_with_logits(lo, tg, reduction='none')
+            custom = (bce * fw).mean()
+            if self.args.aot_loss > 0.0:
+                for_aot = bce * fw if apply_weights_for_aot else bce
+                topk_frac = min(max(1.0 - progress * 8.5, 0.15), 1.0)
+                boot = bootstrap_warmup_loss(for_aot, topk_frac)
+                jac = boot if apply_weights_for_aot else tversky_loss(lo, tg, 1.0, 1.0, 0.1)
+                loss = (boot + jac) / 2.0 * self.args.aot_loss + custom * (1.0 - self.args.aot_loss)
+            else:
+                loss = custom
+            loss = loss * torch.sqrt(which.float().mean())
+        else:
+            loss = torch.tensor(0.0, device=logits.device)
+        return loss
+
+    def per_example(self, model_retval, query_time, progress, metrics_only=False):   # loss.py:238-329
+        out = model_retval['output_mask']; tgt = model_retval['target_mask']
+        if metrics_only:
+            return {'metrics': calculate_metrics_mask_track(out, tgt)}
+        a = self.args
+        res = {'track': None, 'occl_mask': None, 'cont_mask': None}
+        if a.track_lw > 0.0:
+            fw = self.frame_weights(model_retval['sel_occl_fracs'], query_time)
+            pw = self.pixel_weights(tgt[:, :, 0], model_retval['snitch_occl_by_ptr'][:, :, 0])
+            sw = fw[..., None, None] * pw
+            model_retval['snitch_weights'] = sw
+            res['track'] = self.mask_loss(out[:, :, 0], tgt[:, :, 0], sw, progress, False)
+        for name, ch, lw in (('occl_mask', 1, a.occl_mask_lw), ('cont_mask', 2, a.cont_mask_lw)):
+            if lw > 0.0:
+                w = tgt[:, :, ch].any(dim=-1).any(dim=-1)[..., None, None].expand_as(tgt[:, :, ch]).to(torch.float32)
+                w = w * (1.0 - a.occl_cont_zero_weight) + a.occl_cont_zero_weight
+                res[name] = self.mask_loss(out[:, :, ch], tgt[:, :, ch], w, progress, True)
+        res['metrics'] = calculate_metrics_mask_track(out, tgt)
+        return res
+
+    def entire_batch(self, loss_retval):                                   # loss.py:331-421 (logging omitted)
+        a = self.args
+        terms = {k: (torch.mean(v) if torch.is_tensor(v) else -1.0) for k, v in loss_retval.items() if k != 'metrics'}
+        total = terms['track'] * a.track_lw + terms['occl_mask'] * a.occl_mask_lw + terms['cont_mask'] * a.cont_mask_lw
+        out = {k: (float(v.detach()) if torch.is_tensor(v) else v) for k, v in terms.items()}
+        out['total_seeker'] = total
+        out['metrics'] = loss_retval['metrics']
+        return out

@@ -1,0 +1,89 @@
+"""Caller rows P / L / M (pipeline, loss, metrics) against golden values captured from the real reference
+(tests/golden/g5_pipeline_cfg1.npz, written by oracle/make_golden_pipeline.py)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import build_hip_seeker, load_golden
+from tcow_amd import synth
+from tcow_amd.metrics import calculate_metrics_mask_track
+from tcow_amd.pipeline import SeekerPipeline, sample_query_inds
+from tcow_amd.tcow_loss import default_args
+
+B, Qs, T, H, W = 2, 3, 4, 64, 64
+
+
+def _data(device=None):
+    return synth.to_torch_tree(synth.make_kubric_batch(B, T, H, W, seed=900), device)
+
+
+class _Replay(torch.nn.Module):
+    """Stands in for the model on CPU: replays the reference's own output_mask (B,Qs,3,T,H,W)."""
+    def __init__(self, out): super().__init__(); self.out = out
+    def forward(self, rgb, qm):
+        assert tuple(rgb.shape) == (B * Qs, 3, T, H, W) and tuple(qm.shape) == (B * Qs, 1, T, H, W)
+        return self.out.reshape(B * Qs, 3, T, H, W), None
+
+
+@pytest.mark.parametrize('phase', ['test', 'train'])
+def test_query_selection_masks_losses_metrics_match_reference(phase):
+    _, g = load_golden('g5_pipeline_cfg1')
+    data = _data()
+    ref_out = torch.from_numpy(g[f'{phase}::output_mask'])
+    pipe = SeekerPipeline(_Replay(ref_out), num_queries=Qs, train_args=default_args(hard_negative_factor=1.0), phase=phase, device='cpu')
+    sel = torch.from_numpy(g[f'{phase}::sel_query_inds'])
+    if phase == 'test':                                                     # deterministic top-Qs by desirability (my_utils.py:287-292)
+        kr = data['kubric_retval']
+        assert torch.equal(sample_query_inds(B, Qs, kr['pv_inst_count'], kr['traject_retval_tf']['desirability_tf'], 'test'), sel)
+    mr = pipe.forward_kubric(data, sel_query_inds=sel)
+    for k in ('seeker_query_mask', 'snitch_occl_by_ptr', 'full_occl_cont_id', 'target_mask', 'sel_occl_fracs'):   # bit-exact (integer / mask work)
+        assert np.array_equal(mr[k].numpy(), g[f'{phase}::{k}']), k
+    assert np.allclose(mr['sel_desirability'].numpy(), g[f'{phase}::sel_desirability'])
+    for tag, progress in (('p0', 0.0), ('p5', 0.5)):
+        res = pipe.step_losses(data, mr, progress)
+        for k in ('track', 'occl_mask', 'cont_mask'):
+            assert abs(res[k] - float(g[f'{phase}_{tag}::{k}'])) < 2e-6, (k, tag)
+        assert abs(float(res['total_seeker']) - float(g[f'{phase}_{tag}::total_seeker'])) < 2e-6
+        for k, v in res['metrics'].items():
+            ref = g[f'{phase}_{tag}::metric::{k}']
+            assert (int(v) == int(ref)) if 'count' in k else abs(float(v) - float(ref)) < 1e-6, k
+    assert np.allclose(mr['snitch_weights'].numpy(), g[f'{phase}::snitch_weights'], atol=1e-6)
+
+
+def test_metrics_edge_cases():
+    out = torch.full((1, 1, 3, 2, 4, 4), -1.0); tgt = torch.zeros(1, 1, 3, 2, 4, 4)
+    m = calculate_metrics_mask_track(out, tgt)                              # nothing annotated -> means -1, counts 0 (metrics.py:85-96)
+    assert all(float(v) == -1.0 for k, v in m.items() if k.startswith('mean')) and all(int(v) == 0 for k, v in m.items() if k.startswith('count'))
+    tgt[0, 0, 0, 0, :2] = 1; out[0, 0, 0, 0, :1] = 1.0
+    m = calculate_metrics_mask_track(out, tgt)
+    assert int(m['count_snitch_iou']) == 1 and abs(float(m['mean_snitch_iou']) - 0.5) < 1e-6 and int(m['count_snitch_during_vis_iou']) == 1
+    mp = calculate_metrics_mask_track(out[:, 0], tgt[:, 0] - 0.0, plugin=True)
+    assert abs(float(mp['mean_snitch_iou']) - 0.5) < 1e-6
+
+
+def test_hard_negative_band_matches_reference_blur():
+    from tcow_amd.tcow_loss import hard_negative_band
+    _, g = load_golden('g5_pipeline_cfg1')
+    tm = torch.from_numpy(g['test::target_mask'])[:, :, 0]
+    assert int(hard_negative_band(tm, H, W).sum()) == int(g['hard_negative_band_sum'])   # equality with gaussian_blur>0 asserted at generation
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('precision,tol', [('fp32', 2e-5), ('bf16', 2e-2)])
+def test_full_step_on_gpu_matches_reference(cuda, precision, tol):
+    """Synthetic Kubric batch -> HIP Seeker (3 queries batched) -> TCOW loss -> backward, vs the reference's scalars."""
+    _, g = load_golden('g5_pipeline_cfg1')
+    cfg = synth.seeker_config(num_total_frames=T, frame_height=H, frame_width=W, embed_dim=256, depth=2, num_heads=4, causal_attention=1)
+    net = build_hip_seeker(cfg, synth.make_state_dict(cfg, 900), precision).cuda().train()
+    pipe = SeekerPipeline(net, num_queries=Qs, train_args=default_args(hard_negative_factor=1.0), phase='train', device='cuda')
+    data = _data('cuda')
+    mr = pipe.forward_kubric(data, sel_query_inds=torch.from_numpy(g['train::sel_query_inds']))
+    assert float((mr['output_mask'].detach().cpu() - torch.from_numpy(g['train::output_mask'])).abs().max()) < (1e-4 if precision == 'fp32' else 5e-3)
+    res = pipe.step_losses(data, mr, 0.0)
+    assert abs(float(res['total_seeker']) - float(g['train_p0::total_seeker'])) < tol
+    res['total_seeker'].backward()
+    gn = sum(float(p.grad.norm()) ** 2 for p in net.parameters() if p.grad is not None) ** 0.5
+    assert abs(gn - float(g['train::grad_norm_total'])) < (1e-3 if precision == 'fp32' else 5e-2) * float(g['train::grad_norm_total'])
+    gb = net.seeker.tracker_post_linear.bias.grad.cpu().numpy()
+    ref = g['train::grad::seeker.tracker_post_linear.bias']
+    assert np.abs(gb - ref).max() < (1e-4 if precision == 'fp32' else 5e-2) * np.abs(ref).max() + 1e-8
