@@ -40,33 +40,27 @@ def parse():
 
 
 class KernelTimer:
-    """HIP-event timing of every GEMM launch (the dominant kernel) on the stream it is launched on."""
+    """HIP-event timing of every NT-GEMM launch (the dominant kernel) inside the timed region, recorded by the library
+    itself on the launch stream (tcow_prof_gemm_begin/_end: two hipEventRecord per launch, no Python in the loop)."""
 
     def __init__(self):
-        self.recs = []
-        self.enabled = False
+        from tcow_amd import _lib
+        self.L = _lib
+        self.result = None
 
-    def wrap(self, ops):
-        orig = ops.gemm_nt
-        timer = self
+    def begin(self, max_launches):
+        self.L.check(self.L.lib().tcow_prof_gemm_begin(int(max_launches)), 'tcow_prof_gemm_begin')
 
-        def timed(mode, A, W, out, **kw):
-            if not timer.enabled:
-                return orig(mode, A, W, out, **kw)
-            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-            e0.record()
-            r = orig(mode, A, W, out, **kw)
-            e1.record()
-            timer.recs.append((e0, e1, 2.0 * A.shape[0] * W.shape[0] * A.shape[1]))
-            return r
-        ops.gemm_nt = timed
+    def end(self):
+        import ctypes
+        ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_long()
+        self.L.check(self.L.lib().tcow_prof_gemm_end(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n)), 'tcow_prof_gemm_end')
+        if n.value:
+            self.result = dict(launches=n.value, avg_us=ms.value * 1e3 / n.value, flops_per_launch=fl.value / n.value,
+                               tflops=fl.value / (ms.value * 1e-3) / 1e12)
 
     def summary(self):
-        if not self.recs:
-            return None
-        ms = sum(a.elapsed_time(b) for a, b, _ in self.recs)
-        fl = sum(f for _, _, f in self.recs)
-        return dict(launches=len(self.recs), avg_us=ms * 1e3 / len(self.recs), flops_per_launch=fl / len(self.recs), tflops=fl / (ms * 1e-3) / 1e12)
+        return self.result
 
 
 def cpu_baseline(cfg, budget_s):
@@ -133,7 +127,7 @@ def main():
     pipe = SeekerPipeline(net, num_queries=Qs, train_args=default_args(), phase='train', device=dev,
                           rng=__import__('numpy').random.default_rng(ddp.shard_seed(900, rank)))
 
-    timer = KernelTimer(); timer.wrap(ops)
+    timer = KernelTimer()
     state = {'step': 0}
 
     def step():
@@ -153,7 +147,7 @@ def main():
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
-    timer.enabled = True
+    timer.begin(400 * args.steps)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -161,7 +155,7 @@ def main():
     if world > 1:
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
-    timer.enabled = False
+    timer.end()
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)

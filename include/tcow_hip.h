@@ -75,6 +75,12 @@ typedef struct {
 } tcow_gemm_args;
 int tcow_gemm_nt(void* stream, const tcow_gemm_args* args);
 
+/* Measurement aid for bench.py: between _begin and _end every tcow_gemm_nt launch is bracketed by HIP events recorded
+ * on its own stream; _end synchronises on them and returns the summed event time (ms), the summed 2*M*N*K and the
+ * number of launches (at most max_launches are recorded). */
+int tcow_prof_gemm_begin(int max_launches);
+int tcow_prof_gemm_end(double* total_ms, double* total_flops, long* launches);
+
 /* Weight-gradient GEMM  dW[N,K] (f32) (+)= dY[M,N]^T . X[M,K]   (autograd of nn.Linear.weight).
  * dY, X: `dtype` row-major (ldy, ldx in elements).  The M (token) dimension is split across workgroups;
  * partial tiles go to `workspace` (f32, tcow_gemm_tn_workspace_bytes) and are reduced deterministically.

@@ -2,6 +2,8 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <vector>
+
 #include "common.h"
 
 static thread_local char g_err[512] = "";
@@ -27,7 +29,53 @@ extern "C" {
 int tcow_version(void) { return 1; }
 const char* tcow_last_error(void) { return g_err; }
 
+// ---- optional low-overhead HIP-event timing of the dominant kernel (the NT GEMM), on the launch stream
+static std::vector<hipEvent_t> g_prof_events;
+static std::vector<double> g_prof_flops;
+static size_t g_prof_used = 0;
+static bool g_prof_on = false;
+
+int tcow_prof_gemm_begin(int max_launches) {
+    TCOW_CHECK_ARG(max_launches > 0, "tcow_prof_gemm_begin: max_launches must be positive");
+    while (g_prof_events.size() < (size_t)max_launches * 2) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) { tcow_set_error("tcow_prof_gemm_begin: hipEventCreate failed"); return TCOW_ERR_LAUNCH; }
+        g_prof_events.push_back(e);
+    }
+    g_prof_flops.assign(max_launches, 0.0);
+    g_prof_used = 0;
+    g_prof_on = true;
+    return TCOW_OK;
+}
+
+int tcow_prof_gemm_end(double* total_ms, double* total_flops, long* launches) {
+    g_prof_on = false;
+    double ms = 0.0, fl = 0.0;
+    for (size_t i = 0; i < g_prof_used; ++i) {
+        if (hipEventSynchronize(g_prof_events[2 * i + 1]) != hipSuccess) { tcow_set_error("tcow_prof_gemm_end: event sync failed"); return TCOW_ERR_LAUNCH; }
+        float t = 0.f;
+        (void)hipEventElapsedTime(&t, g_prof_events[2 * i], g_prof_events[2 * i + 1]);
+        ms += t; fl += g_prof_flops[i];
+    }
+    if (total_ms) *total_ms = ms;
+    if (total_flops) *total_flops = fl;
+    if (launches) *launches = (long)g_prof_used;
+    return TCOW_OK;
+}
+
+static int gemm_nt_dispatch(void* stream, const tcow_gemm_args* a);
+
 int tcow_gemm_nt(void* stream, const tcow_gemm_args* a) {
+    if (!g_prof_on || a == nullptr || g_prof_used >= g_prof_flops.size()) return gemm_nt_dispatch(stream, a);
+    const size_t i = g_prof_used++;
+    g_prof_flops[i] = 2.0 * a->M * (double)a->N * a->K;
+    (void)hipEventRecord(g_prof_events[2 * i], (hipStream_t)stream);
+    const int rc = gemm_nt_dispatch(stream, a);
+    (void)hipEventRecord(g_prof_events[2 * i + 1], (hipStream_t)stream);
+    return rc;
+}
+
+static int gemm_nt_dispatch(void* stream, const tcow_gemm_args* a) {
     TCOW_CHECK_ARG(a != nullptr, "tcow_gemm_nt: null args");
     TCOW_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0, "tcow_gemm_nt: bad shape M=%d N=%d K=%d", a->M, a->N, a->K);
     TCOW_CHECK_ARG(a->A && a->W && a->C, "tcow_gemm_nt: null operand");
