@@ -12,16 +12,19 @@
 // c ^ g(r), g(r) = ((r>>1)&1)<<2 | ((r>>2)&3), which is conflict-free for both the ds_read_b128 row fragments and
 // the transpose reads (applied on the SOURCE address: the LDS image of a direct-to-LDS load stays lane-linear).
 //
-//   SHARED = true  (spatial):  one 256-thread workgroup per (clip, frame, head); all K/V (or Q/dO) tiles of the
-//                              sequence resident in LDS (S <= 320: 80 KiB -> 2 workgroups per CU); waves take query
-//                              (or key) tiles round-robin.
+//   streaming (spatial, default; any length): a 256-thread workgroup owns 4 query (or key) tiles of one (clip, frame, head),
+//                              one per wave, and walks the other side in chunks of 4 tiles through 32 KiB of LDS
+//                              (4 workgroups per CU); also used for temporal sequences longer than 64 frames.
 //   SHARED = false (temporal): one wave per (clip, slot, head) with wave-private LDS tiles (T <= 64), no barriers.
-// Longer sequences use the f32 kernels of attention_simple.hip.
+//   SHARED = true            : earlier variant with the whole sequence resident in LDS (S <= 320), kept for A/B runs
+//                              (TCOW_ATTN_SHARED=1); the streaming kernels are 20-50 % faster (profiles/r01_attention.txt).
 //
 // Backward (recompute from the saved log-sum-exp, delta = rowsum(dO * O) precomputed):
 //   dkv kernel: a wave owns key tile j: S = Q K^T and dP = dO V^T in the (rows = q in registers, cols = key in lanes)
 //               orientation, so P and dS feed dV += P^T dO, dK += dS^T Q as A operands without any shuffle.
 //   dq  kernel: a wave owns query tile i: S^T, dP^T in the forward orientation, dQ += dS K.
+#include <stdlib.h>
+
 #include "attention_common.h"
 
 namespace {
@@ -85,6 +88,62 @@ __device__ __forceinline__ WorkId work_id(const SeqDesc& sd, int wave) {
     return w;
 }
 
+// One 32-key tile against one 32-query tile (forward): S^T = K Q^T, online softmax, O^T += V^T P^T.
+__device__ __forceinline__ void fwd_tile(const SeqDesc& sd, const char* ktile, const char* vtile, const bf16x8 (&qf)[4], int j, int qt, int q, int l31, int hi, int lane,
+                                         float& m, float& l, f32x16& o0, f32x16& o1) {
+    const float sc = kScale * kLog2e;
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(ktile, l31, ks, hi), qf[ks], s, 0, 0, 0);
+    const bool need_mask = (32 * j + 31 >= sd.L) || ((long)32 * j + 31 > (long)32 * qt + sd.diag);
+    float mx = -1e30f;
+    float p[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float v = s[r] * sc;
+        if (need_mask) {
+            const int key = 32 * j + crow32(r, hi);
+            if (key >= sd.L || (long)key > (long)q + sd.diag) v = -1e30f;
+        }
+        p[r] = v; mx = fmaxf(mx, v);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mn = fmaxf(m, mx);
+    const float alpha = exp2f(m - mn);
+    float ps = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { const float e = (p[r] <= -1e29f) ? 0.f : exp2f(p[r] - mn); p[r] = e; ps += e; }
+    l = l * alpha + ps;
+    m = mn;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+    const bf16x8 pb0 = pack8(p), pb1 = pack8(p + 8);
+    o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(vtile, 0, 0, lane), pb0, o0, 0, 0, 0);
+    o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(vtile, 1, 0, lane), pb1, o0, 0, 0, 0);
+    o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(vtile, 0, 1, lane), pb0, o1, 0, 0, 0);
+    o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(vtile, 1, 1, lane), pb1, o1, 0, 0, 0);
+}
+
+// normalise and store one query tile's output (+ log-sum-exp)
+__device__ __forceinline__ void fwd_store(const SeqDesc& sd, long base, int head, int q, int hi, float m, float l, const f32x16& o0, const f32x16& o1,
+                                          bf16_t* __restrict__ out, float* __restrict__ lse) {
+    l += __shfl_xor(l, 32, 64);
+    if (q < sd.L) {
+        const float inv = 1.0f / l;
+        const long row = base + (long)q * sd.pos_stride;
+        bf16_t* orow = out + row * sd.D + head * ATT_HD;
+        // O^T C layout: register r of lane (q, hi) holds d = 32*dt + 8*(r>>2) + 4*hi + (r&3): 4 consecutive d per group
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            st4(orow + 8 * gq + 4 * hi, make_float4(o0[4 * gq] * inv, o0[4 * gq + 1] * inv, o0[4 * gq + 2] * inv, o0[4 * gq + 3] * inv));
+            st4(orow + 32 + 8 * gq + 4 * hi, make_float4(o1[4 * gq] * inv, o1[4 * gq + 1] * inv, o1[4 * gq + 2] * inv, o1[4 * gq + 3] * inv));
+        }
+        if (lse && hi == 0) lse[row * sd.heads + head] = (m + log2f(l)) * 0.6931471805599453f;   // natural-log LSE of the scaled scores
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ forward
 template <bool SHARED>
 __global__ __launch_bounds__(256) void attn_fwd_mfma(SeqDesc sd, int nt, const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse) {
@@ -126,56 +185,52 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(SeqDesc sd, int nt, const b
         float m = -1e30f, l = 0.f;
         const long klim = (long)32 * qt + 31 + sd.diag;            // last key any query of this tile may see
         const int kt_end = klim >= (long)sd.L - 1 ? nt : (int)(klim / 32) + 1;
-        for (int j = 0; j < kt_end; ++j) {
-            const char* ktile = kt + j * TILE_B;
-            const char* vtile = vt + j * TILE_B;
-            f32x16 s;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(ktile, l31, ks, hi), qf[ks], s, 0, 0, 0);
-            const bool need_mask = (32 * j + 31 >= sd.L) || ((long)32 * j + 31 > (long)32 * qt + sd.diag);
-            float mx = -1e30f;
-            float p[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = s[r] * sc;
-                if (need_mask) {
-                    const int key = 32 * j + crow32(r, hi);
-                    if (key >= sd.L || (long)key > (long)q + sd.diag) v = -1e30f;
-                }
-                p[r] = v; mx = fmaxf(mx, v);
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float mn = fmaxf(m, mx);
-            const float alpha = exp2f(m - mn);
-            float ps = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { const float e = (p[r] <= -1e29f) ? 0.f : exp2f(p[r] - mn); p[r] = e; ps += e; }
-            l = l * alpha + ps;
-            m = mn;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
-            const bf16x8 pb0 = pack8(p), pb1 = pack8(p + 8);
-            o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(vtile, 0, 0, lane), pb0, o0, 0, 0, 0);
-            o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(vtile, 1, 0, lane), pb1, o0, 0, 0, 0);
-            o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(vtile, 0, 1, lane), pb0, o1, 0, 0, 0);
-            o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(vtile, 1, 1, lane), pb1, o1, 0, 0, 0);
-        }
-        l += __shfl_xor(l, 32, 64);
-        if (q < sd.L) {
-            const float inv = 1.0f / l;
-            const long row = base + (long)q * sd.pos_stride;
-            bf16_t* orow = out + row * sd.D + w.head * ATT_HD;
-            // O^T C layout: register r of lane (q, hi) holds d = 32*dt + 8*(r>>2) + 4*hi + (r&3): 4 consecutive d per group
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                st4(orow + 8 * gq + 4 * hi, make_float4(o0[4 * gq] * inv, o0[4 * gq + 1] * inv, o0[4 * gq + 2] * inv, o0[4 * gq + 3] * inv));
-                st4(orow + 32 + 8 * gq + 4 * hi, make_float4(o1[4 * gq] * inv, o1[4 * gq + 1] * inv, o1[4 * gq + 2] * inv, o1[4 * gq + 3] * inv));
-            }
-            if (lse && hi == 0) lse[row * sd.heads + w.head] = (m + log2f(l)) * 0.6931471805599453f;   // natural-log LSE of the scaled scores
-        }
+        for (int j = 0; j < kt_end; ++j) fwd_tile(sd, kt + j * TILE_B, vt + j * TILE_B, qf, j, qt, q, l31, hi, lane, m, l, o0, o1);
+        fwd_store(sd, base, w.head, q, hi, m, l, o0, o1, out, lse);
     }
+}
+
+// Streaming variant for workgroup-shared sequences of ANY length: a workgroup owns 4 query tiles (one per wave) of one
+// (item, head) and walks the keys in chunks of 4 tiles (wave w loads K/V tile 4c+w of chunk c), 32 KiB of LDS -> 4
+// workgroups per CU.  K/V are re-read from L2 by the ceil(nt/4) workgroups of a sequence.
+__global__ __launch_bounds__(256) void attn_fwd_stream(SeqDesc sd, int nt, const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse) {
+    __shared__ __attribute__((aligned(16))) char smem[8 * TILE_B];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int item = blockIdx.x / sd.heads, head = blockIdx.x - item * sd.heads;
+    const long base = seq_base(sd, item);
+    const long ld3 = 3L * sd.D, pse = sd.pos_stride * ld3;
+    const bf16_t* qh = qkv + base * ld3 + head * ATT_HD;
+    char* kt = smem;
+    char* vt = smem + 4 * TILE_B;
+    const int qt = blockIdx.y * 4 + wave;
+    const bool active = qt < nt;
+    const int q = 32 * qt + l31;
+    const int qc = q < sd.L ? q : sd.L - 1;
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = frag_row_global(qh, pse, qc, ks, hi);
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    float m = -1e30f, l = 0.f;
+    const long klim = (long)32 * qt + 31 + sd.diag;
+    const int kt_end = (!active) ? 0 : (klim >= (long)sd.L - 1 ? nt : (int)(klim / 32) + 1);
+    const long klim_wg = (long)32 * (blockIdx.y * 4 + 3) + 31 + sd.diag;          // last key tile any wave of this workgroup needs
+    const int kt_end_wg = klim_wg >= (long)sd.L - 1 ? nt : (int)(klim_wg / 32) + 1;
+    for (int c0 = 0; c0 < kt_end_wg; c0 += 4) {
+        __syncthreads();                                   // previous chunk fully consumed
+        if (c0 + wave < nt) {
+            load_tile(qh + sd.D, pse, 32 * (c0 + wave), sd.L, kt + wave * TILE_B, lane);
+            load_tile(qh + 2 * sd.D, pse, 32 * (c0 + wave), sd.L, vt + wave * TILE_B, lane);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int jend = (c0 + 4 < kt_end) ? c0 + 4 : kt_end;
+        for (int j = c0; j < jend; ++j) fwd_tile(sd, kt + (j - c0) * TILE_B, vt + (j - c0) * TILE_B, qf, j, qt, q, l31, hi, lane, m, l, o0, o1);
+    }
+    if (active) fwd_store(sd, base, head, q, hi, m, l, o0, o1, out, lse);
 }
 
 // ------------------------------------------------------------------------------------------------ backward prep
@@ -196,6 +251,97 @@ __global__ void attn_bwd_prep_kernel(SeqDesc sd, int Lp, const bf16_t* __restric
             v = make_float2(lse[row * sd.heads + h], s);
         }
         ld[i] = v;
+    }
+}
+
+// One 32-query tile against the wave's 32-key tile (backward, dK / dV side).
+__device__ __forceinline__ void dkv_tile(const SeqDesc& sd, const char* qtile, const char* dotile, const float2* __restrict__ ldh, int i, int key,
+                                         const bf16x8 (&kf)[4], const bf16x8 (&vf)[4], int l31, int hi, int lane, f32x16& dk0, f32x16& dk1, f32x16& dv0, f32x16& dv1) {
+    f32x16 s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(qtile, l31, ks, hi), kf[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(dotile, l31, ks, hi), vf[ks], dp, 0, 0, 0);
+    }
+    // rows of the accumulators are queries q = 32*i + 8*(r>>2) + 4*hi + (r&3); lse/delta for 4 consecutive q per group
+    float pv[16], dsv[16];
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+        const float4* p4 = reinterpret_cast<const float4*>(ldh + 32 * i + 8 * gq + 4 * hi);
+        const float4 a = p4[0], b = p4[1];   // (lse0, d0, lse1, d1), (lse2, d2, lse3, d3)
+        const float ls[4] = {a.x, a.z, b.x, b.z}, dl[4] = {a.y, a.w, b.y, b.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int r = 4 * gq + e;
+            const int q = 32 * i + 8 * gq + 4 * hi + e;
+            const bool ok = q < sd.L && key < sd.L && (long)key <= (long)q + sd.diag;
+            const float p = ok ? exp2f(s[r] * (kScale * kLog2e) - ls[e] * kLog2e) : 0.f;
+            pv[r] = p;
+            dsv[r] = p * (dp[r] - dl[e]) * kScale;
+        }
+    }
+    const bf16x8 pa0 = pack8(pv), pa1 = pack8(pv + 8), da0 = pack8(dsv), da1 = pack8(dsv + 8);
+    dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa0, frag_tr(dotile, 0, 0, lane), dv0, 0, 0, 0);
+    dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa1, frag_tr(dotile, 1, 0, lane), dv0, 0, 0, 0);
+    dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa0, frag_tr(dotile, 0, 1, lane), dv1, 0, 0, 0);
+    dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa1, frag_tr(dotile, 1, 1, lane), dv1, 0, 0, 0);
+    dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da0, frag_tr(qtile, 0, 0, lane), dk0, 0, 0, 0);
+    dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da1, frag_tr(qtile, 1, 0, lane), dk0, 0, 0, 0);
+    dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da0, frag_tr(qtile, 0, 1, lane), dk1, 0, 0, 0);
+    dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da1, frag_tr(qtile, 1, 1, lane), dk1, 0, 0, 0);
+}
+
+// C layout: lane (col = d = l31 (+32), hi), register r -> key row 32*j + crow32(r, hi)
+__device__ __forceinline__ void dkv_store(const SeqDesc& sd, long base, long ld3, int head, int j, int l31, int hi, const f32x16& dk0, const f32x16& dk1,
+                                          const f32x16& dv0, const f32x16& dv1, bf16_t* __restrict__ dqkv) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int kr = 32 * j + crow32(r, hi);
+        if (kr < sd.L) {
+            bf16_t* drow = dqkv + (base + (long)kr * sd.pos_stride) * ld3 + head * ATT_HD;
+            drow[sd.D + l31] = f2bf(dk0[r]); drow[sd.D + 32 + l31] = f2bf(dk1[r]);
+            drow[2 * sd.D + l31] = f2bf(dv0[r]); drow[2 * sd.D + 32 + l31] = f2bf(dv1[r]);
+        }
+    }
+}
+
+// One 32-key tile against the wave's 32-query tile (backward, dQ side).
+__device__ __forceinline__ void dq_tile(const SeqDesc& sd, const char* ktile, const char* vtile, int j, int q, const bf16x8 (&qf)[4], const bf16x8 (&dof)[4],
+                                        float ls, float dl, int l31, int hi, int lane, f32x16& dq0, f32x16& dq1) {
+    f32x16 s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(ktile, l31, ks, hi), qf[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(vtile, l31, ks, hi), dof[ks], dp, 0, 0, 0);
+    }
+    float dsv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int key = 32 * j + crow32(r, hi);
+        const bool ok = q < sd.L && key < sd.L && (long)key <= (long)q + sd.diag;
+        const float p = ok ? exp2f(s[r] * (kScale * kLog2e) - ls) : 0.f;
+        dsv[r] = p * (dp[r] - dl) * kScale;
+    }
+    const bf16x8 da0 = pack8(dsv), da1 = pack8(dsv + 8);
+    dq0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da0, frag_tr(ktile, 0, 0, lane), dq0, 0, 0, 0);
+    dq0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da1, frag_tr(ktile, 1, 0, lane), dq0, 0, 0, 0);
+    dq1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da0, frag_tr(ktile, 0, 1, lane), dq1, 0, 0, 0);
+    dq1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da1, frag_tr(ktile, 1, 1, lane), dq1, 0, 0, 0);
+}
+
+__device__ __forceinline__ void dq_store(const SeqDesc& sd, long base, long ld3, int head, int qt, int l31, int hi, const f32x16& dq0, const f32x16& dq1,
+                                         bf16_t* __restrict__ dqkv) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int qr = 32 * qt + crow32(r, hi);
+        if (qr < sd.L) {
+            bf16_t* drow = dqkv + (base + (long)qr * sd.pos_stride) * ld3 + head * ATT_HD;
+            drow[l31] = f2bf(dq0[r]); drow[32 + l31] = f2bf(dq1[r]);
+        }
     }
 }
 
@@ -242,54 +388,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma(SeqDesc sd, int nt, con
         // first query tile that can see any key of this tile: q >= 32*j - diag
         const long qlo = (long)32 * j - sd.diag;
         const int i0 = qlo > 0 ? (int)(qlo / 32) : 0;
-        for (int i = i0; i < nt; ++i) {
-            const char* qtile = qt_ + i * TILE_B;
-            const char* dotile = dot_ + i * TILE_B;
-            f32x16 s, dp;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(qtile, l31, ks, hi), kf[ks], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(dotile, l31, ks, hi), vf[ks], dp, 0, 0, 0);
-            }
-            // rows of the accumulators are queries q = 32*i + 8*(r>>2) + 4*hi + (r&3); lse/delta for 4 consecutive q per group
-            float pv[16], dsv[16];
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                const float4* p4 = reinterpret_cast<const float4*>(ldh + 32 * i + 8 * gq + 4 * hi);
-                const float4 a = p4[0], b = p4[1];   // (lse0, d0, lse1, d1), (lse2, d2, lse3, d3)
-                const float ls[4] = {a.x, a.z, b.x, b.z}, dl[4] = {a.y, a.w, b.y, b.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int r = 4 * gq + e;
-                    const int q = 32 * i + 8 * gq + 4 * hi + e;
-                    const bool ok = q < sd.L && key < sd.L && (long)key <= (long)q + sd.diag;
-                    const float p = ok ? exp2f(s[r] * (kScale * kLog2e) - ls[e] * kLog2e) : 0.f;
-                    pv[r] = p;
-                    dsv[r] = p * (dp[r] - dl[e]) * kScale;
-                }
-            }
-            const bf16x8 pa0 = pack8(pv), pa1 = pack8(pv + 8), da0 = pack8(dsv), da1 = pack8(dsv + 8);
-            dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa0, frag_tr(dotile, 0, 0, lane), dv0, 0, 0, 0);
-            dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa1, frag_tr(dotile, 1, 0, lane), dv0, 0, 0, 0);
-            dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa0, frag_tr(dotile, 0, 1, lane), dv1, 0, 0, 0);
-            dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa1, frag_tr(dotile, 1, 1, lane), dv1, 0, 0, 0);
-            dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da0, frag_tr(qtile, 0, 0, lane), dk0, 0, 0, 0);
-            dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da1, frag_tr(qtile, 1, 0, lane), dk0, 0, 0, 0);
-            dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da0, frag_tr(qtile, 0, 1, lane), dk1, 0, 0, 0);
-            dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da1, frag_tr(qtile, 1, 1, lane), dk1, 0, 0, 0);
-        }
-        // C layout: lane (col = d = l31 (+32), hi), register r -> key row 32*j + crow32(r, hi)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int kr = 32 * j + crow32(r, hi);
-            if (kr < sd.L) {
-                bf16_t* drow = dqkv + (base + (long)kr * sd.pos_stride) * ld3 + w.head * ATT_HD;
-                drow[sd.D + l31] = f2bf(dk0[r]); drow[sd.D + 32 + l31] = f2bf(dk1[r]);
-                drow[2 * sd.D + l31] = f2bf(dv0[r]); drow[2 * sd.D + 32 + l31] = f2bf(dv1[r]);
-            }
-        }
+        for (int i = i0; i < nt; ++i) dkv_tile(sd, qt_ + i * TILE_B, dot_ + i * TILE_B, ldh, i, key, kf, vf, l31, hi, lane, dk0, dk1, dv0, dv1);
+        dkv_store(sd, base, ld3, w.head, j, l31, hi, dk0, dk1, dv0, dv1, dqkv);
     }
 }
 
@@ -337,40 +437,99 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma(SeqDesc sd, int nt, cons
         for (int r = 0; r < 16; ++r) { dq0[r] = 0.f; dq1[r] = 0.f; }
         const long klim = (long)32 * qt + 31 + sd.diag;
         const int kt_end = klim >= (long)sd.L - 1 ? nt : (int)(klim / 32) + 1;
-        for (int j = 0; j < kt_end; ++j) {
-            const char* ktile = kt + j * TILE_B;
-            const char* vtile = vt + j * TILE_B;
-            f32x16 s, dp;
+        for (int j = 0; j < kt_end; ++j) dq_tile(sd, kt + j * TILE_B, vt + j * TILE_B, j, q, qf, dof, ls, dl, l31, hi, lane, dq0, dq1);
+        dq_store(sd, base, ld3, w.head, qt, l31, hi, dq0, dq1, dqkv);
+    }
+}
+
+// ---- streaming backward kernels (any sequence length): a workgroup owns 4 key tiles (dK/dV) or 4 query tiles (dQ), one per
+// wave, and walks the other side in chunks of 4 tiles staged in 32 KiB of LDS (wave w loads tile 4c+w of the chunk).
+__global__ __launch_bounds__(256) void attn_bwd_dkv_stream(SeqDesc sd, int nt, const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                           const float2* __restrict__ ld, bf16_t* __restrict__ dqkv) {
+    __shared__ __attribute__((aligned(16))) char smem[8 * TILE_B];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int item = blockIdx.x / sd.heads, head = blockIdx.x - item * sd.heads;
+    const long base = seq_base(sd, item);
+    const long ld3 = 3L * sd.D, pse = sd.pos_stride * ld3, pso = sd.pos_stride * sd.D;
+    const bf16_t* qh = qkv + base * ld3 + head * ATT_HD;
+    const bf16_t* doh = dout + base * sd.D + head * ATT_HD;
+    const float2* ldh = ld + ((size_t)item * sd.heads + head) * (nt * 32);
+    char* qt_ = smem;
+    char* dot_ = smem + 4 * TILE_B;
+    const int j = blockIdx.y * 4 + wave;
+    const bool active = j < nt;
+    const int key = 32 * j + l31;
+    const int kc = key < sd.L ? key : sd.L - 1;
+    bf16x8 kf[4], vf[4];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+    for (int ks = 0; ks < 4; ++ks) { kf[ks] = frag_row_global(qh + sd.D, pse, kc, ks, hi); vf[ks] = frag_row_global(qh + 2 * sd.D, pse, kc, ks, hi); }
+    f32x16 dk0, dk1, dv0, dv1;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(ktile, l31, ks, hi), qf[ks], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(vtile, l31, ks, hi), dof[ks], dp, 0, 0, 0);
-            }
-            float dsv[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = 32 * j + crow32(r, hi);
-                const bool ok = q < sd.L && key < sd.L && (long)key <= (long)q + sd.diag;
-                const float p = ok ? exp2f(s[r] * (kScale * kLog2e) - ls) : 0.f;
-                dsv[r] = p * (dp[r] - dl) * kScale;
-            }
-            const bf16x8 da0 = pack8(dsv), da1 = pack8(dsv + 8);
-            dq0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da0, frag_tr(ktile, 0, 0, lane), dq0, 0, 0, 0);
-            dq0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da1, frag_tr(ktile, 1, 0, lane), dq0, 0, 0, 0);
-            dq1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da0, frag_tr(ktile, 0, 1, lane), dq1, 0, 0, 0);
-            dq1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da1, frag_tr(ktile, 1, 1, lane), dq1, 0, 0, 0);
+    for (int r = 0; r < 16; ++r) { dk0[r] = 0.f; dk1[r] = 0.f; dv0[r] = 0.f; dv1[r] = 0.f; }
+    const long qlo = (long)32 * j - sd.diag;                       // first query tile that can see this wave's keys
+    const int i0 = qlo > 0 ? (int)(qlo / 32) : 0;
+    const long qlo_wg = (long)32 * (blockIdx.y * 4) - sd.diag;     // ... and any key of this workgroup
+    const int c_start = qlo_wg > 0 ? (int)(qlo_wg / 32) & ~3 : 0;
+    for (int c0 = c_start; c0 < nt; c0 += 4) {
+        __syncthreads();
+        if (c0 + wave < nt) {
+            load_tile(qh, pse, 32 * (c0 + wave), sd.L, qt_ + wave * TILE_B, lane);
+            load_tile(doh, pso, 32 * (c0 + wave), sd.L, dot_ + wave * TILE_B, lane);
         }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int qr = 32 * qt + crow32(r, hi);
-            if (qr < sd.L) {
-                bf16_t* drow = dqkv + (base + (long)qr * sd.pos_stride) * ld3 + w.head * ATT_HD;
-                drow[l31] = f2bf(dq0[r]); drow[32 + l31] = f2bf(dq1[r]);
-            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (active) {
+            const int ib = c0 > i0 ? c0 : i0, ie = c0 + 4 < nt ? c0 + 4 : nt;
+            for (int i = ib; i < ie; ++i) dkv_tile(sd, qt_ + (i - c0) * TILE_B, dot_ + (i - c0) * TILE_B, ldh, i, key, kf, vf, l31, hi, lane, dk0, dk1, dv0, dv1);
         }
     }
+    if (active) dkv_store(sd, base, ld3, head, j, l31, hi, dk0, dk1, dv0, dv1, dqkv);
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_dq_stream(SeqDesc sd, int nt, const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                          const float2* __restrict__ ld, bf16_t* __restrict__ dqkv) {
+    __shared__ __attribute__((aligned(16))) char smem[8 * TILE_B];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int item = blockIdx.x / sd.heads, head = blockIdx.x - item * sd.heads;
+    const long base = seq_base(sd, item);
+    const long ld3 = 3L * sd.D, pse = sd.pos_stride * ld3, pso = sd.pos_stride * sd.D;
+    const bf16_t* qh = qkv + base * ld3 + head * ATT_HD;
+    const bf16_t* doh = dout + base * sd.D + head * ATT_HD;
+    const float2* ldh = ld + ((size_t)item * sd.heads + head) * (nt * 32);
+    char* kt = smem;
+    char* vt = smem + 4 * TILE_B;
+    const int qt = blockIdx.y * 4 + wave;
+    const bool active = qt < nt;
+    const int q = 32 * qt + l31;
+    const int qc = q < sd.L ? q : sd.L - 1;
+    bf16x8 qf[4], dof[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) { qf[ks] = frag_row_global(qh, pse, qc, ks, hi); dof[ks] = frag_row_global(doh, pso, qc, ks, hi); }
+    const float2 lq = active ? ldh[32 * qt + l31] : make_float2(0.f, 0.f);
+    const float ls = lq.x * kLog2e, dl = lq.y;
+    f32x16 dq0, dq1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dq0[r] = 0.f; dq1[r] = 0.f; }
+    const long klim = (long)32 * qt + 31 + sd.diag;
+    const int kt_end = (!active) ? 0 : (klim >= (long)sd.L - 1 ? nt : (int)(klim / 32) + 1);
+    const long klim_wg = (long)32 * (blockIdx.y * 4 + 3) + 31 + sd.diag;
+    const int kt_end_wg = klim_wg >= (long)sd.L - 1 ? nt : (int)(klim_wg / 32) + 1;
+    for (int c0 = 0; c0 < kt_end_wg; c0 += 4) {
+        __syncthreads();
+        if (c0 + wave < nt) {
+            load_tile(qh + sd.D, pse, 32 * (c0 + wave), sd.L, kt + wave * TILE_B, lane);
+            load_tile(qh + 2 * sd.D, pse, 32 * (c0 + wave), sd.L, vt + wave * TILE_B, lane);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int jend = (c0 + 4 < kt_end) ? c0 + 4 : kt_end;
+        for (int j = c0; j < jend; ++j) dq_tile(sd, kt + (j - c0) * TILE_B, vt + (j - c0) * TILE_B, j, q, qf, dof, ls, dl, l31, hi, lane, dq0, dq1);
+    }
+    if (active) dq_store(sd, base, ld3, head, qt, l31, hi, dq0, dq1, dqkv);
 }
 
 template <typename K>
@@ -381,15 +540,21 @@ static void set_lds_attr(K kernel, int bytes) {
 }  // namespace
 
 // nt = number of 32-position tiles; returns false when the MFMA kernels do not cover this shape
+// shared sequences: 1 = resident K/V (S <= 320), 2 = streaming (any length, default)
+static int shared_variant() { static const int v = [] { const char* e = getenv("TCOW_ATTN_SHARED"); return e ? atoi(e) : 2; }(); return v; }
+
 bool tcow_attn_mfma_supported(const SeqDesc& d, bool shared) {
     const int nt = (d.L + 31) / 32;
-    return shared ? nt <= 10 : nt <= 2;
+    if (shared) return shared_variant() == 2 ? true : nt <= 10;
+    return true;      // temporal: wave-private tiles up to T = 64, the streaming kernels beyond
 }
 
 int tcow_attn_mfma_fwd(hipStream_t st, const SeqDesc& d, bool shared, const void* qkv, void* out, float* lse) {
     const int nt = (d.L + 31) / 32;
     const int pairs = d.n_outer * d.n_inner * d.heads;
-    if (shared) {
+    if ((shared && shared_variant() == 2) || (!shared && nt > 2)) {
+        hipLaunchKernelGGL(attn_fwd_stream, dim3(pairs, cdiv(nt, 4)), dim3(256), 0, st, d, nt, (const bf16_t*)qkv, (bf16_t*)out, lse);
+    } else if (shared) {
         const int lds = 2 * nt * TILE_B;
         set_lds_attr(attn_fwd_mfma<true>, lds);
         hipLaunchKernelGGL(attn_fwd_mfma<true>, dim3(pairs), dim3(256), lds, st, d, nt, (const bf16_t*)qkv, (bf16_t*)out, lse);
@@ -416,7 +581,11 @@ int tcow_attn_mfma_bwd(hipStream_t st, const SeqDesc& d, bool shared, const void
     int blocks = cdiv(total, 256); if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3(blocks), dim3(256), 0, st, d, nt * 32, (const bf16_t*)out, (const bf16_t*)dout, lse, ld);
     TCOW_CHECK_LAUNCH();
-    if (shared) {
+    if ((shared && shared_variant() == 2) || (!shared && nt > 2)) {
+        hipLaunchKernelGGL(attn_bwd_dkv_stream, dim3(pairs, cdiv(nt, 4)), dim3(256), 0, st, d, nt, (const bf16_t*)qkv, (const bf16_t*)dout, ld, (bf16_t*)dqkv);
+        TCOW_CHECK_LAUNCH();
+        hipLaunchKernelGGL(attn_bwd_dq_stream, dim3(pairs, cdiv(nt, 4)), dim3(256), 0, st, d, nt, (const bf16_t*)qkv, (const bf16_t*)dout, ld, (bf16_t*)dqkv);
+    } else if (shared) {
         const int lds = 2 * nt * TILE_B;
         set_lds_attr(attn_bwd_dkv_mfma<true>, lds); set_lds_attr(attn_bwd_dq_mfma<true>, lds);
         hipLaunchKernelGGL(attn_bwd_dkv_mfma<true>, dim3(pairs), dim3(256), lds, st, d, nt, (const bf16_t*)qkv, (const bf16_t*)dout, ld, (bf16_t*)dqkv);

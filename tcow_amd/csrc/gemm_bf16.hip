@@ -36,7 +36,6 @@ struct NtParams {
     int act;
     bf16_t* aux; long ldaux;
     int tiles_m, tiles_n;
-    int dbg;   // profiling aid: 1 = skip epilogue, 2 = skip MFMAs, 3 = skip loads
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
@@ -48,6 +47,172 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 
 __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((GLB_PTR(const uint32_t))gsrc, (LDS_PTR(uint32_t))lds_wave_base, 16, 0, 0);
+}
+
+// Epilogue: accumulators -> LDS (f32 [128][128]) -> coalesced row-wise stores.  Column-dependent operands (bias) are the
+// same for all 16 row passes of a thread; row-dependent ones (row scale, residual, GELU' input) are fetched for 8 passes at
+// a time and ISSUED EARLY (first half before the LDS staging + barrier, second half before the first half is consumed) so
+// that their L2/HBM latency overlaps the staging instead of serialising behind it once per tile.
+struct EpiOperands { float4 res[8]; float4 ax[8]; float rs[8]; };
+
+__device__ __forceinline__ void epi_fetch(const NtParams& p, EpiOperands& o, int half, int tid, int m0, int gn, bool col_ok) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int gm = m0 + (half * 8 + u) * 8 + (tid >> 5);
+        o.res[u] = make_float4(0.f, 0.f, 0.f, 0.f); o.ax[u] = o.res[u]; o.rs[u] = 1.0f;
+        if (col_ok && gm < p.M) {
+            if (p.row_scale) o.rs[u] = p.row_scale[gm];
+            if (p.resid) o.res[u] = ld4(p.resid + (size_t)gm * p.ldr + gn);
+            if (p.act == TCOW_ACT_DGELU) o.ax[u] = ld4(p.aux + (size_t)gm * p.ldaux + gn);
+        }
+    }
+}
+
+__device__ __forceinline__ void epi_apply(const NtParams& p, const EpiOperands& o, const float* ct, float4 b4, int half, int tid, int m0, int gn, int c4) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int row = (half * 8 + u) * 8 + (tid >> 5);
+        const int gm = m0 + row;
+        if (gm >= p.M) continue;
+        float4 v = *reinterpret_cast<const float4*>(ct + row * BN + c4);
+        v.x = (v.x + b4.x) * o.rs[u]; v.y = (v.y + b4.y) * o.rs[u]; v.z = (v.z + b4.z) * o.rs[u]; v.w = (v.w + b4.w) * o.rs[u];
+        if (p.act == TCOW_ACT_GELU) {
+            if (p.aux) st4(p.aux + (size_t)gm * p.ldaux + gn, v);
+            v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
+        } else if (p.act == TCOW_ACT_DGELU) {
+            v.x *= gelu_erf_grad(o.ax[u].x); v.y *= gelu_erf_grad(o.ax[u].y); v.z *= gelu_erf_grad(o.ax[u].z); v.w *= gelu_erf_grad(o.ax[u].w);
+        }
+        v.x += o.res[u].x; v.y += o.res[u].y; v.z += o.res[u].z; v.w += o.res[u].w;
+        if (p.out_f32) st4(reinterpret_cast<float*>(p.C) + (size_t)gm * p.ldc + gn, v);
+        else st4(reinterpret_cast<bf16_t*>(p.C) + (size_t)gm * p.ldc + gn, v);
+    }
+}
+
+__device__ __forceinline__ void nt_epilogue(const NtParams& p, char* smem, f32x16 (&acc)[2][2], float4 b4, int tid, int wm, int wn, int l31, int hi, int m0, int n0) {
+    const int c4 = (tid & 31) * 4, gn = n0 + c4;
+    const bool col_ok = gn < p.N;                 // N % 4 == 0: a thread's 4 columns are all in or all out
+    EpiOperands o0, o1;
+    epi_fetch(p, o0, 0, tid, m0, gn, col_ok);
+    float* ct = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * 64 + i * 32 + crow32(r, hi);
+                const int col = wn * 64 + j * 32 + l31;
+                ct[row * BN + col] = acc[i][j][r];
+            }
+    __syncthreads();
+    epi_fetch(p, o1, 1, tid, m0, gn, col_ok);
+    if (!col_ok) return;
+    epi_apply(p, o0, ct, b4, 0, tid, m0, gn, c4);
+    epi_apply(p, o1, ct, b4, 1, tid, m0, gn, c4);
+}
+
+// bias for this thread's 4 epilogue columns, fetched at kernel start (its latency hides behind the whole main loop)
+__device__ __forceinline__ float4 epi_bias(const NtParams& p, int tid, int n0) {
+    const int gn = n0 + (tid & 31) * 4;
+    return (p.bias && gn < p.N) ? ld4(p.bias + gn) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// ---- v2: same 128x128 tile, but K walked 32 at a time through a 4-deep LDS ring with COUNTED waits:
+// the loads of slice kt+3 are issued in iteration kt and only slice kt+1 is waited for (s_waitcnt vmcnt(8) leaves
+// two slices = 8 wave-loads in flight across the raw s_barrier), so L2/HBM latency spans three compute phases
+// instead of one.  LDS rows are 64 B (4 chunks); chunk c of row r sits at c ^ ((r>>2)&3): conflict-free b128 reads.
+constexpr int R_BK = 32;
+constexpr int R_TILE = 128 * 64;            // 8 KiB per operand per slice
+constexpr int R_STAGE = 2 * R_TILE;
+constexpr int R_NS = 4;
+
+__global__ __launch_bounds__(256, 2) void gemm_nt_bf16_ring_kernel(NtParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int nblk = p.tiles_m * p.tiles_n;
+    const int pid = xcd_remap(blockIdx.x, nblk);
+    const int pm = pid / p.tiles_n, pn = pid - pm * p.tiles_n;
+    const int m0 = pm * BM, n0 = pn * BN;
+    const float4 b4 = epi_bias(p, tid, n0);
+
+    // wave w issues wave-loads 2w, 2w+1 of each operand per slice; a wave-load covers 16 tile rows x 64 B
+    const bf16_t* a_src[2];
+    const bf16_t* w_src[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = (wave * 2 + j) * 16 + (lane >> 2);
+        const int c = (lane & 3) ^ ((r >> 2) & 3);
+        int gm = m0 + r; gm = gm < p.M ? gm : p.M - 1;
+        int gn = n0 + r; gn = gn < p.N ? gn : p.N - 1;
+        a_src[j] = p.A + (size_t)gm * p.lda + c * 8;
+        w_src[j] = p.W + (size_t)gn * p.ldw + c * 8;
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = p.K / R_BK;
+    auto issue = [&](int kt) {
+        char* sa = smem + (kt & (R_NS - 1)) * R_STAGE;
+        char* sw = sa + R_TILE;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            glds16(a_src[j] + (size_t)kt * R_BK, sa + (wave * 2 + j) * 1024);
+            glds16(w_src[j] + (size_t)kt * R_BK, sw + (wave * 2 + j) * 1024);
+        }
+    };
+    auto wait_slices_in_flight = [&](int n) {   // wait until at most n slices (4 wave-loads each) are still outstanding
+        if (n >= 2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        else if (n == 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    };
+    int a_off[2], w_off[2], a_sw[2], w_sw[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int ra = wm * 64 + i * 32 + l31, rw = wn * 64 + i * 32 + l31;
+        a_off[i] = ra * 64; a_sw[i] = (ra >> 2) & 3;
+        w_off[i] = rw * 64; w_sw[i] = (rw >> 2) & 3;
+    }
+
+    const int pre = nk < 3 ? nk : 3;
+    for (int s = 0; s < pre; ++s) issue(s);
+    wait_slices_in_flight(pre - 1);
+    __builtin_amdgcn_s_barrier();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 3 < nk) issue(kt + 3);
+        const char* sa = smem + (kt & (R_NS - 1)) * R_STAGE;
+        const char* sw = sa + R_TILE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int c = 2 * ks + hi;
+            bf16x8 fa[2], fw[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                fa[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sa + a_off[i] + ((c ^ a_sw[i]) << 4)));
+                fw[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sw + w_off[i] + ((c ^ w_sw[i]) << 4)));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fw[j], acc[i][j], 0, 0, 0);
+        }
+        // slice kt+1 must have landed; slices kt+2, kt+3 (if issued) may stay in flight across the barrier
+        int ahead = nk - 2 - kt; ahead = ahead > 2 ? 2 : (ahead < 0 ? 0 : ahead);
+        wait_slices_in_flight(ahead);
+        __builtin_amdgcn_s_barrier();
+    }
+    asm volatile("" ::: "memory");
+    nt_epilogue(p, smem, acc, b4, tid, wm, wn, l31, hi, m0, n0);
 }
 
 __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(NtParams p) {
@@ -62,6 +227,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(NtParams p) {
     const int pid = xcd_remap(blockIdx.x, nblk);
     const int pm = pid / p.tiles_n, pn = pid - pm * p.tiles_n;
     const int m0 = pm * BM, n0 = pn * BN;
+    const float4 b4 = epi_bias(p, tid, n0);
 
     // ---- per-lane source pointers for the direct-to-LDS loads: wave w issues wave-loads 4w..4w+3 per operand,
     // each covering 8 tile rows x 128 B; lane -> (row r = 8*q + (lane>>3), LDS chunk position lane&7).
@@ -111,7 +277,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(NtParams p) {
 
     for (int kt = 0; kt < nk; ++kt) {
         const int stage = kt & 1;
-        if (kt + 1 < nk && p.dbg != 3) issue(kt + 1, stage ^ 1);
+        if (kt + 1 < nk) issue(kt + 1, stage ^ 1);
         const char* sa = smem + stage * STAGE_BYTES;
         const char* sw = sa + TILE_BYTES;
 #pragma unroll
@@ -127,71 +293,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(NtParams p) {
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    if (p.dbg != 2) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fw[j], acc[i][j], 0, 0, 0);
-                    else acc[i][j][0] += __builtin_bit_cast(float, (uint32_t)(fa[i][0] != fw[j][0]));
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fw[j], acc[i][j], 0, 0, 0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    if (p.dbg == 1) {
-        float t = 0.f;
-        for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) t += acc[i][j][r];
-        if (t == 123.456f) reinterpret_cast<float*>(p.C)[0] = t;
-        return;
-    }
-
-    // ---- epilogue: accumulators -> LDS (f32 [128][128]) -> coalesced row-wise stores
-    float* ct = reinterpret_cast<float*>(smem);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * 64 + i * 32 + crow32(r, hi);
-                const int col = wn * 64 + j * 32 + l31;
-                ct[row * BN + col] = acc[i][j][r];
-            }
-    __syncthreads();
-
-    // Column-dependent operands are the same for all 16 row passes of a thread; row-dependent ones (row scale,
-    // residual, GELU' input) are fetched 8 passes at a time BEFORE the arithmetic so that their latencies overlap.
-    const int c4 = (tid & 31) * 4, gn = n0 + c4;
-    if (gn >= p.N) return;                       // N % 4 == 0: a thread's 4 columns are all in or all out
-    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.bias) b4 = ld4(p.bias + gn);
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        float4 res[8]; float rs[8]; float4 ax[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int row = (half * 8 + u) * 8 + (tid >> 5);
-            const int gm = m0 + row;
-            res[u] = make_float4(0.f, 0.f, 0.f, 0.f); ax[u] = res[u]; rs[u] = 1.0f;
-            if (gm < p.M) {
-                if (p.row_scale) rs[u] = p.row_scale[gm];
-                if (p.resid) res[u] = ld4(p.resid + (size_t)gm * p.ldr + gn);
-                if (p.act == TCOW_ACT_DGELU) ax[u] = ld4(p.aux + (size_t)gm * p.ldaux + gn);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int row = (half * 8 + u) * 8 + (tid >> 5);
-            const int gm = m0 + row;
-            if (gm >= p.M) continue;
-            float4 v = *reinterpret_cast<const float4*>(ct + row * BN + c4);
-            v.x = (v.x + b4.x) * rs[u]; v.y = (v.y + b4.y) * rs[u]; v.z = (v.z + b4.z) * rs[u]; v.w = (v.w + b4.w) * rs[u];
-            if (p.act == TCOW_ACT_GELU) {
-                if (p.aux) st4(p.aux + (size_t)gm * p.ldaux + gn, v);
-                v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
-            } else if (p.act == TCOW_ACT_DGELU) {
-                v.x *= gelu_erf_grad(ax[u].x); v.y *= gelu_erf_grad(ax[u].y); v.z *= gelu_erf_grad(ax[u].z); v.w *= gelu_erf_grad(ax[u].w);
-            }
-            v.x += res[u].x; v.y += res[u].y; v.z += res[u].z; v.w += res[u].w;
-            if (p.out_f32) st4(reinterpret_cast<float*>(p.C) + (size_t)gm * p.ldc + gn, v);
-            else st4(reinterpret_cast<bf16_t*>(p.C) + (size_t)gm * p.ldc + gn, v);
-        }
-    }
+    nt_epilogue(p, smem, acc, b4, tid, wm, wn, l31, hi, m0, n0);
 }
 
 }  // namespace
@@ -207,13 +314,19 @@ int tcow_gemm_nt_bf16(hipStream_t stream, const tcow_gemm_args* a) {
     p.C = a->C; p.ldc = a->ldc; p.out_f32 = a->out_f32; p.bias = a->bias; p.row_scale = a->row_scale;
     p.resid = a->resid; p.ldr = a->ldr; p.act = a->act; p.aux = (bf16_t*)a->aux; p.ldaux = a->ldaux;
     p.tiles_m = cdiv(a->M, BM); p.tiles_n = cdiv(a->N, BN);
-    { const char* e = getenv("TCOW_GEMM_DBG"); p.dbg = e ? atoi(e) : 0; }
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
         attr_set = true;
     }
-    hipLaunchKernelGGL(gemm_nt_bf16_kernel, dim3(p.tiles_m * p.tiles_n), dim3(256), NT_LDS_BYTES, stream, p);
+    static const int variant = [] { const char* e = getenv("TCOW_GEMM_NT"); return e ? atoi(e) : 1; }();   // 1 = two-stage BK=64 (default: faster on MI355X, profiles/r01_gemm_variants.txt), 2 = 4-deep BK=32 ring
+    if (variant == 2) {
+        static bool attr2 = false;
+        if (!attr2) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_ring_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES); attr2 = true; }
+        hipLaunchKernelGGL(gemm_nt_bf16_ring_kernel, dim3(p.tiles_m * p.tiles_n), dim3(256), NT_LDS_BYTES, stream, p);
+    } else {
+        hipLaunchKernelGGL(gemm_nt_bf16_kernel, dim3(p.tiles_m * p.tiles_n), dim3(256), NT_LDS_BYTES, stream, p);
+    }
     TCOW_CHECK_LAUNCH();
     return TCOW_OK;
 }

@@ -24,6 +24,8 @@ def default_args(**over):
 
 def bootstrap_warmup_loss(loss_pixels, topk_frac):                         # loss.py:13-17
     k = int(topk_frac * loss_pixels.numel())
+    if k == loss_pixels.numel():
+        return loss_pixels.mean()          # top-k of everything is everything (early training: topk_frac == 1)
     return torch.topk(loss_pixels.flatten(), k=k)[0].mean()
 
 
@@ -44,7 +46,9 @@ def hard_negative_band(target, H, W):
     if k % 2 == 0:
         k += 1
     shp = target.shape
-    d = F.max_pool2d(target.reshape(-1, 1, H, W), kernel_size=k, stride=1, padding=k // 2).reshape(shp) > 0.0
+    x = target.reshape(-1, 1, H, W)
+    x = F.max_pool2d(x, kernel_size=(k, 1), stride=1, padding=(k // 2, 0))        # box dilation is separable
+    d = F.max_pool2d(x, kernel_size=(1, k), stride=1, padding=(0, k // 2)).reshape(shp) > 0.0
     return d & ~(target >= 0.5)
 
 
@@ -81,8 +85,12 @@ class TcowLosses:
         while which.ndim > 3:
             which = which.any(dim=-1)
         which = which[..., None, None].expand_as(weights)
-        if bool(which.any()) and float(weights.mean()) >= 1e-4:
-            lo = logits[which]; tg = target[which]; fw = weights[which]
+        n_sel = int(which.sum())                                              # one host sync, like the reference's which_frames.any()
+        if n_sel > 0 and float(weights.mean()) >= 1e-4:
+            if n_sel == which.numel():     # every frame carries weight (the usual case): skip the boolean gather
+                lo = logits.reshape(-1); tg = target.reshape(-1); fw = weights.reshape(-1)
+            else:
+                lo = logits[which]; tg = target[which]; fw = weights[which]
             if self.args.focal_loss:
                 raise NotImplementedError('focal_loss needs torchvision.ops.sigmoid_focal_loss (loss.py:49-51); default is BCE')
             bce = F.binary_cross_entropy_with_logits(lo, tg, reduction='none')
@@ -95,7 +103,7 @@ class TcowLosses:
                 loss = (boot + jac) / 2.0 * self.args.aot_loss + custom * (1.0 - self.args.aot_loss)
             else:
                 loss = custom
-            loss = loss * torch.sqrt(which.float().mean())
+            loss = loss * math.sqrt(n_sel / which.numel())
         else:
             loss = torch.tensor(0.0, device=logits.device)
         return loss

@@ -71,3 +71,5 @@ run(1, 30, 301, 12, 1, False, True)
 run(1, 30, 301, 12, 1, True, True)
 run(3, 30, 301, 12, 1, False, True)
 run(3, 30, 301, 12, 1, True, True)
+run(1, 6, 1201, 12, 1, True, True)
+run(1, 2, 333, 2, 2, True)
