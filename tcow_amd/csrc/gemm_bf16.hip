@@ -111,6 +111,63 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, char* smem, f32x1
     epi_apply(p, o1, ct, b4, 1, tid, m0, gn, c4);
 }
 
+// ---- register-direct epilogue (A/B variant 1; measured 5-10 % SLOWER than the LDS-staged one: its 8-byte stores land 32 rows apart).  The main loop issues mfma(W fragment, A fragment), i.e. it accumulates C^T tiles:
+// lane (l&31, hi) then owns ONE output row m and, per 32-wide column tile, 16 columns n = 8*(r>>2) + 4*hi + (r&3) -- four
+// groups of 4 CONSECUTIVE columns.  Each group is one 8-byte (bf16) or 16-byte (f32) store, residual / GELU' operands are
+// matching vector loads, and no LDS round trip or workgroup barrier is needed: waves retire independently.
+struct DirectBias { float4 b[2][4]; };
+
+__device__ __forceinline__ DirectBias direct_bias(const NtParams& p, int wn, int hi, int n0) {
+    DirectBias d;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int gn = n0 + wn * 64 + j * 32 + 8 * g + 4 * hi;
+            d.b[j][g] = (p.bias && gn < p.N) ? ld4(p.bias + gn) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    return d;
+}
+
+__device__ __forceinline__ void nt_epilogue_direct(const NtParams& p, f32x16 (&acc)[2][2], const DirectBias& db, int wm, int wn, int l31, int hi, int m0, int n0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int gm = m0 + wm * 64 + i * 32 + l31;
+        if (gm >= p.M) continue;
+        const float rs = p.row_scale ? p.row_scale[gm] : 1.0f;
+        float4 res[2][4], ax[2][4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int gn = n0 + wn * 64 + j * 32 + 8 * g + 4 * hi;
+                res[j][g] = make_float4(0.f, 0.f, 0.f, 0.f); ax[j][g] = res[j][g];
+                if (gn < p.N) {
+                    if (p.resid) res[j][g] = ld4(p.resid + (size_t)gm * p.ldr + gn);
+                    if (p.act == TCOW_ACT_DGELU) ax[j][g] = ld4(p.aux + (size_t)gm * p.ldaux + gn);
+                }
+            }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int gn = n0 + wn * 64 + j * 32 + 8 * g + 4 * hi;
+                if (gn >= p.N) continue;
+                const float4 b = db.b[j][g];
+                float4 v = make_float4((acc[i][j][4 * g] + b.x) * rs, (acc[i][j][4 * g + 1] + b.y) * rs, (acc[i][j][4 * g + 2] + b.z) * rs, (acc[i][j][4 * g + 3] + b.w) * rs);
+                if (p.act == TCOW_ACT_GELU) {
+                    if (p.aux) st4(p.aux + (size_t)gm * p.ldaux + gn, v);
+                    v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
+                } else if (p.act == TCOW_ACT_DGELU) {
+                    v.x *= gelu_erf_grad(ax[j][g].x); v.y *= gelu_erf_grad(ax[j][g].y); v.z *= gelu_erf_grad(ax[j][g].z); v.w *= gelu_erf_grad(ax[j][g].w);
+                }
+                v.x += res[j][g].x; v.y += res[j][g].y; v.z += res[j][g].z; v.w += res[j][g].w;
+                if (p.out_f32) st4(reinterpret_cast<float*>(p.C) + (size_t)gm * p.ldc + gn, v);
+                else st4(reinterpret_cast<bf16_t*>(p.C) + (size_t)gm * p.ldc + gn, v);
+            }
+    }
+}
+
 // bias for this thread's 4 epilogue columns, fetched at kernel start (its latency hides behind the whole main loop)
 __device__ __forceinline__ float4 epi_bias(const NtParams& p, int tid, int n0) {
     const int gn = n0 + (tid & 31) * 4;
@@ -215,6 +272,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_ring_kernel(NtParams p) {
     nt_epilogue(p, smem, acc, b4, tid, wm, wn, l31, hi, m0, n0);
 }
 
+template <bool DIRECT>
 __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(NtParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -227,7 +285,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(NtParams p) {
     const int pid = xcd_remap(blockIdx.x, nblk);
     const int pm = pid / p.tiles_n, pn = pid - pm * p.tiles_n;
     const int m0 = pm * BM, n0 = pn * BN;
-    const float4 b4 = epi_bias(p, tid, n0);
+    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    DirectBias db;
+    if (DIRECT) db = direct_bias(p, wn, hi, n0); else b4 = epi_bias(p, tid, n0);
 
     // ---- per-lane source pointers for the direct-to-LDS loads: wave w issues wave-loads 4w..4w+3 per operand,
     // each covering 8 tile rows x 128 B; lane -> (row r = 8*q + (lane>>3), LDS chunk position lane&7).
@@ -293,12 +353,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(NtParams p) {
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fw[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = DIRECT ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0)
+                                       : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fw[j], acc[i][j], 0, 0, 0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    nt_epilogue(p, smem, acc, b4, tid, wm, wn, l31, hi, m0, n0);
+    if (DIRECT) nt_epilogue_direct(p, acc, db, wm, wn, l31, hi, m0, n0);
+    else nt_epilogue(p, smem, acc, b4, tid, wm, wn, l31, hi, m0, n0);
 }
 
 }  // namespace
@@ -316,16 +378,19 @@ int tcow_gemm_nt_bf16(hipStream_t stream, const tcow_gemm_args* a) {
     p.tiles_m = cdiv(a->M, BM); p.tiles_n = cdiv(a->N, BN);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
         attr_set = true;
     }
-    static const int variant = [] { const char* e = getenv("TCOW_GEMM_NT"); return e ? atoi(e) : 1; }();   // 1 = two-stage BK=64 (default: faster on MI355X, profiles/r01_gemm_variants.txt), 2 = 4-deep BK=32 ring
+    static const int variant = [] { const char* e = getenv("TCOW_GEMM_NT"); return e ? atoi(e) : 3; }();   // 3 = two-stage BK=64 + LDS-staged epilogue (default, fastest: profiles/r01_gemm_variants.txt), 1 = register-direct epilogue, 2 = 4-deep BK=32 ring
     if (variant == 2) {
         static bool attr2 = false;
         if (!attr2) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_ring_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES); attr2 = true; }
         hipLaunchKernelGGL(gemm_nt_bf16_ring_kernel, dim3(p.tiles_m * p.tiles_n), dim3(256), NT_LDS_BYTES, stream, p);
+    } else if (variant == 3) {       // LDS-staged epilogue (earlier default), kept for A/B
+        hipLaunchKernelGGL(gemm_nt_bf16_kernel<false>, dim3(p.tiles_m * p.tiles_n), dim3(256), NT_LDS_BYTES, stream, p);
     } else {
-        hipLaunchKernelGGL(gemm_nt_bf16_kernel, dim3(p.tiles_m * p.tiles_n), dim3(256), NT_LDS_BYTES, stream, p);
+        hipLaunchKernelGGL(gemm_nt_bf16_kernel<true>, dim3(p.tiles_m * p.tiles_n), dim3(256), NT_LDS_BYTES, stream, p);
     }
     TCOW_CHECK_LAUNCH();
     return TCOW_OK;
@@ -354,7 +419,7 @@ struct TnParams {
     const bf16_t* dY; long ldy;
     const bf16_t* X; long ldx;
     float* slab;
-    int tiles_n, tiles_k, mps;   // mps: token rows per slice (multiple of TN_MC)
+    int tiles_n, tiles_k, mps, nz;   // mps: token rows per slice (multiple of TN_MC); nz slices
 };
 
 __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int off0) {
@@ -370,9 +435,16 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(TnParams p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int pn = blockIdx.x / p.tiles_k, pk = blockIdx.x - pn * p.tiles_k;
+    // XCD-aware placement: blocks are dispatched round-robin over the 8 XCDs (private L2s).  All output tiles of one token
+    // slice z read the same dY / X rows, so slice z is pinned to XCD z % 8: its rows are fetched from HBM once per XCD-resident
+    // slice instead of once per XCD (measured: FETCH_SIZE 4-8x the algorithmic bytes with the naive order).
+    const int ntile = p.tiles_n * p.tiles_k;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int z = xcd + 8 * (idx / ntile), tile = idx % ntile;
+    if (z >= p.nz) return;
+    const int pn = tile / p.tiles_k, pk = tile - pn * p.tiles_k;
     const int n0 = pn * TN_T, k0 = pk * TN_T;
-    const int mbeg = blockIdx.y * p.mps;
+    const int mbeg = z * p.mps;
     const int mend = (mbeg + p.mps < p.M) ? mbeg + p.mps : p.M;
 
     // direct-to-LDS loads: wave-load q (16 per operand per stage) covers tile rows 4q..4q+3 x 256 B.
@@ -446,7 +518,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(TnParams p) {
         __syncthreads();
     }
 
-    float* out = p.slab + (size_t)blockIdx.y * p.N * p.K;
+    float* out = p.slab + (size_t)z * p.N * p.K;
     const int l31 = lane & 31;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -473,13 +545,14 @@ int tcow_gemm_tn_bf16(hipStream_t stream, int M, int N, int K, const bf16_t* dY,
     int mps = cdiv(M, splits); mps = ((mps + TN_MC - 1) / TN_MC) * TN_MC;
     p.mps = mps;
     const int nz = cdiv(M, mps);
+    p.nz = nz;
     *nz_out = nz;
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES);
         attr_set = true;
     }
-    hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3(p.tiles_n * p.tiles_k, nz), dim3(256), TN_LDS_BYTES, stream, p);
+    hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3(8 * cdiv(nz, 8) * p.tiles_n * p.tiles_k), dim3(256), TN_LDS_BYTES, stream, p);
     TCOW_CHECK_LAUNCH();
     return TCOW_OK;
 }

@@ -179,12 +179,13 @@ int tcow_gemm_nt_f32(hipStream_t stream, const tcow_gemm_args* a) {
     return TCOW_OK;
 }
 
-// number of token-dimension slices used by the weight-gradient GEMMs (both dtypes)
+// number of token-dimension slices used by the weight-gradient GEMMs (both dtypes): ~2 workgroups per CU, a multiple of
+// 8 so that every XCD owns the same number of slices (gemm_tn_bf16_kernel pins slice z to XCD z % 8), >= 256 tokens each.
 int tcow_tn_splits(int M, int N, int K, int tile_outputs) {
     const int tiles = cdiv(N, tile_outputs) * cdiv(K, tile_outputs);
-    int s = cdiv(512, tiles);                  // aim for ~2 workgroups per CU (slab traffic grows with the split count)
-    const int max_s = cdiv(M, 512);            // at least 512 tokens per slice
-    if (s > max_s) s = max_s;
+    int s = ((cdiv(512, tiles) + 7) / 8) * 8;
+    const int max_s = M / 256;
+    if (s > max_s) s = max_s >= 8 ? (max_s / 8) * 8 : max_s;
     if (s < 1) s = 1;
     if (s > 64) s = 64;
     return s;
