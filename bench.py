@@ -100,8 +100,9 @@ def main():
     from tcow_amd.seeker import Seeker
     rank, local_rank, world = ddp.init_distributed()
     assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    ndev = max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(local_rank % ndev)              # (% ndev only matters for the single-GPU gloo dry run of the N>1 path)
+    dev = torch.device('cuda', local_rank % ndev)
 
     cfg = synth.seeker_config(num_total_frames=args.frames, frame_height=args.height, frame_width=args.width,
                               depth=args.depth, causal_attention=1)
@@ -135,8 +136,7 @@ def main():
         model_retval = pipe.forward_kubric(data)                           # query sampling, query/target masks, ONE batched Seeker call (pipeline.py:85-200)
         progress = state['step'] / 1000.0
         loss = pipe.step_losses(data, model_retval, progress)['total_seeker']   # loss.py:238-421: weighted BCE + bootstrapped BCE + soft Jaccard
-        loss.backward()                                                    # train.py:98
-        sync.finish()
+        loss.backward()                                                    # train.py:98 (bucketed RCCL all-reduce runs inside, overlapped)
         torch.nn.utils.clip_grad_norm_(params, 0.3)                        # train.py:99-101
         opt.step()
         state['step'] += 1

@@ -29,18 +29,19 @@ def init_distributed(backend=None):
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'     # 'nccl' is RCCL on ROCm
+            backend = os.environ.get('TCOW_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')     # 'nccl' is RCCL on ROCm
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend == 'nccl':
-            torch.cuda.set_device(local_rank)
+            torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
 
 
 class GradSync:
-    """Bucketed, overlapped gradient averaging. Attach with `module.grad_hook = sync`; call `finish()` after
-    backward (before clipping / the optimizer step)."""
+    """Bucketed, overlapped gradient averaging. Attach with `module.grad_hook = sync`: engine.run_backward calls it once
+    per completed bucket and drains it (`finish()`) before handing the gradients to autograd, so after `loss.backward()`
+    every param.grad is already the mean over ranks."""
 
     def __init__(self, world_size=None, group=None):
         self.group = group

@@ -386,6 +386,10 @@ def run_backward(module, sv, params, d_mask, d_flags):
     grads[4].copy_(dtime_eff.sum(0))       # bias gradient = sum over all patch rows
     if module.grad_hook is not None:
         module.grad_hook('embed', emb_flat)
+        # The collectives launched above were overlapped with the remaining backward compute; they must be complete (in
+        # stream order) before autograd copies the bucket views into param.grad, so the hook is drained here.
+        if hasattr(module.grad_hook, 'finish'):
+            module.grad_hook.finish()
     return grads
 
 

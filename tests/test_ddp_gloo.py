@@ -52,3 +52,11 @@ def test_single_process_is_a_noop():
     t = torch.ones(5)
     sync('x', t); sync.finish()
     assert torch.equal(t, torch.ones(5)) and sync.pending == []
+
+
+def test_backward_drains_the_hook_before_returning_grads():
+    """engine.run_backward must call hook.finish() itself (autograd copies bucket views right after it returns)."""
+    import inspect
+    from tcow_amd import engine
+    src = inspect.getsource(engine.run_backward)
+    assert src.index("module.grad_hook('embed', emb_flat)") < src.index('module.grad_hook.finish()') < src.rindex('return grads')
