@@ -17,11 +17,13 @@ void tcow_set_error(const char* fmt, ...) {
 
 int tcow_gemm_nt_bf16(hipStream_t stream, const tcow_gemm_args* a);
 int tcow_gemm_nt_f32(hipStream_t stream, const tcow_gemm_args* a);
-int tcow_gemm_tn_bf16(hipStream_t stream, int M, int N, int K, const bf16_t* dY, long ldy, const bf16_t* X, long ldx, float* slab, int splits, int* nz_out);
+int tcow_gemm_tn_bf16(hipStream_t stream, int M, int N, int K, const bf16_t* dY, long ldy, const bf16_t* X, long ldx, float* slab, int splits, int* nz_out,
+                      float* bias_part, int* bias_parts_out);
 int tcow_gemm_tn_f32(hipStream_t stream, int M, int N, int K, const float* dY, long ldy, const float* X, long ldx, float* dW, long lddw, int accumulate,
                      float* slab, int splits);
 int tcow_tn_splits(int M, int N, int K, int tile_outputs);
 int tcow_launch_slab_reduce(hipStream_t stream, const float* slab, int nz, long slab_stride, long rows, long cols, float* out, long ldo, int accumulate);
+int tcow_launch_row_reduce(hipStream_t stream, const float* part, int nrows, long ld, int N, float* out, int accumulate);
 int tcow_launch_colsum(hipStream_t stream, int dtype, const void* Y, long ldy, int M, int N, float* out, int accumulate, float* part, int max_parts);
 
 extern "C" {
@@ -89,7 +91,7 @@ static int gemm_nt_dispatch(void* stream, const tcow_gemm_args* a) {
     return TCOW_ERR_INVALID_ARG;
 }
 
-static const int kColsumParts = 64;
+static const int kColsumParts = 64 * 24 * 2;   // >= nz * tiles_k * 2 partial rows of the fused bias gradient (nz <= 64, K <= 3072)
 
 long tcow_gemm_tn_workspace_bytes(int M, int N, int K) {
     const int s_bf = tcow_tn_splits(M, N, K, 128), s_f = tcow_tn_splits(M, N, K, 64);
@@ -103,14 +105,17 @@ int tcow_gemm_tn(void* stream, int dtype, int M, int N, int K, const void* dY, l
     TCOW_CHECK_ARG(workspace_bytes >= tcow_gemm_tn_workspace_bytes(M, N, K), "tcow_gemm_tn: workspace too small (%ld < %ld)", workspace_bytes,
                    tcow_gemm_tn_workspace_bytes(M, N, K));
     float* slab = (float*)workspace;
+    float* part = slab + (size_t)(workspace_bytes / 4 - (long)kColsumParts * N - 8);
     int rc;
     if (dtype == TCOW_BF16) {
         const int splits = tcow_tn_splits(M, N, K, 128);
-        int nz = 0;
-        rc = tcow_gemm_tn_bf16((hipStream_t)stream, M, N, K, (const bf16_t*)dY, ldy, (const bf16_t*)X, ldx, slab, splits, &nz);
+        int nz = 0, nparts = 0;
+        const bool fuse_bias = bias_grad != nullptr && (long)splits * ((K + 127) / 128) * 2 <= kColsumParts;
+        rc = tcow_gemm_tn_bf16((hipStream_t)stream, M, N, K, (const bf16_t*)dY, ldy, (const bf16_t*)X, ldx, slab, splits, &nz, fuse_bias ? part : nullptr, &nparts);
         if (rc) return rc;
         rc = tcow_launch_slab_reduce((hipStream_t)stream, slab, nz, (long)N * K, N, K, dW, lddw, accumulate);
         if (rc) return rc;
+        if (fuse_bias) return tcow_launch_row_reduce((hipStream_t)stream, part, nparts, N, N, bias_grad, accumulate);
     } else if (dtype == TCOW_F32) {
         const int splits = tcow_tn_splits(M, N, K, 64);
         rc = tcow_gemm_tn_f32((hipStream_t)stream, M, N, K, (const float*)dY, ldy, (const float*)X, ldx, dW, lddw, accumulate, slab, splits);
@@ -120,8 +125,7 @@ int tcow_gemm_tn(void* stream, int dtype, int M, int N, int K, const void* dY, l
         return TCOW_ERR_INVALID_ARG;
     }
     if (bias_grad) {
-        float* part = slab + (size_t)(workspace_bytes / 4 - (long)kColsumParts * N - 8);
-        rc = tcow_launch_colsum((hipStream_t)stream, dtype, dY, ldy, M, N, bias_grad, accumulate, part, kColsumParts);
+        rc = tcow_launch_colsum((hipStream_t)stream, dtype, dY, ldy, M, N, bias_grad, accumulate, part, 64);
         if (rc) return rc;
     }
     return TCOW_OK;

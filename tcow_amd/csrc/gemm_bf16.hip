@@ -420,6 +420,8 @@ struct TnParams {
     const bf16_t* X; long ldx;
     float* slab;
     int tiles_n, tiles_k, mps, nz;   // mps: token rows per slice (multiple of TN_MC); nz slices
+    float* bias_part;                // optional [nz][tiles_k][2][N] partial column sums of dY (bias gradient)
+    int rows_per_pk;                 // LDS rows of each 64-row stage summed by the workgroup with k-tile index pk
 };
 
 __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int off0) {
@@ -489,6 +491,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(TnParams p) {
         x_off[i] = rr * 256 + ((((cx >> 3) ^ ((q16 >> 2) << 2))) << 4) + (cx & 7) * 2;
     }
 
+    // column-sum duty of this thread: column cs_col of the dY tile, LDS rows [cs_r0, cs_r1) of every stage
+    const int cs_col = tid & 127;
+    const int cs_lo = pk * p.rows_per_pk, cs_hi = (cs_lo + p.rows_per_pk < TN_MC) ? cs_lo + p.rows_per_pk : TN_MC;
+    const int cs_mid = cs_lo + (cs_hi - cs_lo + 1) / 2;
+    const int cs_r0 = (tid >> 7) ? cs_mid : cs_lo, cs_r1 = (tid >> 7) ? cs_hi : (cs_mid < cs_hi ? cs_mid : cs_hi);
+    float colsum = 0.f;
+
     const int nmt = (mend - mbeg + TN_MC - 1) / TN_MC;
     if (nmt > 0) {
         issue(mbeg, 0);
@@ -514,9 +523,20 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(TnParams p) {
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fy[i], fx[j], acc[i][j], 0, 0, 0);
         }
+        if (p.bias_part) {
+            // bias gradient = column sums of dY: the dY stage is already in LDS; the tiles_k workgroups that share it split
+            // its 64 rows between them (and each between its two thread halves), so the extra work is a few LDS reads each.
+#pragma unroll 4
+            for (int r = cs_r0; r < cs_r1; ++r) {
+                const int off = r * 256 + ((((cs_col >> 3) ^ ((r & 3) << 2))) << 4) + (cs_col & 7) * 2;
+                colsum += bf2f(*reinterpret_cast<const bf16_t*>(sy + off));
+            }
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
+    if (p.bias_part && n0 + cs_col < p.N)
+        p.bias_part[(((size_t)z * p.tiles_k + pk) * 2 + (tid >> 7)) * p.N + n0 + cs_col] = colsum;
 
     float* out = p.slab + (size_t)z * p.N * p.K;
     const int l31 = lane & 31;
@@ -537,7 +557,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(TnParams p) {
 }  // namespace
 
 int tcow_gemm_tn_bf16(hipStream_t stream, int M, int N, int K, const bf16_t* dY, long ldy, const bf16_t* X, long ldx, float* slab, int splits,
-                      int* nz_out) {
+                      int* nz_out, float* bias_part, int* bias_parts_out) {
     TCOW_CHECK_ARG(N % 8 == 0 && K % 8 == 0 && ldy % 8 == 0 && ldx % 8 == 0, "tcow_gemm_tn(bf16): N, K, ldy, ldx must be multiples of 8");
     TnParams p;
     p.M = M; p.N = N; p.K = K; p.dY = dY; p.ldy = ldy; p.X = X; p.ldx = ldx; p.slab = slab;
@@ -547,6 +567,9 @@ int tcow_gemm_tn_bf16(hipStream_t stream, int M, int N, int K, const bf16_t* dY,
     const int nz = cdiv(M, mps);
     p.nz = nz;
     *nz_out = nz;
+    p.bias_part = bias_part;
+    p.rows_per_pk = cdiv(TN_MC, p.tiles_k);
+    if (bias_parts_out) *bias_parts_out = nz * p.tiles_k * 2;
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES);

@@ -138,6 +138,21 @@ __global__ void slab_reduce4_kernel(const float* __restrict__ slab, int nz, long
     }
 }
 
+// out[c] (+)= sum_r part[r][c] for a tall-skinny partial table (many rows, few columns): 16 columns x 16 row groups per block
+__global__ __launch_bounds__(256) void row_reduce_kernel(const float* __restrict__ part, int nrows, long ld, int N, float* __restrict__ out, int accumulate) {
+    __shared__ float red[16][17];
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15), g = threadIdx.x >> 4;
+    float s = 0.f;
+    if (c < N)
+        for (int r = g; r < nrows; r += 16) s += part[(size_t)r * ld + c];
+    red[g][threadIdx.x & 15] = s;
+    __syncthreads();
+    if (g == 0 && c < N) {
+        for (int k = 1; k < 16; ++k) s += red[k][threadIdx.x & 15];
+        out[c] = accumulate ? out[c] + s : s;
+    }
+}
+
 // column sums of Y[M,N] (bias gradient): thread = 4 consecutive columns, a block covers 128 columns x a row slice with
 // 8 row groups folded through LDS; partial rows go to `part` and tcow_launch_slab_reduce finishes.
 template <typename T>
@@ -201,6 +216,12 @@ int tcow_launch_slab_reduce(hipStream_t stream, const float* slab, int nz, long 
         int blocks = cdiv(n, 256); if (blocks > 2048) blocks = 2048;
         hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, stream, slab, nz, slab_stride, n, out, rows, cols, ldo, accumulate);
     }
+    TCOW_CHECK_LAUNCH();
+    return TCOW_OK;
+}
+
+int tcow_launch_row_reduce(hipStream_t stream, const float* part, int nrows, long ld, int N, float* out, int accumulate) {
+    hipLaunchKernelGGL(row_reduce_kernel, dim3(cdiv(N, 16)), dim3(256), 0, stream, part, nrows, ld, N, out, accumulate);
     TCOW_CHECK_LAUNCH();
     return TCOW_OK;
 }

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int D, const T* _
 
 }  // namespace
 
-int tcow_launch_slab_reduce(hipStream_t stream, const float* slab, int nz, long slab_stride, long rows, long cols, float* out, long ldo, int accumulate);
+int tcow_launch_row_reduce(hipStream_t stream, const float* part, int nrows, long ld, int N, float* out, int accumulate);
 
 static const int kLnBwdBlocks = 512;
 
@@ -164,9 +164,9 @@ int tcow_layernorm_bwd(void* stream, int dtype, int rows, int D, const void* dy,
     TCOW_CHECK_LAUNCH();
     if (want_param_grads) {
         // part is [blocks][2][D]: slab stride 2*D, dgamma partials first, dbeta partials at +D
-        int rc = tcow_launch_slab_reduce((hipStream_t)stream, part, blocks, 2L * D, 1, D, dgamma, D, accumulate);
+        int rc = tcow_launch_row_reduce((hipStream_t)stream, part, blocks, 2L * D, D, dgamma, accumulate);
         if (rc) return rc;
-        return tcow_launch_slab_reduce((hipStream_t)stream, part + D, blocks, 2L * D, 1, D, dbeta, D, accumulate);
+        return tcow_launch_row_reduce((hipStream_t)stream, part + D, blocks, 2L * D, D, dbeta, accumulate);
     }
     return TCOW_OK;
 }
