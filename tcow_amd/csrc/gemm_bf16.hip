@@ -49,50 +49,69 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((GLB_PTR(const uint32_t))gsrc, (LDS_PTR(uint32_t))lds_wave_base, 16, 0, 0);
 }
 
-// Epilogue: accumulators -> LDS (f32 [128][128]) -> coalesced row-wise stores.  Column-dependent operands (bias) are the
-// same for all 16 row passes of a thread; row-dependent ones (row scale, residual, GELU' input) are fetched for 8 passes at
-// a time and ISSUED EARLY (first half before the LDS staging + barrier, second half before the first half is consumed) so
-// that their L2/HBM latency overlaps the staging instead of serialising behind it once per tile.
-struct EpiOperands { float4 res[8]; float4 ax[8]; float rs[8]; };
-
-__device__ __forceinline__ void epi_fetch(const NtParams& p, EpiOperands& o, int half, int tid, int m0, int gn, bool col_ok) {
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const int gm = m0 + (half * 8 + u) * 8 + (tid >> 5);
-        o.res[u] = make_float4(0.f, 0.f, 0.f, 0.f); o.ax[u] = o.res[u]; o.rs[u] = 1.0f;
-        if (col_ok && gm < p.M) {
-            if (p.row_scale) o.rs[u] = p.row_scale[gm];
-            if (p.resid) o.res[u] = ld4(p.resid + (size_t)gm * p.ldr + gn);
-            if (p.act == TCOW_ACT_DGELU) o.ax[u] = ld4(p.aux + (size_t)gm * p.ldaux + gn);
-        }
-    }
+// Epilogue: accumulators -> LDS (f32) -> coalesced row-wise stores.  The row loop is deliberately NOT unrolled and the erf-based
+// activations are out-of-line calls: a fully unrolled epilogue with erff inlined 128x is ~160 KB of straight-line code per kernel
+// and runs at instruction-fetch speed (measured: 80 us of a 230 us GEMM).  Row-dependent operands (row scale, residual or GELU'
+// input) of row group it+1 are requested before row group it is processed so their latency overlaps.
+__device__ __noinline__ float4 gelu4(float4 v) { return make_float4(gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w)); }
+__device__ __noinline__ float4 dgelu4(float4 v, float4 a) {
+    return make_float4(v.x * gelu_erf_grad(a.x), v.y * gelu_erf_grad(a.y), v.z * gelu_erf_grad(a.z), v.w * gelu_erf_grad(a.w));
 }
 
-__device__ __forceinline__ void epi_apply(const NtParams& p, const EpiOperands& o, const float* ct, float4 b4, int half, int tid, int m0, int gn, int c4) {
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const int row = (half * 8 + u) * 8 + (tid >> 5);
-        const int gm = m0 + row;
-        if (gm >= p.M) continue;
-        float4 v = *reinterpret_cast<const float4*>(ct + row * BN + c4);
-        v.x = (v.x + b4.x) * o.rs[u]; v.y = (v.y + b4.y) * o.rs[u]; v.z = (v.z + b4.z) * o.rs[u]; v.w = (v.w + b4.w) * o.rs[u];
-        if (p.act == TCOW_ACT_GELU) {
-            if (p.aux) st4(p.aux + (size_t)gm * p.ldaux + gn, v);
-            v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
-        } else if (p.act == TCOW_ACT_DGELU) {
-            v.x *= gelu_erf_grad(o.ax[u].x); v.y *= gelu_erf_grad(o.ax[u].y); v.z *= gelu_erf_grad(o.ax[u].z); v.w *= gelu_erf_grad(o.ax[u].w);
+struct EpiRow { float4 ext; float rs; };
+
+__device__ __forceinline__ EpiRow epi_row_fetch(const NtParams& p, int gm, int gn, bool ok) {
+    EpiRow o; o.ext = make_float4(0.f, 0.f, 0.f, 0.f); o.rs = 1.0f;
+    if (ok && gm < p.M) {
+        if (p.row_scale) o.rs = p.row_scale[gm];
+        if (p.resid) o.ext = ld4(p.resid + (size_t)gm * p.ldr + gn);
+        else if (p.act == TCOW_ACT_DGELU) o.ext = ld4(p.aux + (size_t)gm * p.ldaux + gn);
+    }
+    return o;
+}
+
+__device__ __forceinline__ void epi_row_apply(const NtParams& p, const EpiRow& o, float4 v, float4 b4, int gm, int gn) {
+    v.x = (v.x + b4.x) * o.rs; v.y = (v.y + b4.y) * o.rs; v.z = (v.z + b4.z) * o.rs; v.w = (v.w + b4.w) * o.rs;
+    if (p.act == TCOW_ACT_GELU) {
+        if (p.aux) st4(p.aux + (size_t)gm * p.ldaux + gn, v);
+        v = gelu4(v);
+    } else if (p.act == TCOW_ACT_DGELU) {
+        v = dgelu4(v, o.ext);
+    }
+    if (p.resid) { v.x += o.ext.x; v.y += o.ext.y; v.z += o.ext.z; v.w += o.ext.w; }
+    if (p.out_f32) st4(reinterpret_cast<float*>(p.C) + (size_t)gm * p.ldc + gn, v);
+    else st4(reinterpret_cast<bf16_t*>(p.C) + (size_t)gm * p.ldc + gn, v);
+}
+
+// Store loop over the 16 row groups a thread owns.  gfx9's vmcnt counts stores as well as loads, and hipcc waits vmcnt(0) for a
+// load result that sits behind younger stores -- a loop that mixes "fetch next row operands" with "store this row" therefore
+// waits for every store to complete before the next one (measured: 27 us per 256x256 tile).  So: without row operands the loop
+// contains no loads at all; with row operands ALL of them are fetched up front and the loop only stores.
+__device__ __forceinline__ void epi_rows(const NtParams& p, const float* ct, int ct_ld, float4 b4, int gm_first, int row_first, int row_step, int c4, int gn) {
+    const bool rowops = p.row_scale != nullptr || p.resid != nullptr || p.act == TCOW_ACT_DGELU;
+    if (!rowops) {
+        EpiRow o; o.ext = make_float4(0.f, 0.f, 0.f, 0.f); o.rs = 1.0f;
+#pragma unroll 1
+        for (int it = 0; it < 16; ++it) {
+            const int gm = gm_first + it * row_step;
+            if (gm >= p.M) break;
+            epi_row_apply(p, o, *reinterpret_cast<const float4*>(ct + (row_first + it * row_step) * ct_ld + c4), b4, gm, gn);
         }
-        v.x += o.res[u].x; v.y += o.res[u].y; v.z += o.res[u].z; v.w += o.res[u].w;
-        if (p.out_f32) st4(reinterpret_cast<float*>(p.C) + (size_t)gm * p.ldc + gn, v);
-        else st4(reinterpret_cast<bf16_t*>(p.C) + (size_t)gm * p.ldc + gn, v);
+    } else {
+        EpiRow o[16];
+#pragma unroll
+        for (int it = 0; it < 16; ++it) o[it] = epi_row_fetch(p, gm_first + it * row_step, gn, true);
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int gm = gm_first + it * row_step;
+            if (gm < p.M) epi_row_apply(p, o[it], *reinterpret_cast<const float4*>(ct + (row_first + it * row_step) * ct_ld + c4), b4, gm, gn);
+        }
     }
 }
 
 __device__ __forceinline__ void nt_epilogue(const NtParams& p, char* smem, f32x16 (&acc)[2][2], float4 b4, int tid, int wm, int wn, int l31, int hi, int m0, int n0) {
     const int c4 = (tid & 31) * 4, gn = n0 + c4;
     const bool col_ok = gn < p.N;                 // N % 4 == 0: a thread's 4 columns are all in or all out
-    EpiOperands o0, o1;
-    epi_fetch(p, o0, 0, tid, m0, gn, col_ok);
     float* ct = reinterpret_cast<float*>(smem);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -105,67 +124,8 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, char* smem, f32x1
                 ct[row * BN + col] = acc[i][j][r];
             }
     __syncthreads();
-    epi_fetch(p, o1, 1, tid, m0, gn, col_ok);
     if (!col_ok) return;
-    epi_apply(p, o0, ct, b4, 0, tid, m0, gn, c4);
-    epi_apply(p, o1, ct, b4, 1, tid, m0, gn, c4);
-}
-
-// ---- register-direct epilogue (A/B variant 1; measured 5-10 % SLOWER than the LDS-staged one: its 8-byte stores land 32 rows apart).  The main loop issues mfma(W fragment, A fragment), i.e. it accumulates C^T tiles:
-// lane (l&31, hi) then owns ONE output row m and, per 32-wide column tile, 16 columns n = 8*(r>>2) + 4*hi + (r&3) -- four
-// groups of 4 CONSECUTIVE columns.  Each group is one 8-byte (bf16) or 16-byte (f32) store, residual / GELU' operands are
-// matching vector loads, and no LDS round trip or workgroup barrier is needed: waves retire independently.
-struct DirectBias { float4 b[2][4]; };
-
-__device__ __forceinline__ DirectBias direct_bias(const NtParams& p, int wn, int hi, int n0) {
-    DirectBias d;
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int gn = n0 + wn * 64 + j * 32 + 8 * g + 4 * hi;
-            d.b[j][g] = (p.bias && gn < p.N) ? ld4(p.bias + gn) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    return d;
-}
-
-__device__ __forceinline__ void nt_epilogue_direct(const NtParams& p, f32x16 (&acc)[2][2], const DirectBias& db, int wm, int wn, int l31, int hi, int m0, int n0) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int gm = m0 + wm * 64 + i * 32 + l31;
-        if (gm >= p.M) continue;
-        const float rs = p.row_scale ? p.row_scale[gm] : 1.0f;
-        float4 res[2][4], ax[2][4];
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int gn = n0 + wn * 64 + j * 32 + 8 * g + 4 * hi;
-                res[j][g] = make_float4(0.f, 0.f, 0.f, 0.f); ax[j][g] = res[j][g];
-                if (gn < p.N) {
-                    if (p.resid) res[j][g] = ld4(p.resid + (size_t)gm * p.ldr + gn);
-                    if (p.act == TCOW_ACT_DGELU) ax[j][g] = ld4(p.aux + (size_t)gm * p.ldaux + gn);
-                }
-            }
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int gn = n0 + wn * 64 + j * 32 + 8 * g + 4 * hi;
-                if (gn >= p.N) continue;
-                const float4 b = db.b[j][g];
-                float4 v = make_float4((acc[i][j][4 * g] + b.x) * rs, (acc[i][j][4 * g + 1] + b.y) * rs, (acc[i][j][4 * g + 2] + b.z) * rs, (acc[i][j][4 * g + 3] + b.w) * rs);
-                if (p.act == TCOW_ACT_GELU) {
-                    if (p.aux) st4(p.aux + (size_t)gm * p.ldaux + gn, v);
-                    v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
-                } else if (p.act == TCOW_ACT_DGELU) {
-                    v.x *= gelu_erf_grad(ax[j][g].x); v.y *= gelu_erf_grad(ax[j][g].y); v.z *= gelu_erf_grad(ax[j][g].z); v.w *= gelu_erf_grad(ax[j][g].w);
-                }
-                v.x += res[j][g].x; v.y += res[j][g].y; v.z += res[j][g].z; v.w += res[j][g].w;
-                if (p.out_f32) st4(reinterpret_cast<float*>(p.C) + (size_t)gm * p.ldc + gn, v);
-                else st4(reinterpret_cast<bf16_t*>(p.C) + (size_t)gm * p.ldc + gn, v);
-            }
-    }
+    epi_rows(p, ct, BN, b4, m0 + (tid >> 5), tid >> 5, 8, c4, gn);
 }
 
 // bias for this thread's 4 epilogue columns, fetched at kernel start (its latency hides behind the whole main loop)
@@ -272,7 +232,111 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_ring_kernel(NtParams p) {
     nt_epilogue(p, smem, acc, b4, tid, wm, wn, l31, hi, m0, n0);
 }
 
-template <bool DIRECT>
+// ---- 256 x 256 tile, 8 waves (2 x 4, 128 x 64 each).  PMC on the 128-tile kernel (profiles/r01_pmc_gemm_sq.txt): zero LDS bank
+// conflicts, MFMA pipe busy 29 %, waves parked 39 % of their cycles in the vmcnt/barrier wait -- the 128 x 128 x 64 step pulls
+// 32 KiB per workgroup per 2.1 MFLOP, ~10 TB/s of L2->LDS traffic chip-wide.  The 256-square tile halves the bytes per FLOP
+// (64 KiB per 8.4 MFLOP) and needs 6 instead of 8 fragment reads per 8 MFMAs.  128 KiB LDS (two stages), one workgroup per CU.
+constexpr int B_BM = 256, B_BN = 256;
+constexpr int B_TILE = 256 * 128;              // 32 KiB per operand per stage
+constexpr int B_STAGE = 2 * B_TILE;
+constexpr int B_LDS = 2 * B_STAGE;             // 128 KiB
+
+__global__ __launch_bounds__(512, 2) void gemm_nt_bf16_256_kernel(NtParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int nblk = p.tiles_m * p.tiles_n;
+    const int pid = xcd_remap(blockIdx.x, nblk);
+    const int pm = pid / p.tiles_n, pn = pid - pm * p.tiles_n;
+    const int m0 = pm * B_BM, n0 = pn * B_BN;
+
+    const bf16_t* a_src[4];
+    const bf16_t* w_src[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = (wave * 4 + j) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        int gm = m0 + r; gm = gm < p.M ? gm : p.M - 1;
+        int gn = n0 + r; gn = gn < p.N ? gn : p.N - 1;
+        a_src[j] = p.A + (size_t)gm * p.lda + c * 8;
+        w_src[j] = p.W + (size_t)gn * p.ldw + c * 8;
+    }
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = p.K / BK;
+    auto issue = [&](int kt, int stage) {
+        char* sa = smem + stage * B_STAGE;
+        char* sw = sa + B_TILE;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            glds16(a_src[j] + (size_t)kt * BK, sa + (wave * 4 + j) * 1024);
+            glds16(w_src[j] + (size_t)kt * BK, sw + (wave * 4 + j) * 1024);
+        }
+    };
+    int a_off[4], a_sw[4], w_off[2], w_sw[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int ra = wm * 128 + i * 32 + l31; a_off[i] = ra * 128; a_sw[i] = (ra >> 1) & 7; }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { const int rw = wn * 64 + j * 32 + l31; w_off[j] = rw * 128; w_sw[j] = (rw >> 1) & 7; }
+
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int stage = kt & 1;
+        if (kt + 1 < nk) issue(kt + 1, stage ^ 1);
+        const char* sa = smem + stage * B_STAGE;
+        const char* sw = sa + B_TILE;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int c = 2 * ks + hi;
+            bf16x8 fa[4], fw[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fw[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sw + w_off[j] + ((c ^ w_sw[j]) << 4)));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sa + a_off[i] + ((c ^ a_sw[i]) << 4)));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fw[j], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---- epilogue: every wave stages its own 128 x 64 tile through a private 16 KiB LDS region, 64 rows at a time, and writes
+    // full output rows (128 B bf16 / 256 B f32 per row).  No workgroup barrier: a wave's LDS operations execute in order.
+    float* ct = reinterpret_cast<float*>(smem + wave * 16384);
+    const int c4 = (lane & 15) * 4;
+    const int gn = n0 + wn * 64 + c4;
+    const bool col_ok = gn < p.N;
+    const float4 b4 = (p.bias && col_ok) ? ld4(p.bias + gn) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int mrow0 = m0 + wm * 128 + pass * 64;
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    ct[(ii * 32 + crow32(r, hi)) * 64 + j * 32 + l31] = acc[pass * 2 + ii][j][r];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (col_ok) epi_rows(p, ct, 64, b4, mrow0 + (lane >> 4), lane >> 4, 4, c4, gn);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads of this pass done before the next pass overwrites the region
+    }
+}
+
 __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(NtParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -285,9 +349,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(NtParams p) {
     const int pid = xcd_remap(blockIdx.x, nblk);
     const int pm = pid / p.tiles_n, pn = pid - pm * p.tiles_n;
     const int m0 = pm * BM, n0 = pn * BN;
-    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    DirectBias db;
-    if (DIRECT) db = direct_bias(p, wn, hi, n0); else b4 = epi_bias(p, tid, n0);
+    const float4 b4 = epi_bias(p, tid, n0);
 
     // ---- per-lane source pointers for the direct-to-LDS loads: wave w issues wave-loads 4w..4w+3 per operand,
     // each covering 8 tile rows x 128 B; lane -> (row r = 8*q + (lane>>3), LDS chunk position lane&7).
@@ -353,14 +415,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(NtParams p) {
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = DIRECT ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0)
-                                       : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fw[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fw[j], acc[i][j], 0, 0, 0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    if (DIRECT) nt_epilogue_direct(p, acc, db, wm, wn, l31, hi, m0, n0);
-    else nt_epilogue(p, smem, acc, b4, tid, wm, wn, l31, hi, m0, n0);
+    nt_epilogue(p, smem, acc, b4, tid, wm, wn, l31, hi, m0, n0);
 }
 
 }  // namespace
@@ -378,19 +438,27 @@ int tcow_gemm_nt_bf16(hipStream_t stream, const tcow_gemm_args* a) {
     p.tiles_m = cdiv(a->M, BM); p.tiles_n = cdiv(a->N, BN);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
         attr_set = true;
     }
-    static const int variant = [] { const char* e = getenv("TCOW_GEMM_NT"); return e ? atoi(e) : 3; }();   // 3 = two-stage BK=64 + LDS-staged epilogue (default, fastest: profiles/r01_gemm_variants.txt), 1 = register-direct epilogue, 2 = 4-deep BK=32 ring
+    static const int big = [] { const char* e = getenv("TCOW_GEMM_BIG"); return e ? atoi(e) : 1; }();
+    // the 256-square tile runs one workgroup per CU: it only pays when there are several full rounds of tiles (>= ~2.7 per CU)
+    if (big && (long)cdiv(a->M, B_BM) * cdiv(a->N, B_BN) >= 700) {
+        p.tiles_m = cdiv(a->M, B_BM); p.tiles_n = cdiv(a->N, B_BN);
+        static bool attr3 = false;
+        if (!attr3) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, B_LDS); attr3 = true; }
+        hipLaunchKernelGGL(gemm_nt_bf16_256_kernel, dim3(p.tiles_m * p.tiles_n), dim3(512), B_LDS, stream, p);
+        TCOW_CHECK_LAUNCH();
+        return TCOW_OK;
+    }
+    static const int variant = [] { const char* e = getenv("TCOW_GEMM_NT"); return e ? atoi(e) : 3; }();   // 3 = two-stage BK=64 (default), 2 = 4-deep BK=32 ring (A/B; slower, profiles/r01_gemm_variants.txt). A register-direct
+    // epilogue with the swapped MFMA orientation was also tried and dropped (5-10 % slower: its 8-byte stores land 32 rows apart).
     if (variant == 2) {
         static bool attr2 = false;
         if (!attr2) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_ring_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES); attr2 = true; }
         hipLaunchKernelGGL(gemm_nt_bf16_ring_kernel, dim3(p.tiles_m * p.tiles_n), dim3(256), NT_LDS_BYTES, stream, p);
-    } else if (variant == 3) {       // LDS-staged epilogue (earlier default), kept for A/B
-        hipLaunchKernelGGL(gemm_nt_bf16_kernel<false>, dim3(p.tiles_m * p.tiles_n), dim3(256), NT_LDS_BYTES, stream, p);
     } else {
-        hipLaunchKernelGGL(gemm_nt_bf16_kernel<true>, dim3(p.tiles_m * p.tiles_n), dim3(256), NT_LDS_BYTES, stream, p);
+        hipLaunchKernelGGL(gemm_nt_bf16_kernel, dim3(p.tiles_m * p.tiles_n), dim3(256), NT_LDS_BYTES, stream, p);
     }
     TCOW_CHECK_LAUNCH();
     return TCOW_OK;
