@@ -6,9 +6,9 @@
 
 namespace {
 
-constexpr int LN_MAXV = 8;  // float4 per lane -> D <= 64*4*8 = 2048
+constexpr int LN_MAXV = 8;  // float4 per lane -> D <= 64*4*8 = 2048; kernels are instantiated for NV = 1, 2, 3, 4, 8 (NV = 3 is D = 768)
 
-template <typename T>
+template <typename T, int NV>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(int rows, int D, const float* __restrict__ x, long ldx, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float eps, T* __restrict__ y, long ldy,
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out) {
@@ -17,17 +17,17 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(int rows, int D, const floa
     if (row >= rows) return;
     const int nv = D >> 2;  // float4 count
     const float* xr = x + (size_t)row * ldx;
-    float4 v[LN_MAXV];
+    float4 v[NV];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c = lane + i * 64;
         if (c < nv) { v[i] = ld4(xr + c * 4); s += (v[i].x + v[i].y) + (v[i].z + v[i].w); }
     }
     const float mean = wave_sum(s) / (float)D;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c = lane + i * 64;
         if (c < nv) {
             const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(int rows, int D, const floa
     }
     T* yr = y + (size_t)row * ldy;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c = lane + i * 64;
         if (c < nv) {
             const float4 g = ld4(gamma + c * 4), b = ld4(beta + c * 4);
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(int rows, int D, const floa
 // dx_out = dres + dx (the gradient arriving through the residual connection is added here).
 // dgamma / dbeta partial sums: each wave keeps per-column partials over the rows it visits, the block folds its
 // 4 waves through LDS and writes one partial row per block; tcow_launch_slab_reduce finishes the sum.
-template <typename T>
+template <typename T, int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int D, const T* __restrict__ dy, long lddy, const float* __restrict__ x, long ldx,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const float* __restrict__ dres, long lddres,
@@ -65,24 +65,42 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int D, const T* _
     extern __shared__ __attribute__((aligned(16))) float red[];  // [4][2*D]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = D >> 2;
-    float4 gsum[LN_MAXV], bsum[LN_MAXV], gam[LN_MAXV];
+    float4 gsum[NV], bsum[NV], gam[NV];
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         gsum[i] = make_float4(0.f, 0.f, 0.f, 0.f); bsum[i] = gsum[i];
         const int c = lane + i * 64;
         gam[i] = (c < nv) ? ld4(gamma + c * 4) : gsum[i];
     }
-    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
-        const float mu = mean[row], rs = rstd[row];
-        const float* xr = x + (size_t)row * ldx;
-        const T* dyr = dy + (size_t)row * lddy;
-        float4 xh[LN_MAXV], g[LN_MAXV];
-        float s1 = 0.f, s2 = 0.f;
+    // Software-pipelined over the rows a wave visits: the loads of the NEXT row are issued before this row's results are stored.
+    // (vmcnt counts stores too: a "load, compute, store" loop body makes every row wait for the previous row's stores.)
+    const int rstep = gridDim.x * 4;
+    int row = blockIdx.x * 4 + wave;
+    float4 xn[NV], dn[NV], rn[NV];
+    float mu_n = 0.f, rs_n = 0.f;
+    auto fetch = [&](int r) {
+        mu_n = mean[r]; rs_n = rstd[r];
 #pragma unroll
-        for (int i = 0; i < LN_MAXV; ++i) {
+        for (int i = 0; i < NV; ++i) {
             const int c = lane + i * 64;
             if (c < nv) {
-                const float4 xv = ld4(xr + c * 4), d = ld4(dyr + c * 4);
+                xn[i] = ld4(x + (size_t)r * ldx + c * 4);
+                dn[i] = ld4(dy + (size_t)r * lddy + c * 4);
+                if (dres) rn[i] = ld4(dres + (size_t)r * lddres + c * 4);
+            }
+        }
+    };
+    if (row < rows) fetch(row);
+    for (; row < rows; row += rstep) {
+        const float mu = mu_n, rs = rs_n;
+        float4 xh[NV], g[NV], rr[NV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + i * 64;
+            if (c < nv) {
+                const float4 xv = xn[i], d = dn[i];
+                rr[i] = rn[i];
                 xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
                 g[i] = make_float4(d.x * gam[i].x, d.y * gam[i].y, d.z * gam[i].z, d.w * gam[i].w);
                 s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
@@ -91,22 +109,23 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int D, const T* _
                 bsum[i].x += d.x; bsum[i].y += d.y; bsum[i].z += d.z; bsum[i].w += d.w;
             }
         }
+        if (row + rstep < rows) fetch(row + rstep);
         const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
         float* dxr = dx + (size_t)row * lddx;
 #pragma unroll
-        for (int i = 0; i < LN_MAXV; ++i) {
+        for (int i = 0; i < NV; ++i) {
             const int c = lane + i * 64;
             if (c < nv) {
                 float4 o = make_float4(rs * (g[i].x - m1 - xh[i].x * m2), rs * (g[i].y - m1 - xh[i].y * m2), rs * (g[i].z - m1 - xh[i].z * m2),
                                        rs * (g[i].w - m1 - xh[i].w * m2));
-                if (dres) { const float4 r = ld4(dres + (size_t)row * lddres + c * 4); o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
+                if (dres) { o.x += rr[i].x; o.y += rr[i].y; o.z += rr[i].z; o.w += rr[i].w; }
                 st4(dxr + c * 4, o);
             }
         }
     }
     if (!part) return;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c = lane + i * 64;
         if (c < nv) {
             *reinterpret_cast<float4*>(red + (size_t)wave * 2 * D + c * 4) = gsum[i];
@@ -132,11 +151,15 @@ int tcow_layernorm_fwd(void* stream, int dtype, int rows, int D, const float* x,
     TCOW_CHECK_ARG(rows > 0 && D > 0 && D % 4 == 0 && D <= 64 * 4 * LN_MAXV, "tcow_layernorm_fwd: D=%d must be a multiple of 4 and <= %d", D, 64 * 4 * LN_MAXV);
     TCOW_CHECK_ARG(x && gamma && beta && y && ldx % 4 == 0 && ldy % 4 == 0, "tcow_layernorm_fwd: bad pointers / strides");
     const dim3 grid(cdiv(rows, 4)), block(256);
-    if (dtype == TCOW_BF16)
-        hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, rows, D, x, ldx, gamma, beta, eps, (bf16_t*)y, ldy, mean, rstd);
-    else if (dtype == TCOW_F32)
-        hipLaunchKernelGGL(ln_fwd_kernel<float>, grid, block, 0, (hipStream_t)stream, rows, D, x, ldx, gamma, beta, eps, (float*)y, ldy, mean, rstd);
-    else { tcow_set_error("tcow_layernorm_fwd: unknown dtype %d", dtype); return TCOW_ERR_INVALID_ARG; }
+    if (dtype != TCOW_BF16 && dtype != TCOW_F32) { tcow_set_error("tcow_layernorm_fwd: unknown dtype %d", dtype); return TCOW_ERR_INVALID_ARG; }
+    const int nvl = (D / 4 + 63) / 64;
+#define LN_FWD(NVV)                                                                                                                               \
+    do {                                                                                                                                          \
+        if (dtype == TCOW_BF16) hipLaunchKernelGGL((ln_fwd_kernel<bf16_t, NVV>), grid, block, 0, (hipStream_t)stream, rows, D, x, ldx, gamma, beta, eps, (bf16_t*)y, ldy, mean, rstd); \
+        else hipLaunchKernelGGL((ln_fwd_kernel<float, NVV>), grid, block, 0, (hipStream_t)stream, rows, D, x, ldx, gamma, beta, eps, (float*)y, ldy, mean, rstd); \
+    } while (0)
+    if (nvl <= 1) LN_FWD(1); else if (nvl == 2) LN_FWD(2); else if (nvl == 3) LN_FWD(3); else if (nvl == 4) LN_FWD(4); else LN_FWD(8);
+#undef LN_FWD
     TCOW_CHECK_LAUNCH();
     return TCOW_OK;
 }
@@ -154,13 +177,15 @@ int tcow_layernorm_bwd(void* stream, int dtype, int rows, int D, const void* dy,
     int blocks = cdiv(rows, 4); if (blocks > kLnBwdBlocks) blocks = kLnBwdBlocks;
     float* part = want_param_grads ? (float*)workspace : nullptr;
     const size_t lds = want_param_grads ? (size_t)8 * D * 4 : 0;
-    if (dtype == TCOW_BF16)
-        hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), lds, (hipStream_t)stream, rows, D, (const bf16_t*)dy, lddy, x, ldx, mean, rstd, gamma, dres,
-                           lddres, dx, lddx, part);
-    else if (dtype == TCOW_F32)
-        hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(blocks), dim3(256), lds, (hipStream_t)stream, rows, D, (const float*)dy, lddy, x, ldx, mean, rstd, gamma, dres,
-                           lddres, dx, lddx, part);
-    else { tcow_set_error("tcow_layernorm_bwd: unknown dtype %d", dtype); return TCOW_ERR_INVALID_ARG; }
+    if (dtype != TCOW_BF16 && dtype != TCOW_F32) { tcow_set_error("tcow_layernorm_bwd: unknown dtype %d", dtype); return TCOW_ERR_INVALID_ARG; }
+    const int nvl = (D / 4 + 63) / 64;
+#define LN_BWD(NVV)                                                                                                                               \
+    do {                                                                                                                                          \
+        if (dtype == TCOW_BF16) hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, NVV>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, rows, D, (const bf16_t*)dy, lddy, x, ldx, mean, rstd, gamma, dres, lddres, dx, lddx, part); \
+        else hipLaunchKernelGGL((ln_bwd_kernel<float, NVV>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, rows, D, (const float*)dy, lddy, x, ldx, mean, rstd, gamma, dres, lddres, dx, lddx, part); \
+    } while (0)
+    if (nvl <= 1) LN_BWD(1); else if (nvl == 2) LN_BWD(2); else if (nvl == 3) LN_BWD(3); else if (nvl == 4) LN_BWD(4); else LN_BWD(8);
+#undef LN_BWD
     TCOW_CHECK_LAUNCH();
     if (want_param_grads) {
         // part is [blocks][2][D]: slab stride 2*D, dgamma partials first, dbeta partials at +D
