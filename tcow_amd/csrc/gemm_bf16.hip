@@ -87,22 +87,23 @@ __device__ __forceinline__ void epi_row_apply(const NtParams& p, const EpiRow& o
 // load result that sits behind younger stores -- a loop that mixes "fetch next row operands" with "store this row" therefore
 // waits for every store to complete before the next one (measured: 27 us per 256x256 tile).  So: without row operands the loop
 // contains no loads at all; with row operands ALL of them are fetched up front and the loop only stores.
+template <int NIT = 16>
 __device__ __forceinline__ void epi_rows(const NtParams& p, const float* ct, int ct_ld, float4 b4, int gm_first, int row_first, int row_step, int c4, int gn) {
     const bool rowops = p.row_scale != nullptr || p.resid != nullptr || p.act == TCOW_ACT_DGELU;
     if (!rowops) {
         EpiRow o; o.ext = make_float4(0.f, 0.f, 0.f, 0.f); o.rs = 1.0f;
 #pragma unroll 1
-        for (int it = 0; it < 16; ++it) {
+        for (int it = 0; it < NIT; ++it) {
             const int gm = gm_first + it * row_step;
             if (gm >= p.M) break;
             epi_row_apply(p, o, *reinterpret_cast<const float4*>(ct + (row_first + it * row_step) * ct_ld + c4), b4, gm, gn);
         }
     } else {
-        EpiRow o[16];
+        EpiRow o[NIT];
 #pragma unroll
-        for (int it = 0; it < 16; ++it) o[it] = epi_row_fetch(p, gm_first + it * row_step, gn, true);
+        for (int it = 0; it < NIT; ++it) o[it] = epi_row_fetch(p, gm_first + it * row_step, gn, true);
 #pragma unroll
-        for (int it = 0; it < 16; ++it) {
+        for (int it = 0; it < NIT; ++it) {
             const int gm = gm_first + it * row_step;
             if (gm < p.M) epi_row_apply(p, o[it], *reinterpret_cast<const float4*>(ct + (row_first + it * row_step) * ct_ld + c4), b4, gm, gn);
         }
@@ -452,7 +453,8 @@ int tcow_gemm_nt_bf16(hipStream_t stream, const tcow_gemm_args* a) {
         return TCOW_OK;
     }
     static const int variant = [] { const char* e = getenv("TCOW_GEMM_NT"); return e ? atoi(e) : 3; }();   // 3 = two-stage BK=64 (default), 2 = 4-deep BK=32 ring (A/B; slower, profiles/r01_gemm_variants.txt). A register-direct
-    // epilogue with the swapped MFMA orientation was also tried and dropped (5-10 % slower: its 8-byte stores land 32 rows apart).
+    // epilogue with the swapped MFMA orientation (5-10 % slower: its 8-byte stores land 32 rows apart) and a BK=32 two-stage variant
+    // with 4 workgroups per CU (10-30 % slower: 64-byte rows, twice the barriers) were also tried and dropped.
     if (variant == 2) {
         static bool attr2 = false;
         if (!attr2) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_ring_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES); attr2 = true; }
@@ -475,10 +477,7 @@ int tcow_gemm_nt_bf16(hipStream_t stream, const tcow_gemm_args* a) {
 namespace {
 
 constexpr int TN_T = 128;                 // output tile edge (n and k)
-constexpr int TN_MC = 64;                 // token rows per LDS stage
-constexpr int TN_TILE_BYTES = TN_MC * 256;
-constexpr int TN_STAGE_BYTES = 2 * TN_TILE_BYTES;
-constexpr int TN_LDS_BYTES = 2 * TN_STAGE_BYTES;
+// token rows per LDS stage: template parameter MC (64: 64 KiB of LDS, 2 workgroups/CU; 32: 32 KiB, 4 workgroups/CU)
 
 __device__ uint4 g_zero16 = {0u, 0u, 0u, 0u};
 
@@ -500,7 +499,9 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int off0) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
-__global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(TnParams p) {
+template <int MC>
+__global__ __launch_bounds__(256, MC == 32 ? 4 : 2) void gemm_tn_bf16_kernel(TnParams p) {
+    constexpr int TILE_BYTES_ = MC * 256, STAGE_BYTES_ = 2 * TILE_BYTES_;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -533,11 +534,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(TnParams p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     auto issue = [&](int mt, int stage) {
-        char* sy = smem + stage * TN_STAGE_BYTES;
-        char* sx = sy + TN_TILE_BYTES;
+        char* sy = smem + stage * STAGE_BYTES_;
+        char* sx = sy + TILE_BYTES_;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int q = wave * 4 + j;
+        for (int j = 0; j < MC / 16; ++j) {
+            const int q = wave * (MC / 16) + j;
             const int gm = mt + q * 4 + lrow;
             const bool ok = gm < mend;
             const bf16_t* ys = (ok && n_ok) ? p.dY + (size_t)gm * p.ldy + ncol : zero;
@@ -561,12 +562,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(TnParams p) {
 
     // column-sum duty of this thread: column cs_col of the dY tile, LDS rows [cs_r0, cs_r1) of every stage
     const int cs_col = tid & 127;
-    const int cs_lo = pk * p.rows_per_pk, cs_hi = (cs_lo + p.rows_per_pk < TN_MC) ? cs_lo + p.rows_per_pk : TN_MC;
+    const int cs_lo = pk * p.rows_per_pk, cs_hi = (cs_lo + p.rows_per_pk < MC) ? cs_lo + p.rows_per_pk : MC;
     const int cs_mid = cs_lo + (cs_hi - cs_lo + 1) / 2;
     const int cs_r0 = (tid >> 7) ? cs_mid : cs_lo, cs_r1 = (tid >> 7) ? cs_hi : (cs_mid < cs_hi ? cs_mid : cs_hi);
     float colsum = 0.f;
 
-    const int nmt = (mend - mbeg + TN_MC - 1) / TN_MC;
+    const int nmt = (mend - mbeg + MC - 1) / MC;
     if (nmt > 0) {
         issue(mbeg, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -574,11 +575,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(TnParams p) {
     }
     for (int it = 0; it < nmt; ++it) {
         const int stage = it & 1;
-        if (it + 1 < nmt) issue(mbeg + (it + 1) * TN_MC, stage ^ 1);
-        const char* sy = smem + stage * TN_STAGE_BYTES;
-        const char* sx = sy + TN_TILE_BYTES;
+        if (it + 1 < nmt) issue(mbeg + (it + 1) * MC, stage ^ 1);
+        const char* sy = smem + stage * STAGE_BYTES_;
+        const char* sx = sy + TILE_BYTES_;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        for (int ks = 0; ks < MC / 16; ++ks) {
             bf16x8 fy[2], fx[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -630,20 +631,23 @@ int tcow_gemm_tn_bf16(hipStream_t stream, int M, int N, int K, const bf16_t* dY,
     TnParams p;
     p.M = M; p.N = N; p.K = K; p.dY = dY; p.ldy = ldy; p.X = X; p.ldx = ldx; p.slab = slab;
     p.tiles_n = cdiv(N, TN_T); p.tiles_k = cdiv(K, TN_T);
-    int mps = cdiv(M, splits); mps = ((mps + TN_MC - 1) / TN_MC) * TN_MC;
+    static const int mc = [] { const char* e = getenv("TCOW_GEMM_TN_MC"); return (e && atoi(e) == 64) ? 64 : 32; }();   // 32 (4 workgroups/CU) measured 5-25 % faster than 64 (profiles/r01_gemm_tn_ab.txt)
+    int mps = cdiv(M, splits); mps = ((mps + 63) / 64) * 64;
     p.mps = mps;
     const int nz = cdiv(M, mps);
     p.nz = nz;
     *nz_out = nz;
     p.bias_part = bias_part;
-    p.rows_per_pk = cdiv(TN_MC, p.tiles_k);
+    p.rows_per_pk = cdiv(mc, p.tiles_k);
     if (bias_parts_out) *bias_parts_out = nz * p.tiles_k * 2;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_bf16_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
         attr_set = true;
     }
-    hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3(8 * cdiv(nz, 8) * p.tiles_n * p.tiles_k), dim3(256), TN_LDS_BYTES, stream, p);
+    const dim3 grid(8 * cdiv(nz, 8) * p.tiles_n * p.tiles_k);
+    if (mc == 32) hipLaunchKernelGGL(gemm_tn_bf16_kernel<32>, grid, dim3(256), 32768, stream, p);
+    else hipLaunchKernelGGL(gemm_tn_bf16_kernel<64>, grid, dim3(256), 65536, stream, p);
     TCOW_CHECK_LAUNCH();
     return TCOW_OK;
 }
