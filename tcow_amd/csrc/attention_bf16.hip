@@ -283,27 +283,33 @@ __device__ __forceinline__ void dkv_tile(const SeqDesc& sd, const char* qtile, c
         }
     }
     const bf16x8 pa0 = pack8(pv), pa1 = pack8(pv + 8), da0 = pack8(dsv), da1 = pack8(dsv + 8);
-    dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa0, frag_tr(dotile, 0, 0, lane), dv0, 0, 0, 0);
-    dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa1, frag_tr(dotile, 1, 0, lane), dv0, 0, 0, 0);
-    dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa0, frag_tr(dotile, 0, 1, lane), dv1, 0, 0, 0);
-    dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa1, frag_tr(dotile, 1, 1, lane), dv1, 0, 0, 0);
-    dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da0, frag_tr(qtile, 0, 0, lane), dk0, 0, 0, 0);
-    dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da1, frag_tr(qtile, 1, 0, lane), dk0, 0, 0, 0);
-    dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da0, frag_tr(qtile, 0, 1, lane), dk1, 0, 0, 0);
-    dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da1, frag_tr(qtile, 1, 1, lane), dk1, 0, 0, 0);
+    dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(dotile, 0, 0, lane), pa0, dv0, 0, 0, 0);
+    dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(dotile, 1, 0, lane), pa1, dv0, 0, 0, 0);
+    dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(dotile, 0, 1, lane), pa0, dv1, 0, 0, 0);
+    dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(dotile, 1, 1, lane), pa1, dv1, 0, 0, 0);
+    dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(qtile, 0, 0, lane), da0, dk0, 0, 0, 0);
+    dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(qtile, 1, 0, lane), da1, dk0, 0, 0, 0);
+    dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(qtile, 0, 1, lane), da0, dk1, 0, 0, 0);
+    dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(qtile, 1, 1, lane), da1, dk1, 0, 0, 0);
 }
 
-// C layout: lane (col = d = l31 (+32), hi), register r -> key row 32*j + crow32(r, hi)
+// The gradient MFMAs are issued as (transposed-read fragment, P or dS), i.e. they accumulate dV^T / dK^T / dQ^T: lane (l31, hi)
+// owns ONE token row and per 32-wide d tile the channels d = 8*(r>>2) + 4*hi + (r&3) -- groups of 4 consecutive channels, each
+// an 8-byte store (instead of 64 two-byte stores per lane with the untransposed layout).
+__device__ __forceinline__ void store_rowT(bf16_t* drow, int hi, const f32x16& a0, const f32x16& a1) {
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+        st4(drow + 8 * gq + 4 * hi, make_float4(a0[4 * gq], a0[4 * gq + 1], a0[4 * gq + 2], a0[4 * gq + 3]));
+        st4(drow + 32 + 8 * gq + 4 * hi, make_float4(a1[4 * gq], a1[4 * gq + 1], a1[4 * gq + 2], a1[4 * gq + 3]));
+    }
+}
 __device__ __forceinline__ void dkv_store(const SeqDesc& sd, long base, long ld3, int head, int j, int l31, int hi, const f32x16& dk0, const f32x16& dk1,
                                           const f32x16& dv0, const f32x16& dv1, bf16_t* __restrict__ dqkv) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int kr = 32 * j + crow32(r, hi);
-        if (kr < sd.L) {
-            bf16_t* drow = dqkv + (base + (long)kr * sd.pos_stride) * ld3 + head * ATT_HD;
-            drow[sd.D + l31] = f2bf(dk0[r]); drow[sd.D + 32 + l31] = f2bf(dk1[r]);
-            drow[2 * sd.D + l31] = f2bf(dv0[r]); drow[2 * sd.D + 32 + l31] = f2bf(dv1[r]);
-        }
+    const int kr = 32 * j + l31;
+    if (kr < sd.L) {
+        bf16_t* drow = dqkv + (base + (long)kr * sd.pos_stride) * ld3 + head * ATT_HD;
+        store_rowT(drow + sd.D, hi, dk0, dk1);
+        store_rowT(drow + 2 * sd.D, hi, dv0, dv1);
     }
 }
 
@@ -327,22 +333,16 @@ __device__ __forceinline__ void dq_tile(const SeqDesc& sd, const char* ktile, co
         dsv[r] = p * (dp[r] - dl) * kScale;
     }
     const bf16x8 da0 = pack8(dsv), da1 = pack8(dsv + 8);
-    dq0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da0, frag_tr(ktile, 0, 0, lane), dq0, 0, 0, 0);
-    dq0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da1, frag_tr(ktile, 1, 0, lane), dq0, 0, 0, 0);
-    dq1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da0, frag_tr(ktile, 0, 1, lane), dq1, 0, 0, 0);
-    dq1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da1, frag_tr(ktile, 1, 1, lane), dq1, 0, 0, 0);
+    dq0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(ktile, 0, 0, lane), da0, dq0, 0, 0, 0);
+    dq0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(ktile, 1, 0, lane), da1, dq0, 0, 0, 0);
+    dq1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(ktile, 0, 1, lane), da0, dq1, 0, 0, 0);
+    dq1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(ktile, 1, 1, lane), da1, dq1, 0, 0, 0);
 }
 
 __device__ __forceinline__ void dq_store(const SeqDesc& sd, long base, long ld3, int head, int qt, int l31, int hi, const f32x16& dq0, const f32x16& dq1,
                                          bf16_t* __restrict__ dqkv) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int qr = 32 * qt + crow32(r, hi);
-        if (qr < sd.L) {
-            bf16_t* drow = dqkv + (base + (long)qr * sd.pos_stride) * ld3 + head * ATT_HD;
-            drow[l31] = f2bf(dq0[r]); drow[32 + l31] = f2bf(dq1[r]);
-        }
-    }
+    const int qr = 32 * qt + l31;
+    if (qr < sd.L) store_rowT(dqkv + (base + (long)qr * sd.pos_stride) * ld3 + head * ATT_HD, hi, dq0, dq1);
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
