@@ -113,10 +113,10 @@ def main():
     net = net.to(dev).train()
     ddp.broadcast_parameters(net)
     params = [p for p in net.parameters()]
-    try:
-        opt = torch.optim.AdamW(params, lr=1e-4, fused=True)               # train.py:239-241, args.py:108
-    except Exception:
-        opt = torch.optim.AdamW(params, lr=1e-4, foreach=True)
+    from tcow_amd.optim import FusedAdamWClip
+    opt = FusedAdamWClip(params, lr=1e-4, max_norm=0.3)                    # train.py:99-102,239-241: clip_grad_norm_(0.3) + AdamW(lr 1e-4), fused
+    opt.on_step.append(net.seeker.invalidate_weight_cache)
+    net.seeker.persistent_grads = True                                     # one backward per step: gradients live in persistent flat buckets
     sync = ddp.GradSync(world)
     net.seeker.grad_hook = sync
 
@@ -132,13 +132,11 @@ def main():
     state = {'step': 0}
 
     def step():
-        opt.zero_grad(set_to_none=True)
-        model_retval = pipe.forward_kubric(data)                           # query sampling, query/target masks, ONE batched Seeker call (pipeline.py:85-200)
+        model_retval = pipe.forward_kubric(data)                            # (no zero_grad: persistent gradient buckets are overwritten)                           # query sampling, query/target masks, ONE batched Seeker call (pipeline.py:85-200)
         progress = state['step'] / 1000.0
         loss = pipe.step_losses(data, model_retval, progress)['total_seeker']   # loss.py:238-421: weighted BCE + bootstrapped BCE + soft Jaccard
         loss.backward()                                                    # train.py:98 (bucketed RCCL all-reduce runs inside, overlapped)
-        torch.nn.utils.clip_grad_norm_(params, 0.3)                        # train.py:99-101
-        opt.step()
+        opt.step()                                                         # grad-clip 0.3 + AdamW in three launches
         state['step'] += 1
         return loss
 

@@ -175,6 +175,15 @@ int tcow_scale_cast(void* stream, int dtype, long rows, int D, const float* src,
                     void* dst, long ld_dst);
 int tcow_cast_transpose(void* stream, int dtype, int N, int K, const float* W, void* Wc, void* Wt);
 
+/* ------------------------------------------------------------------------------------------- optimizer step
+ * clip_grad_norm_(params, max_norm) followed by AdamW.step() (train.py:99-102; torch defaults) in three
+ * launches over a device-resident chunk table: records {float* p; const float* g; float* m; float* v; long n} of
+ * tcow_adamw_chunk_bytes() bytes each, n <= 65536.  scratch: f32 [n_chunks + 2]; afterwards scratch[n_chunks] is the clip
+ * coefficient and scratch[n_chunks + 1] the total gradient norm.  max_norm <= 0 disables clipping.  step counts from 1. */
+long tcow_adamw_chunk_bytes(void);
+int tcow_adamw_clip_step(void* stream, const void* chunks, int n_chunks, float lr, float beta1, float beta2, float eps,
+                         float weight_decay, int step, float max_norm, float* scratch);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,86 @@
+// Fused gradient clipping + AdamW over all parameters of the Seeker in three launches (train.py:99-102:
+// clip_grad_norm_(seeker.parameters(), 0.3) then AdamW.step(); torch defaults betas (0.9, 0.999), eps 1e-8, weight_decay 0.01 on
+// every parameter).  The reference's foreach implementation walks ~250 tensors from Python / ATen per step;
+// here a device-resident chunk table (<= 65536 elements per chunk) lets one grid cover every tensor.
+//   1. sumsq_kernel   : per-chunk sum of squares of the gradient
+//   2. clipcoef_kernel: total norm -> clip coefficient min(1, max_norm / (norm + 1e-6))   (torch.nn.utils.clip_grad_norm_)
+//   3. adamw_kernel   : p, m, v update with the clipped gradient (decoupled weight decay, bias correction as torch.optim.AdamW)
+#include "common.h"
+
+namespace {
+
+struct Chunk { float* p; const float* g; float* m; float* v; long n; };
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const Chunk* __restrict__ chunks, float* __restrict__ partial) {
+    __shared__ float red[4];
+    const Chunk c = chunks[blockIdx.x];
+    float s = 0.f;
+    const long n4 = c.n >> 2;
+    for (long i = threadIdx.x; i < n4; i += 256) { const float4 g = ld4(c.g + i * 4); s += g.x * g.x + g.y * g.y + g.z * g.z + g.w * g.w; }
+    for (long i = (n4 << 2) + threadIdx.x; i < c.n; i += 256) s += c.g[i] * c.g[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void clipcoef_kernel(const float* __restrict__ partial, int n, float max_norm, float* __restrict__ out /* [0]=coef, [1]=norm */) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float norm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+        float coef = max_norm > 0.f ? max_norm / (norm + 1e-6f) : 1.0f;
+        out[0] = coef < 1.0f ? coef : 1.0f;
+        out[1] = norm;
+    }
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(const Chunk* __restrict__ chunks, const float* __restrict__ coef_ptr, float lr, float beta1, float beta2, float eps,
+                                                    float weight_decay, float bc1, float bc2_sqrt) {
+    const Chunk c = chunks[blockIdx.x];
+    const float coef = coef_ptr[0];
+    const float decay = 1.0f - lr * weight_decay, step_size = lr / bc1;
+    const long n4 = c.n >> 2;
+    auto upd = [&](float& p, float g, float& m, float& v) {
+        g *= coef;
+        p *= decay;
+        m = beta1 * m + (1.0f - beta1) * g;
+        v = beta2 * v + (1.0f - beta2) * g * g;
+        p -= step_size * m / (sqrtf(v) / bc2_sqrt + eps);
+    };
+    for (long i = threadIdx.x; i < n4; i += 256) {
+        float4 p = ld4(c.p + i * 4), m = ld4(c.m + i * 4), v = ld4(c.v + i * 4);
+        const float4 g = ld4(c.g + i * 4);
+        upd(p.x, g.x, m.x, v.x); upd(p.y, g.y, m.y, v.y); upd(p.z, g.z, m.z, v.z); upd(p.w, g.w, m.w, v.w);
+        st4(c.p + i * 4, p); st4(c.m + i * 4, m); st4(c.v + i * 4, v);
+    }
+    for (long i = (n4 << 2) + threadIdx.x; i < c.n; i += 256) upd(c.p[i], c.g[i], c.m[i], c.v[i]);
+}
+
+}  // namespace
+
+extern "C" {
+
+long tcow_adamw_chunk_bytes(void) { return (long)sizeof(Chunk); }
+
+// chunks: device array of n_chunks {p, g, m, v, n} records (all f32, 16-byte aligned starts); scratch: f32 [n_chunks + 2];
+// on return scratch[n_chunks] = clip coefficient, scratch[n_chunks + 1] = total gradient norm (device side, no sync).
+int tcow_adamw_clip_step(void* stream, const void* chunks, int n_chunks, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                         float max_norm, float* scratch) {
+    TCOW_CHECK_ARG(chunks && scratch && n_chunks > 0 && step >= 1, "tcow_adamw_clip_step: bad arguments");
+    const Chunk* c = (const Chunk*)chunks;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, c, scratch);
+    TCOW_CHECK_LAUNCH();
+    hipLaunchKernelGGL(clipcoef_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, scratch, n_chunks, max_norm, scratch + n_chunks);
+    TCOW_CHECK_LAUNCH();
+    const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adamw_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, c, scratch + n_chunks, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2));
+    TCOW_CHECK_LAUNCH();
+    return TCOW_OK;
+}
+
+}  // extern "C"

@@ -31,7 +31,8 @@ def _get_weight(module, p, train):
     mode = module.mode
     key = id(p)
     ent = module._wcache.get(key)
-    if ent is not None and ent[0] == p._version and ent[1] == mode and (ent[3] is not None or not train):
+    ver = (p._version, getattr(module, '_wepoch', 0))
+    if ent is not None and ent[0] == ver and ent[1] == mode and (ent[3] is not None or not train):
         return ent[2], ent[3]
     w = _w2d(p.detach())
     N, K = w.shape
@@ -46,7 +47,7 @@ def _get_weight(module, p, train):
         if train:
             Wt = torch.empty(K, N, dtype=dt, device=w.device)
             ops.cast_transpose(mode, Wc, None, Wt)
-    module._wcache[key] = (p._version, mode, Wc, Wt)
+    module._wcache[key] = (ver, mode, Wc, Wt)
     return Wc, Wt
 
 
@@ -256,8 +257,16 @@ def run_backward(module, sv, params, d_mask, d_flags):
     def bucket(indices):
         """One flat f32 buffer per gradient bucket (a transformer block, the heads, the embeddings): the views
         become the parameters' gradients and the flat buffer is what the data-parallel all-reduce moves."""
+        indices = list(indices)
         total = sum(params[j].numel() for j in indices)
-        flat = torch.empty(total, dtype=f32, device=dev)
+        flat = None
+        if getattr(module, 'persistent_grads', False):      # stable gradient storage across steps (see QueryMaskTracker.persistent_grads)
+            key = ('gbuf', indices[0], total, str(dev))
+            flat = module._gbufs.get(key)
+            if flat is None:
+                flat = module._gbufs[key] = torch.empty(total, dtype=f32, device=dev)
+        if flat is None:
+            flat = torch.empty(total, dtype=f32, device=dev)
         off = 0
         for j in indices:
             n = params[j].numel()
@@ -413,6 +422,15 @@ class SeekerFunction(torch.autograd.Function):
         grads = run_backward(ctx.module, ctx.sv, ctx.params, d_mask, d_flags)
         ctx.sv = None
         out = []
+        persistent = getattr(ctx.module, 'persistent_grads', False)
         for p, gr, need in zip(ctx.params, grads, ctx.needs_input_grad[3:]):
-            out.append(gr.reshape(p.shape) if (need and gr is not None) else None)
+            if not need or gr is None:
+                out.append(None)
+                continue
+            gr = gr.reshape(p.shape)
+            if persistent and (p.grad is None or p.grad.data_ptr() == gr.data_ptr()):
+                p.grad = gr          # delivered out of band: the same storage every step, no autograd copy
+                out.append(None)
+            else:
+                out.append(gr)
         return (None, None, None, *out)

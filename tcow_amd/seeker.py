@@ -185,6 +185,11 @@ class QueryMaskTracker(nn.Module):
             from .checkpoint import load_pretrained_vit
             load_pretrained_vit(self, self.pretrained_path, logger)
         self._wcache = {}
+        self._gbufs = {}
+        # persistent_grads=True: the backward writes parameter gradients into flat per-bucket buffers that live across steps and
+        # hands them to p.grad directly (same pointers every step: no autograd copies, the fused optimizer's pointer table stays
+        # valid).  Gradients are then OVERWRITTEN, not accumulated, by each backward -- use only with one backward per step.
+        self.persistent_grads = False
         self.forced_drop_masks = None     # tests can inject explicit DropPath keep masks
         self.grad_hook = None             # optional callable(bucket_name, tensors) fired during backward (DDP)
 
@@ -197,8 +202,14 @@ class QueryMaskTracker(nn.Module):
         self._wcache = {}
         return self
 
+    def invalidate_weight_cache(self):
+        """Call after updating parameters through raw pointers (tcow_amd.optim.FusedAdamWClip does): in-place torch ops bump the
+        parameters' autograd version counters, which the operand cache checks on its own."""
+        self._wepoch = getattr(self, '_wepoch', 0) + 1
+
     def _apply(self, fn, *a, **k):
         self._wcache = {}
+        self._gbufs = {}
         return super()._apply(fn, *a, **k)
 
     @property

@@ -153,3 +153,46 @@ def test_errors_surface_as_exceptions(cuda):
         net(torch.zeros(1, 3, 4, 32, 32), torch.zeros(1, 1, 4, 32, 32))                                  # CPU tensors: no fallback
     out, fl = net(torch.zeros(1, 3, 4, 32, 32, device=cuda, dtype=torch.float16), torch.zeros(1, 1, 4, 32, 32, device=cuda, dtype=torch.uint8))
     assert out.dtype == torch.float32 and tuple(out.shape) == (1, 3, 4, 32, 32) and tuple(fl.shape) == (1, 4, 3)   # any input dtype is cast (mask_tracker.py:103-104)
+
+
+def test_fused_adamw_clip_matches_torch(cuda):
+    """tcow_adamw_clip_step == torch.nn.utils.clip_grad_norm_(0.3) + torch.optim.AdamW (train.py:99-102), incl. params without grad."""
+    from tcow_amd.optim import FusedAdamWClip
+    g = torch.Generator(device='cuda').manual_seed(0)
+    shapes = [(768, 768), (3, 5), (70001,), (1, 1, 768), (2304,)]
+    pa = [torch.nn.Parameter(torch.randn(s, device=cuda, generator=g)) for s in shapes] + [torch.nn.Parameter(torch.zeros(7, device=cuda))]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    ref = torch.optim.AdamW(pb, lr=1e-3)
+    opt = FusedAdamWClip(pa, lr=1e-3, max_norm=0.3)
+    for it in range(3):
+        for a, b in zip(pa[:-1], pb[:-1]):                      # the last parameter never gets a gradient
+            gr = torch.randn(a.shape, device=cuda, generator=g) * (10.0 if it == 0 else 0.001)   # clipped on step 0, not afterwards
+            a.grad = gr.clone(); b.grad = gr.clone()
+        n_ref = torch.nn.utils.clip_grad_norm_(pb, 0.3)
+        ref.step(); opt.step()
+        assert abs(float(opt.grad_norm()) - float(n_ref)) <= 1e-4 * float(n_ref)
+        for a, b in zip(pa, pb):
+            assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(b.abs().max()))
+
+
+def test_persistent_gradient_buckets(cuda):
+    """persistent_grads=True: same gradient values, delivered in storage that is stable across steps (no autograd copy)."""
+    cfg = synth.seeker_config(num_total_frames=4, frame_height=32, frame_width=32, embed_dim=128, depth=2, num_heads=2, causal_attention=1)
+    sd = synth.make_state_dict(cfg, 5)
+    clip = synth.make_clip(1, 4, 32, 32, seed=2)
+    rgb = torch.from_numpy(clip['rgb']).cuda(); qm = torch.from_numpy(synth.make_query_mask(clip, 0, 0)).cuda()
+    grads = {}
+    for persistent in (False, True):
+        net = build_hip_seeker(cfg, sd, 'bf16').cuda().train()
+        net.seeker.persistent_grads = persistent
+        ptrs = []
+        for _ in range(2):
+            for p in net.parameters():
+                p.grad = None
+            om, fl = net(rgb, qm)
+            (om.square().mean() + fl.square().mean()).backward()
+            ptrs.append([p.grad.data_ptr() for p in net.parameters() if p.grad is not None])
+        grads[persistent] = [p.grad.clone() for p in net.parameters() if p.grad is not None]
+        if persistent:
+            assert ptrs[0] == ptrs[1]
+    assert all(torch.equal(a, b) for a, b in zip(grads[False], grads[True]))
