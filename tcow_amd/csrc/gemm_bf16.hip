@@ -454,7 +454,8 @@ int tcow_gemm_nt_bf16(hipStream_t stream, const tcow_gemm_args* a) {
     }
     static const int variant = [] { const char* e = getenv("TCOW_GEMM_NT"); return e ? atoi(e) : 3; }();   // 3 = two-stage BK=64 (default), 2 = 4-deep BK=32 ring (A/B; slower, profiles/r01_gemm_variants.txt). A register-direct
     // epilogue with the swapped MFMA orientation (5-10 % slower: its 8-byte stores land 32 rows apart) and a BK=32 two-stage variant
-    // with 4 workgroups per CU (10-30 % slower: 64-byte rows, twice the barriers) were also tried and dropped.
+    // with 4 workgroups per CU (10-30 % slower: 64-byte rows, twice the barriers) and a single-stage BK=64 variant with 4 workgroups per CU
+    // (+-5 %: latency hiding is not the limit, L2->LDS bytes per FLOP are) were also tried and dropped.
     if (variant == 2) {
         static bool attr2 = false;
         if (!attr2) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_ring_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES); attr2 = true; }
