@@ -72,3 +72,19 @@ def test_pretrained_surgery_rules():
     assert torch.equal(out['pos_embed'][0, 1:], sd['pos_embed'][0, src])
     assert torch.equal(out['blocks.0.temporal_attn.qkv.weight'], sd['blocks.0.attn.qkv.weight'])
     assert torch.equal(out['blocks.0.temporal_norm1.weight'], sd['blocks.0.norm1.weight'])
+
+
+def test_reference_checkpoint_round_trip(tmp_path):
+    """A checkpoint written the way train.py:269-304 writes it loads through eval/inference.py:38-54's recipe."""
+    from tcow_amd.checkpoint import load_tcow_checkpoint
+    args = dict(num_total_frames=4, num_visible_frames=4, frame_height=32, frame_width=48, tracker_pretrained='1', attention_type='divided_space_time',
+                patch_size=16, causal_attention=1, norm_embeddings=False, drop_path_rate=0.1, network_depth=12, track_map_stride=4,
+                track_map_resize='bilinear', query_channels=1, output_channels=3, flag_channels=3)
+    cfg = synth.seeker_config(num_total_frames=4, frame_height=32, frame_width=48, causal_attention=1)
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg, 3).items()}
+    path = tmp_path / 'checkpoint.pth'
+    torch.save({'epoch': 7, 'train_args': None, 'dset_args': {}, 'seeker_args': args, 'net_seeker': sd, 'optim_seeker': {}, 'lr_sched_seeker': {}}, path)
+    net = load_tcow_checkpoint(str(path), device='cpu')
+    got = net.state_dict()
+    assert list(got.keys()) == list(sd.keys()) and all(torch.equal(got[k], sd[k]) for k in sd)
+    assert net.seeker.causal_attention == 1 and net.seeker.tracker_pretrained is False
