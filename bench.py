@@ -124,7 +124,8 @@ def main():
     from tcow_amd.pipeline import SeekerPipeline
     from tcow_amd.tcow_loss import default_args
     Qs = args.queries
-    data = synth.to_torch_tree(synth.make_kubric_batch(1, args.frames, args.height, args.width, seed=ddp.shard_seed(900, rank), n_objects=5), dev)
+    data = synth.to_torch_tree(synth.make_kubric_batch(1, args.frames, args.height, args.width, seed=ddp.shard_seed(900, rank), n_objects=5), dev,
+                               host_keys=synth.HOST_KEYS)   # control-flow metadata stays on the host, as in the reference's DataLoader batch
     pipe = SeekerPipeline(net, num_queries=Qs, train_args=default_args(), phase='train', device=dev,
                           rng=__import__('numpy').random.default_rng(ddp.shard_seed(900, rank)))
 

@@ -184,6 +184,36 @@ long tcow_adamw_chunk_bytes(void);
 int tcow_adamw_clip_step(void* stream, const void* chunks, int n_chunks, float lr, float beta1, float beta2, float eps,
                          float weight_decay, int step, float max_norm, float* scratch);
 
+/* ------------------------------------------------------------------------------------------- mask objective (caller row L)
+ * One channel of the TCOW mask loss, forward value and d(loss)/d(logits) together (loss.py:164-225, with
+ * bootstrap_warmup_loss loss.py:13-17 and tversky_loss loss.py:20-32):
+ *   loss = [aot_loss * (boot + jac) / 2 + (1 - aot_loss) * mean(w * bce)] * sqrt(n_selected / n)
+ * over the frames that carry any non-zero weight; 0 when none does or mean(w) < 1e-4.  weighted_aot is the reference's
+ * apply_weights_for_aot (true for the occlusion / containment channels: boot over w * bce and jac := boot).
+ * Pixel (f, i) of frame f (0 <= f < n_frames, 0 <= i < frame_len) lives at
+ *   base + (f / frames_per_seq) * seq_stride + (f % frames_per_seq) * frame_len + i      (elements),
+ * which addresses one channel of a (B*Q, 3, T, H, W) tensor in place.  weight = pixel_w[f * frame_len + i] * frame_w[f]
+ * (either pointer may be NULL = 1).  dlogits (may be NULL) receives loss_weight * d(loss)/d(logits), same addressing;
+ * *loss receives the channel loss, *total (may be NULL) is incremented by loss_weight * loss.  Every decision the
+ * reference takes on the host is taken on the device: the call never synchronises. */
+typedef struct {
+    long n_frames, frame_len, frames_per_seq;
+    const float* logits;  long logits_seq_stride;
+    const float* target;  long target_seq_stride;
+    const float* pixel_w;
+    const float* frame_w;
+    int weighted_aot;
+    float aot_loss;                 /* args.aot_loss (args.py:196) */
+    double topk_frac;               /* loss.py:200: min(max(1 - progress * 8.5, 0.15), 1) */
+    float loss_weight;
+    float* loss;
+    float* total;
+    float* dlogits;  long dlogits_seq_stride;
+    void* ws;  size_t ws_bytes;
+} tcow_mask_loss_args;
+size_t tcow_mask_loss_workspace_bytes(long n_frames, long frame_len);
+int tcow_mask_loss(void* stream, const tcow_mask_loss_args* args);
+
 #ifdef __cplusplus
 }
 #endif

@@ -30,6 +30,17 @@ class GemmArgs(ctypes.Structure):
                 ('ldr', ctypes.c_long), ('act', ctypes.c_int), ('aux', ctypes.c_void_p), ('ldaux', ctypes.c_long)]
 
 
+class MaskLossArgs(ctypes.Structure):
+    _fields_ = [('n_frames', ctypes.c_long), ('frame_len', ctypes.c_long), ('frames_per_seq', ctypes.c_long),
+                ('logits', ctypes.c_void_p), ('logits_seq_stride', ctypes.c_long),
+                ('target', ctypes.c_void_p), ('target_seq_stride', ctypes.c_long),
+                ('pixel_w', ctypes.c_void_p), ('frame_w', ctypes.c_void_p),
+                ('weighted_aot', ctypes.c_int), ('aot_loss', ctypes.c_float), ('topk_frac', ctypes.c_double),
+                ('loss_weight', ctypes.c_float), ('loss', ctypes.c_void_p), ('total', ctypes.c_void_p),
+                ('dlogits', ctypes.c_void_p), ('dlogits_seq_stride', ctypes.c_long),
+                ('ws', ctypes.c_void_p), ('ws_bytes', ctypes.c_size_t)]
+
+
 _lib = None
 
 _vp, _i, _l, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
@@ -65,6 +76,8 @@ SIGNATURES = {
     'tcow_cast_transpose': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     'tcow_adamw_chunk_bytes': (_l, []),
     'tcow_adamw_clip_step': (_i, [_vp, _vp, _i, _f, _f, _f, _f, _f, _i, _f, _vp]),
+    'tcow_mask_loss_workspace_bytes': (ctypes.c_size_t, [_l, _l]),
+    'tcow_mask_loss': (_i, [_vp, ctypes.POINTER(MaskLossArgs)]),
 }
 
 

@@ -20,10 +20,10 @@ def calculate_metrics_mask_track(output_mask, target_mask, plugin=False):
     has = t_area > 0
     sn = has[:, :, 0]
 
-    def agg(sel, values):
-        n = int(sel.sum())
-        mean = float(values[sel].mean()) if n > 0 else -1.0
-        return mean, n
+    def agg(sel, values):                  # masked mean as tensor ops: no host round trip (the reference loops on the host)
+        n = sel.sum()
+        mean = torch.where(n > 0, (values * sel).sum() / n.clamp(min=1), torch.full_like(n, -1.0, dtype=torch.float64))
+        return mean.to(torch.float32), n.to(torch.int32)
 
     res = {}
     res['snitch_iou'] = agg(sn, iou[:, :, 0])
@@ -35,6 +35,6 @@ def calculate_metrics_mask_track(output_mask, target_mask, plugin=False):
     dev = output_mask.device
     out = {}
     for k, (m, n) in res.items():
-        out['mean_' + k] = torch.tensor(m, dtype=torch.float32, device=dev)
-        out['count_' + k] = torch.tensor(n, dtype=torch.int32, device=dev)
+        out['mean_' + k] = m if torch.is_tensor(m) else torch.tensor(m, dtype=torch.float32, device=dev)
+        out['count_' + k] = n if torch.is_tensor(n) else torch.tensor(n, dtype=torch.int32, device=dev)
     return out

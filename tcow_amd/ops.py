@@ -160,3 +160,29 @@ def scale_cast(mode, src, row_scale, dst):
 def cast_transpose(mode, W, Wc=None, Wt=None):
     N, K = W.shape
     L.check(L.lib().tcow_cast_transpose(_stream(), mode, N, K, W.data_ptr(), _p(Wc), _p(Wt)), 'tcow_cast_transpose')
+
+
+def mask_loss(logits, target, channel, pixel_w=None, frame_w=None, weighted_aot=False, aot_loss=0.8, topk_frac=1.0,
+              loss_weight=1.0, loss_out=None, total=None, dlogits=None):
+    """Channel `channel` of the TCOW mask objective on (BQ, C, T, H, W) f32 logits / targets (see tcow_mask_loss):
+    writes loss_out[0], adds loss_weight * loss to total[0] and d(loss)/d(logits) into dlogits[:, channel]."""
+    _need_cuda(logits, target, pixel_w, frame_w, loss_out, total, dlogits)
+    BQ, C, T, H, W = logits.shape
+    for t in (logits, target, dlogits):
+        if t is not None and (t.dtype != torch.float32 or not t.is_contiguous() or t.shape != logits.shape):
+            raise L.TcowError('mask_loss: logits / target / dlogits must be contiguous f32 tensors of one shape')
+    n_frames, frame_len = BQ * T, H * W
+    if pixel_w is not None and (pixel_w.dtype != torch.float32 or not pixel_w.is_contiguous() or pixel_w.numel() != n_frames * frame_len):
+        raise L.TcowError('mask_loss: pixel_w must be a contiguous f32 tensor with one weight per pixel')
+    if frame_w is not None and (frame_w.dtype != torch.float32 or not frame_w.is_contiguous() or frame_w.numel() != n_frames):
+        raise L.TcowError('mask_loss: frame_w must be a contiguous f32 tensor with one weight per frame')
+    lib = L.lib()
+    nb = lib.tcow_mask_loss_workspace_bytes(n_frames, frame_len)
+    ws = workspace(nb, logits.device, 'mask_loss')
+    off = channel * T * frame_len * 4
+    a = L.MaskLossArgs(n_frames, frame_len, T, logits.data_ptr() + off, C * T * frame_len, target.data_ptr() + off, C * T * frame_len,
+                       _p(pixel_w), _p(frame_w), 1 if weighted_aot else 0, float(aot_loss), float(topk_frac), float(loss_weight),
+                       loss_out.data_ptr(), _p(total), (dlogits.data_ptr() + off) if dlogits is not None else None,
+                       C * T * frame_len, ws.data_ptr(), ws.numel())
+    L.check(lib.tcow_mask_loss(_stream(), ctypes.byref(a)), 'tcow_mask_loss')
+    return loss_out

@@ -9,6 +9,13 @@ import torch
 from .tcow_loss import TcowLosses, default_args
 
 
+def to_dev(t, dev):
+    """Host -> device without a stream drain: pageable copies block until the stream is empty, pinned ones do not."""
+    if t.is_cuda or torch.device(dev).type != 'cuda':
+        return t.to(dev)
+    return t.pin_memory().to(dev, non_blocking=True)
+
+
 def sample_query_inds(B, Qs, inst_count, desirability, phase, rng=None):
     """my_utils.py:265-305. Test phases: the Qs most desirable valid instances. Train phases: elitist shuffle
     (inequality 9) plus the occasional uniformly random last query, drawn from `rng` (numpy Generator)."""
@@ -38,7 +45,7 @@ def fill_kubric_query_target_mask_flags(segm, div_segm, query_idx, qt_idx, occl_
     target_mask f32 (B,3,T,H,W), target_flags f32 (B,T,3))."""
     B, _, T, H, W = segm.shape
     dev = segm.device
-    qi = query_idx.to(dev).long()
+    qi = to_dev(query_idx, dev).long()
     bidx = torch.arange(B, device=dev)
     seg = segm[:, 0]                                                       # (B,T,H,W)
     is_q = seg == (qi + 1).to(seg.dtype)[:, None, None, None]
@@ -98,23 +105,37 @@ class SeekerPipeline:
         qt = int(tr['query_time'][0].item())                               # pipeline.py:140: only [0] is used
         if sel_query_inds is None:
             sel_query_inds = sample_query_inds(B, Qs, kr['pv_inst_count'], des, self.phase, self.rng)
-        qms, ptrs, idss, tgts = [], [], [], []
+        qms, ptrs, idss, tgts, nonzero = [], [], [], [], []
         for q in range(Qs):                                                # cheap tensor ops; the model call below is batched
             qm, ptr, ids, tgt, _ = fill_kubric_query_target_mask_flags(segm, div, sel_query_inds[:, q], qt, occl_fracs, dag, self.args)
-            if not bool(qm.any()):
-                raise RuntimeError(f'seeker_query_mask all zero? q: {q} query_idx: {sel_query_inds[:, q]} qt_idx: {qt}')   # pipeline.py:149-151
-            if not bool(tgt.any()):
-                raise RuntimeError(f'target_mask all zero? q: {q}')        # pipeline.py:152-154
+            nonzero += [qm.any(), tgt.any()]
             qms.append(qm); ptrs.append(ptr); idss.append(ids); tgts.append(tgt)
+        # pipeline.py:149-154 raises on an all-zero query / target mask.  The flags travel to pinned host memory behind the
+        # mask kernels and are inspected after the model call has been queued: same error, before any loss / update, but the
+        # host never waits on an empty stream.
+        nonzero = torch.stack(nonzero)
+        if nonzero.is_cuda:
+            host_flags = torch.empty(nonzero.shape, dtype=torch.bool, pin_memory=True)
+            host_flags.copy_(nonzero, non_blocking=True)
+            flags_ready = torch.cuda.Event(); flags_ready.record()
+        else:
+            host_flags, flags_ready = nonzero, None
         query_mask = torch.stack(qms, 1); target = torch.stack(tgts, 1)    # (B,Qs,1,T,H,W), (B,Qs,3,T,H,W)
         rgb_rep = rgb[:, None].expand(B, Qs, 3, T, H, W).reshape(B * Qs, 3, T, H, W)
         out_mask, _ = self.seeker(rgb_rep, query_mask.reshape(B * Qs, 1, T, H, W))   # pipeline.py:157-158, Qs calls in one
+        if flags_ready is not None:
+            flags_ready.synchronize()
+        for q in range(Qs):
+            if not bool(host_flags[2 * q]):
+                raise RuntimeError(f'seeker_query_mask all zero? q: {q} query_idx: {sel_query_inds[:, q]} qt_idx: {qt}')   # pipeline.py:149-151
+            if not bool(host_flags[2 * q + 1]):
+                raise RuntimeError(f'target_mask all zero? q: {q}')        # pipeline.py:152-154
         bi = torch.arange(B)
-        sel_dev = sel_query_inds.to(dev)
+        sel_dev = to_dev(sel_query_inds, dev); bi_dev = to_dev(bi, dev); des_dev = to_dev(des, dev)
         return {
             'sel_query_inds': sel_dev,
-            'sel_occl_fracs': torch.stack([occl_fracs[bi.to(dev), sel_dev[:, q]] for q in range(Qs)], 1),         # (B,Qs,T,3)
-            'sel_desirability': torch.stack([des.to(dev)[bi.to(dev), sel_dev[:, q], 0] for q in range(Qs)], 1),
+            'sel_occl_fracs': torch.stack([occl_fracs[bi_dev, sel_dev[:, q]] for q in range(Qs)], 1),         # (B,Qs,T,3)
+            'sel_desirability': torch.stack([des_dev[bi_dev, sel_dev[:, q], 0] for q in range(Qs)], 1),
             'seeker_input': rgb, 'seeker_query_mask': query_mask,
             'snitch_occl_by_ptr': torch.stack(ptrs, 1), 'full_occl_cont_id': torch.stack(idss, 1),
             'target_mask': target, 'output_mask': out_mask.reshape(B, Qs, 3, T, H, W),

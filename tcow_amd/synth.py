@@ -205,11 +205,16 @@ def make_kubric_batch(B, T, H, W, seed=900, n_objects=5, M=36):
     }
 
 
-def to_torch_tree(x, device=None):
-    """numpy leaves -> torch tensors (optionally on `device`), lists / strings untouched."""
+HOST_KEYS = ('query_time', 'pv_inst_count', 'desirability_tf')
+
+
+def to_torch_tree(x, device=None, host_keys=()):
+    """numpy leaves -> torch tensors (optionally on `device`), lists / strings untouched.  Leaves whose key is in
+    `host_keys` stay on the host: the pipeline reads them to decide control flow (which instances to query, the query
+    frame), exactly as the reference reads them from its CPU-side DataLoader batch (pipeline.py:120-140)."""
     import torch
     if isinstance(x, dict):
-        return {k: to_torch_tree(v, device) for k, v in x.items()}
+        return {k: to_torch_tree(v, None if k in host_keys else device, host_keys) for k, v in x.items()}
     if isinstance(x, np.ndarray):
         t = torch.from_numpy(x)
         return t.to(device) if device is not None else t

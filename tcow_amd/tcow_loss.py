@@ -52,10 +52,40 @@ def hard_negative_band(target, H, W):
     return d & ~(target >= 0.5)
 
 
+class FusedMaskObjective(torch.autograd.Function):
+    """total = sum_c lw[c] * mask_loss_c over the three channels of (B,Q,3,T,H,W) logits, value and logit gradient
+    from libtcow_hip's tcow_mask_loss in the forward (no host synchronisation).  Returns (total, terms[3])."""
+
+    @staticmethod
+    def forward(ctx, logits, target, snitch_w, occl_fw, cont_fw, lws, aot_loss, topk_frac):
+        from . import ops
+        B, Q, C, T, H, W = logits.shape
+        lo = logits.detach().reshape(B * Q, C, T, H, W).contiguous(); tg = target.reshape(B * Q, C, T, H, W).contiguous()
+        terms = torch.zeros(3, dtype=torch.float32, device=lo.device); total = torch.zeros((), dtype=torch.float32, device=lo.device)
+        need_grad = logits.requires_grad
+        dl = torch.empty_like(lo) if need_grad else None
+        for c, (pw, fw, weighted) in enumerate(((snitch_w, None, False), (None, occl_fw, True), (None, cont_fw, True))):
+            if lws[c] > 0.0:
+                ops.mask_loss(lo, tg, c, pixel_w=pw, frame_w=fw, weighted_aot=weighted, aot_loss=aot_loss, topk_frac=topk_frac,
+                              loss_weight=lws[c], loss_out=terms[c:c + 1], total=total, dlogits=dl)
+            elif dl is not None:
+                dl[:, c].zero_()
+        ctx.dl = dl; ctx.shape = logits.shape
+        ctx.mark_non_differentiable(terms)
+        return total, terms
+
+    @staticmethod
+    def backward(ctx, g_total, _g_terms):
+        dl = ctx.dl; ctx.dl = None
+        return (dl * g_total).reshape(ctx.shape), None, None, None, None, None, None, None
+
+
 class TcowLosses:
-    def __init__(self, train_args=None, phase='train'):
+    def __init__(self, train_args=None, phase='train', fused=None):
+        """fused: None = use libtcow_hip's fused mask objective whenever the logits live on the GPU."""
         self.args = train_args if train_args is not None else default_args()
         self.phase = phase
+        self.fused = fused
 
     def frame_weights(self, sel_occl_fracs, query_time):                   # loss.py:55-83
         fw = (sel_occl_fracs[..., 0] * float(self.args.occluded_weight)).to(torch.float32).clip(min=1.0)
@@ -67,14 +97,16 @@ class TcowLosses:
         (B, Q, T, H, W) = snitch_occl_by_ptr.shape
         pw = torch.ones((B, Q, T, H, W), dtype=torch.float32, device=target.device)
         if self.args.class_balancing:
+            # loss.py:100-119 computes the two correction factors on the host in float64; the same arithmetic on
+            # 0-dim float64 device tensors gives the same float32 factors without draining the stream
             pos = target == 1.0; neg = target == 0.0
-            pos_frac = float((pos.sum() / pos.numel()).clip(min=0.05)); neg_frac = float((neg.sum() / neg.numel()).clip(min=0.05))
-            if pos_frac > neg_frac:
-                pos_corr = np.power(neg_frac / pos_frac, 0.7); neg_corr = np.power(neg_frac / pos_frac, -0.3)
-            else:
-                pos_corr = np.power(pos_frac / neg_frac, -0.3); neg_corr = np.power(pos_frac / neg_frac, 0.7)
-            pw = torch.where(neg, pw * float(neg_corr), pw)
-            pw = torch.where(pos, pw * float(pos_corr), pw)
+            pf = (pos.sum() / pos.numel()).clip(min=0.05).double(); nf = (neg.sum() / neg.numel()).clip(min=0.05).double()
+            more_pos = pf > nf
+            ratio = torch.where(more_pos, nf / pf, pf / nf)
+            pos_corr = torch.where(more_pos, ratio ** 0.7, ratio ** -0.3).float()
+            neg_corr = torch.where(more_pos, ratio ** -0.3, ratio ** 0.7).float()
+            pw = torch.where(neg, pw * neg_corr, pw)
+            pw = torch.where(pos, pw * pos_corr, pw)
         pw = torch.where(snitch_occl_by_ptr != 0, pw * 2.0, pw)
         if self.args.hard_negative_factor > 1.0 and not no_hard_negatives:
             pw = torch.where(hard_negative_band(target, H, W), pw * float(self.args.hard_negative_factor), pw)
@@ -113,6 +145,9 @@ class TcowLosses:
         if metrics_only:
             return {'metrics': calculate_metrics_mask_track(out, tgt)}
         a = self.args
+        fused = (out.is_cuda and not a.focal_loss and (out.shape[-1] * out.shape[-2]) % 4 == 0) if self.fused is None else self.fused
+        if fused:
+            return self._per_example_fused(model_retval, query_time, progress)
         res = {'track': None, 'occl_mask': None, 'cont_mask': None}
         if a.track_lw > 0.0:
             fw = self.frame_weights(model_retval['sel_occl_fracs'], query_time)
@@ -128,11 +163,40 @@ class TcowLosses:
         res['metrics'] = calculate_metrics_mask_track(out, tgt)
         return res
 
-    def entire_batch(self, loss_retval):                                   # loss.py:331-421 (logging omitted)
+    def _per_example_fused(self, model_retval, query_time, progress):
+        """Same objective through tcow_mask_loss: weights are prepared with (synchronisation-free) tensor ops, the three
+        channel losses and d(total)/d(logits) come from the HIP passes."""
+        out = model_retval['output_mask']; tgt = model_retval['target_mask']
         a = self.args
-        terms = {k: (torch.mean(v) if torch.is_tensor(v) else -1.0) for k, v in loss_retval.items() if k != 'metrics'}
-        total = terms['track'] * a.track_lw + terms['occl_mask'] * a.occl_mask_lw + terms['cont_mask'] * a.cont_mask_lw
-        out = {k: (float(v.detach()) if torch.is_tensor(v) else v) for k, v in terms.items()}
+        B, Q, C, T, H, W = out.shape
+        sw = None; fws = [None, None]
+        if a.track_lw > 0.0:
+            fw = self.frame_weights(model_retval['sel_occl_fracs'], query_time)
+            pw = self.pixel_weights(tgt[:, :, 0], model_retval['snitch_occl_by_ptr'][:, :, 0])
+            sw = (fw[..., None, None] * pw).contiguous()
+            model_retval['snitch_weights'] = sw
+        for i, (ch, lw) in enumerate(((1, a.occl_mask_lw), (2, a.cont_mask_lw))):
+            if lw > 0.0:
+                has = tgt[:, :, ch].flatten(-2).any(dim=-1).to(torch.float32)                       # (B,Q,T)
+                fws[i] = (has * (1.0 - a.occl_cont_zero_weight) + a.occl_cont_zero_weight).contiguous()
+        topk_frac = min(max(1.0 - progress * 8.5, 0.15), 1.0)
+        lws = (float(a.track_lw), float(a.occl_mask_lw), float(a.cont_mask_lw))
+        total, terms = FusedMaskObjective.apply(out, tgt, sw, fws[0], fws[1], lws, float(a.aot_loss), topk_frac)
+        res = {name: (terms[i] if lws[i] > 0.0 else None) for i, name in enumerate(('track', 'occl_mask', 'cont_mask'))}
+        res['_fused_total'] = total
+        res['metrics'] = calculate_metrics_mask_track(out, tgt)
+        return res
+
+    def entire_batch(self, loss_retval):                                   # loss.py:331-421 (logging omitted)
+        """Scalars are returned as detached 0-dim tensors (float() them to log): no host synchronisation here."""
+        a = self.args
+        fused_total = loss_retval.get('_fused_total')
+        terms = {k: (torch.mean(v) if torch.is_tensor(v) else -1.0) for k, v in loss_retval.items() if k not in ('metrics', '_fused_total')}
+        if fused_total is not None:
+            total = fused_total            # (terms are 0-dim per replica: their mean over replicas is the value itself)
+        else:
+            total = terms['track'] * a.track_lw + terms['occl_mask'] * a.occl_mask_lw + terms['cont_mask'] * a.cont_mask_lw
+        out = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in terms.items()}
         out['total_seeker'] = total
         out['metrics'] = loss_retval['metrics']
         return out

@@ -87,3 +87,83 @@ def test_full_step_on_gpu_matches_reference(cuda, precision, tol):
     gb = net.seeker.tracker_post_linear.bias.grad.cpu().numpy()
     ref = g['train::grad::seeker.tracker_post_linear.bias']
     assert np.abs(gb - ref).max() < (1e-4 if precision == 'fp32' else 5e-2) * np.abs(ref).max() + 1e-8
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('phase', ['test', 'train'])
+def test_fused_mask_objective_matches_reference_scalars(cuda, phase):
+    """tcow_mask_loss (HIP) on the reference's own logits: the three loss terms and the total, early (top-k = all) and
+    late (top-k < all) in training, against the reference's scalars; its logit gradient against autograd of the tensor path."""
+    _, g = load_golden('g5_pipeline_cfg1')
+    data = _data('cuda')
+    ref_out = torch.from_numpy(g[f'{phase}::output_mask']).cuda()
+    sel = torch.from_numpy(g[f'{phase}::sel_query_inds'])
+    args = default_args(hard_negative_factor=1.0)
+    for tag, progress in (('p0', 0.0), ('p5', 0.5), ('p9', 0.09)):
+        grads = {}
+        for fused in (True, False):
+            out = ref_out.clone().requires_grad_(True)
+            pipe = SeekerPipeline(_Replay(out), num_queries=Qs, train_args=args, phase=phase, device='cuda')
+            pipe.losses.fused = fused
+            mr = pipe.forward_kubric(data, sel_query_inds=sel)
+            res = pipe.step_losses(data, mr, progress)
+            if tag != 'p9':
+                for k in ('track', 'occl_mask', 'cont_mask', 'total_seeker'):
+                    assert abs(float(res[k]) - float(g[f'{phase}_{tag}::{k}'])) < 3e-6, (k, tag, fused)
+            res['total_seeker'].backward()
+            grads[fused] = out.grad.clone()
+        scale = float(grads[False].abs().max())
+        assert float((grads[True] - grads[False]).abs().max()) < 2e-5 * scale, tag
+        assert float((grads[True] - grads[False]).norm()) < 1e-5 * float(grads[False].norm()), tag
+
+
+@pytest.mark.gpu
+def test_fused_mask_loss_edge_cases(cuda):
+    """Frames without weight are left out (loss.py:176-181) and scale the loss by sqrt(selected fraction); ties at the top-k
+    threshold; an empty target switches the Jaccard term off (loss.py:21); a negligible mean weight gives zero (loss.py:184)."""
+    from tcow_amd.tcow_loss import TcowLosses
+    torch.manual_seed(5)
+    dev = 'cuda'
+    BQ, Tn, Hn, Wn = 3, 5, 12, 20
+    L = TcowLosses(default_args())
+
+    def both(logits, target, weights, progress, weighted, check_grad=True):
+        outs = []
+        for fused in (True, False):
+            x = logits.clone().requires_grad_(True)
+            if fused:
+                from tcow_amd import ops
+                lo = torch.zeros(BQ, 3, Tn, Hn, Wn, device=dev); tg = torch.zeros_like(lo); dl = torch.full_like(lo, 7.0)
+                lo[:, 1] = x.detach(); tg[:, 1] = target
+                loss = torch.zeros(1, device=dev); total = torch.zeros((), device=dev)
+                ops.mask_loss(lo, tg, 1, pixel_w=weights.contiguous(), weighted_aot=weighted, aot_loss=0.8,
+                              topk_frac=min(max(1.0 - progress * 8.5, 0.15), 1.0), loss_weight=0.5, loss_out=loss, total=total, dlogits=dl)
+                assert float((dl[:, 0] - 7.0).abs().max()) == 0.0 and float((dl[:, 2] - 7.0).abs().max()) == 0.0   # other channels untouched
+                assert abs(float(total) - 0.5 * float(loss)) < 1e-7
+                outs.append((float(loss), dl[:, 1] / 0.5))
+            else:
+                l = L.mask_loss(x, target, weights, progress, weighted)
+                if l.requires_grad:
+                    l.backward()
+                outs.append((float(l), x.grad if x.grad is not None else torch.zeros_like(x)))
+        (lf, gf), (lt, gt) = outs
+        assert abs(lf - lt) < 2e-6 * max(1.0, abs(lt)), (lf, lt)
+        if check_grad:
+            assert float((gf - gt).abs().max()) < 2e-5 * max(float(gt.abs().max()), 1e-12), float((gf - gt).abs().max())
+        return lf
+
+    x = torch.randn(BQ, Tn, Hn, Wn, device=dev) * 3
+    t = (torch.rand(BQ, Tn, Hn, Wn, device=dev) > 0.7).float()
+    w = torch.rand(BQ, Tn, Hn, Wn, device=dev) + 0.5
+    for weighted in (False, True):
+        for progress in (0.0, 0.05, 0.5):
+            both(x, t, w, progress, weighted)
+    w2 = w.clone(); w2[0, 1] = 0; w2[2, 3:] = 0                             # three frames carry no weight
+    for weighted in (False, True):
+        assert both(x, t, w2, 0.06, weighted) > 0
+    xq = torch.round(x)                                                     # few distinct values: many ties at the threshold
+    lf = both(xq, t, torch.ones_like(w), 0.06, False, check_grad=False)      # (torch.topk breaks ties arbitrarily; the kernel shares them)
+    assert lf > 0
+    assert both(x, torch.zeros_like(t), w, 0.06, False) > 0                 # empty target: Jaccard term is 0
+    assert both(x, t, torch.full_like(w, 5e-5), 0.06, True) == 0.0         # mean weight below 1e-4
+    assert both(x, t, torch.zeros_like(w), 0.06, True) == 0.0              # no frame selected
