@@ -22,7 +22,8 @@ int tcow_gemm_tn_bf16(hipStream_t stream, int M, int N, int K, const bf16_t* dY,
 int tcow_gemm_tn_f32(hipStream_t stream, int M, int N, int K, const float* dY, long ldy, const float* X, long ldx, float* dW, long lddw, int accumulate,
                      float* slab, int splits);
 int tcow_tn_splits(int M, int N, int K, int tile_outputs);
-int tcow_launch_slab_reduce(hipStream_t stream, const float* slab, int nz, long slab_stride, long rows, long cols, float* out, long ldo, int accumulate);
+int tcow_launch_slab_reduce(hipStream_t stream, const float* slab, int nz, long slab_stride, long rows, long cols, float* out, long ldo, int accumulate,
+                            const float* bias_part, int bias_nparts, int bias_n, float* bias_out);
 int tcow_launch_row_reduce(hipStream_t stream, const float* part, int nrows, long ld, int N, float* out, int accumulate);
 int tcow_launch_colsum(hipStream_t stream, int dtype, const void* Y, long ldy, int M, int N, float* out, int accumulate, float* part, int max_parts);
 
@@ -113,9 +114,9 @@ int tcow_gemm_tn(void* stream, int dtype, int M, int N, int K, const void* dY, l
         const bool fuse_bias = bias_grad != nullptr && (long)splits * ((K + 127) / 128) * 2 <= kColsumParts;
         rc = tcow_gemm_tn_bf16((hipStream_t)stream, M, N, K, (const bf16_t*)dY, ldy, (const bf16_t*)X, ldx, slab, splits, &nz, fuse_bias ? part : nullptr, &nparts);
         if (rc) return rc;
-        rc = tcow_launch_slab_reduce((hipStream_t)stream, slab, nz, (long)N * K, N, K, dW, lddw, accumulate);
+        rc = tcow_launch_slab_reduce((hipStream_t)stream, slab, nz, (long)N * K, N, K, dW, lddw, accumulate, fuse_bias ? part : nullptr, nparts, N, bias_grad);
         if (rc) return rc;
-        if (fuse_bias) return tcow_launch_row_reduce((hipStream_t)stream, part, nparts, N, N, bias_grad, accumulate);
+        if (fuse_bias) return TCOW_OK;
     } else if (dtype == TCOW_F32) {
         const int splits = tcow_tn_splits(M, N, K, 64);
         rc = tcow_gemm_tn_f32((hipStream_t)stream, M, N, K, (const float*)dY, ldy, (const float*)X, ldx, dW, lddw, accumulate, slab, splits);

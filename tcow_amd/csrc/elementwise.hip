@@ -220,19 +220,36 @@ __global__ void upsample_bwd_kernel(int B, int T_, int C, int h, int w, int st, 
 
 // ------------------------------------------------------------------------------------------ flags
 // flags[b,t,f] = mean_n (Wf . x[b,t,1+n] + bf) = Wf . mean_n x + bf   (mask_tracker.py:135-137)
-__global__ __launch_bounds__(256) void flags_fwd_kernel(int S, int D, int F, const float* __restrict__ x, const float* __restrict__ Wf, const float* __restrict__ bf,
-                                                        float* __restrict__ flags) {
-    extern __shared__ float mean[];  // [D]
+// One workgroup of 1024 threads per (b,t): thread (g, c) sums rows 1+g, 1+g+G, ... of float4 column c (G = 1024 / (D/4) row
+// groups run in parallel; a single thread per column would walk all S rows serially and leave the load pipe empty).
+__global__ __launch_bounds__(1024) void flags_fwd_kernel(int S, int D, int F, const float* __restrict__ x, const float* __restrict__ Wf, const float* __restrict__ bf,
+                                                         float* __restrict__ flags) {
+    extern __shared__ float4 part[];  // [G][D/4]; row 0 ends up holding the mean
     const int bt = blockIdx.x;
-    const float inv = 1.0f / (float)(S - 1);
-    for (int d = threadIdx.x; d < D; d += 256) {
-        float a = 0.f;
-        for (int s = 1; s < S; ++s) a += x[((size_t)bt * S + s) * D + d];
-        mean[d] = a * inv;
+    const int D4 = D >> 2;
+    const int G = 1024 / D4 > 0 ? 1024 / D4 : 1;
+    const float4* xb = reinterpret_cast<const float4*>(x + (size_t)bt * S * D);
+    for (int idx = threadIdx.x; idx < G * D4; idx += 1024) {
+        const int g = idx / D4, c = idx - g * D4;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+        for (int s = 1 + g; s < S; s += G) {
+            const float4 v = xb[(size_t)s * D4 + c];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        part[idx] = a;
     }
     __syncthreads();
+    const float inv = 1.0f / (float)(S - 1);
+    for (int c = threadIdx.x; c < D4; c += 1024) {
+        float4 a = part[c];
+        for (int g = 1; g < G; ++g) { const float4 v = part[g * D4 + c]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+        part[c] = make_float4(a.x * inv, a.y * inv, a.z * inv, a.w * inv);
+    }
+    __syncthreads();
+    const float* mean = reinterpret_cast<const float*>(part);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int f = wave; f < F; f += 4) {
+    for (int f = wave; f < F; f += 16) {
         float a = 0.f;
         for (int d = lane; d < D; d += 64) a += mean[d] * Wf[(size_t)f * D + d];
         a = wave_sum(a);
@@ -349,7 +366,9 @@ int tcow_upsample_bwd(void* stream, int B, int T_, int C, int h, int w, int st, 
 
 int tcow_flags_fwd(void* stream, int BT, int S, int D, int F, const float* x, const float* Wf, const float* bf, float* flags) {
     TCOW_CHECK_ARG(BT > 0 && S > 1 && D > 0 && F > 0 && x && Wf && bf && flags, "tcow_flags_fwd: bad arguments");
-    hipLaunchKernelGGL(flags_fwd_kernel, dim3(BT), dim3(256), (size_t)D * 4, (hipStream_t)stream, S, D, F, x, Wf, bf, flags);
+    TCOW_CHECK_ARG(D % 4 == 0, "tcow_flags_fwd: D %d must be a multiple of 4", D);
+    const int D4 = D / 4, G = 1024 / D4 > 0 ? 1024 / D4 : 1;
+    hipLaunchKernelGGL(flags_fwd_kernel, dim3(BT), dim3(1024), (size_t)G * D4 * 16, (hipStream_t)stream, S, D, F, x, Wf, bf, flags);
     TCOW_CHECK_LAUNCH();
     return TCOW_OK;
 }

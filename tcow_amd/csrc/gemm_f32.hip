@@ -118,9 +118,27 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slab, int nz, long 
         *o = accumulate ? (*o + s) : s;
     }
 }
-__global__ void slab_reduce4_kernel(const float* __restrict__ slab, int nz, long slab_stride, long n4, float* __restrict__ out, long cols4, long ldo, int accumulate) {
+// Workgroups [0, slab_blocks) fold the split-K slabs; the optional tail workgroups fold the bias-gradient partial table of the same
+// weight-gradient GEMM (4 columns x 16 row groups per 64-thread workgroup), so one launch finishes both.
+__global__ __launch_bounds__(64) void slab_reduce4_kernel(const float* __restrict__ slab, int nz, long slab_stride, long n4, float* __restrict__ out, long cols4, long ldo, int accumulate,
+                                                          int slab_blocks, const float* __restrict__ part, int nparts, int N, float* __restrict__ bias_out) {
+    if ((int)blockIdx.x >= slab_blocks) {
+        __shared__ float red[16][4];
+        const int cq = threadIdx.x & 3, g = threadIdx.x >> 2;
+        const int c = ((int)blockIdx.x - slab_blocks) * 4 + cq;
+        float a = 0.f;
+        if (c < N)
+            for (int r = g; r < nparts; r += 16) a += part[(size_t)r * N + c];
+        red[g][cq] = a;
+        __syncthreads();
+        if (g == 0 && c < N) {
+            for (int k = 1; k < 16; ++k) a += red[k][cq];
+            bias_out[c] = accumulate ? bias_out[c] + a : a;
+        }
+        return;
+    }
     long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
-    const long stride = (long)gridDim.x * blockDim.x;
+    const long stride = (long)slab_blocks * blockDim.x;
     for (; i < n4; i += stride) {
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
         // 8 independent loads in flight per thread: the slabs are streamed once, latency not bandwidth is the enemy
@@ -139,7 +157,9 @@ __global__ void slab_reduce4_kernel(const float* __restrict__ slab, int nz, long
 }
 
 // out[c] (+)= sum_r part[r][c] for a tall-skinny partial table (many rows, few columns): 16 columns x 16 row groups per block
-__global__ __launch_bounds__(256) void row_reduce_kernel(const float* __restrict__ part, int nrows, long ld, int N, float* __restrict__ out, int accumulate) {
+// (columns >= N1 go to out2[c - N1]: LayerNorm's dgamma | dbeta table is folded by one launch)
+__global__ __launch_bounds__(256) void row_reduce_kernel(const float* __restrict__ part, int nrows, long ld, int N, float* __restrict__ out, int accumulate,
+                                                         int N1, float* __restrict__ out2) {
     __shared__ float red[16][17];
     const int c = blockIdx.x * 16 + (threadIdx.x & 15), g = threadIdx.x >> 4;
     float s = 0.f;
@@ -149,7 +169,8 @@ __global__ __launch_bounds__(256) void row_reduce_kernel(const float* __restrict
     __syncthreads();
     if (g == 0 && c < N) {
         for (int k = 1; k < 16; ++k) s += red[k][threadIdx.x & 15];
-        out[c] = accumulate ? out[c] + s : s;
+        float* o = c < N1 ? out + c : out2 + (c - N1);
+        *o = accumulate ? *o + s : s;
     }
 }
 
@@ -206,13 +227,19 @@ int tcow_tn_splits(int M, int N, int K, int tile_outputs) {
     return s;
 }
 
-int tcow_launch_slab_reduce(hipStream_t stream, const float* slab, int nz, long slab_stride, long rows, long cols, float* out, long ldo, int accumulate) {
+int tcow_launch_row_reduce(hipStream_t stream, const float* part, int nrows, long ld, int N, float* out, int accumulate);
+
+int tcow_launch_slab_reduce(hipStream_t stream, const float* slab, int nz, long slab_stride, long rows, long cols, float* out, long ldo, int accumulate,
+                            const float* bias_part, int bias_nparts, int bias_n, float* bias_out) {
     const long n = rows * cols;
     const bool vec = (cols % 4 == 0) && (ldo % 4 == 0) && (slab_stride % 4 == 0) && ((reinterpret_cast<uintptr_t>(slab) | reinterpret_cast<uintptr_t>(out)) % 16 == 0);
     if (vec) {
         int blocks = cdiv(n / 4, 64); if (blocks > 8192) blocks = 8192;
-        hipLaunchKernelGGL(slab_reduce4_kernel, dim3(blocks), dim3(64), 0, stream, slab, nz, slab_stride, n / 4, out, cols / 4, ldo, accumulate);
+        const int tail = bias_part ? cdiv(bias_n, 4) : 0;
+        hipLaunchKernelGGL(slab_reduce4_kernel, dim3(blocks + tail), dim3(64), 0, stream, slab, nz, slab_stride, n / 4, out, cols / 4, ldo, accumulate,
+                           blocks, bias_part, bias_nparts, bias_n, bias_out);
     } else {
+        if (bias_part) { const int rc = tcow_launch_row_reduce(stream, bias_part, bias_nparts, bias_n, bias_n, bias_out, accumulate); if (rc) return rc; }
         int blocks = cdiv(n, 256); if (blocks > 2048) blocks = 2048;
         hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, stream, slab, nz, slab_stride, n, out, rows, cols, ldo, accumulate);
     }
@@ -221,7 +248,14 @@ int tcow_launch_slab_reduce(hipStream_t stream, const float* slab, int nz, long 
 }
 
 int tcow_launch_row_reduce(hipStream_t stream, const float* part, int nrows, long ld, int N, float* out, int accumulate) {
-    hipLaunchKernelGGL(row_reduce_kernel, dim3(cdiv(N, 16)), dim3(256), 0, stream, part, nrows, ld, N, out, accumulate);
+    hipLaunchKernelGGL(row_reduce_kernel, dim3(cdiv(N, 16)), dim3(256), 0, stream, part, nrows, ld, N, out, accumulate, N, (float*)nullptr);
+    TCOW_CHECK_LAUNCH();
+    return TCOW_OK;
+}
+
+// out1[c] (+)= column sums of part[:, c] for c < N1, out2[c - N1] for N1 <= c < N1 + N2
+int tcow_launch_row_reduce2(hipStream_t stream, const float* part, int nrows, long ld, int N1, float* out1, int N2, float* out2, int accumulate) {
+    hipLaunchKernelGGL(row_reduce_kernel, dim3(cdiv(N1 + N2, 16)), dim3(256), 0, stream, part, nrows, ld, N1 + N2, out1, accumulate, N1, out2);
     TCOW_CHECK_LAUNCH();
     return TCOW_OK;
 }
@@ -235,7 +269,7 @@ int tcow_launch_colsum(hipStream_t stream, int dtype, const void* Y, long ldy, i
     else
         hipLaunchKernelGGL(colsum_partial_kernel<float>, dim3(cdiv(N, 128), parts), dim3(256), 0, stream, (const float*)Y, ldy, M, N, rpb, part);
     TCOW_CHECK_LAUNCH();
-    return tcow_launch_slab_reduce(stream, part, parts, N, 1, N, out, N, accumulate);
+    return tcow_launch_slab_reduce(stream, part, parts, N, 1, N, out, N, accumulate, nullptr, 0, 0, nullptr);
 }
 
 int tcow_gemm_tn_f32(hipStream_t stream, int M, int N, int K, const float* dY, long ldy, const float* X, long ldx, float* dW, long lddw,
@@ -250,5 +284,5 @@ int tcow_gemm_tn_f32(hipStream_t stream, int M, int N, int K, const float* dY, l
     p.kps = kps; p.slab = slab;
     hipLaunchKernelGGL(gemm_f32_kernel, dim3(cdiv(K, FT), cdiv(N, FT), nz), dim3(256), 0, stream, p);
     TCOW_CHECK_LAUNCH();
-    return tcow_launch_slab_reduce(stream, slab, nz, (long)N * K, N, K, dW, lddw, accumulate);
+    return tcow_launch_slab_reduce(stream, slab, nz, (long)N * K, N, K, dW, lddw, accumulate, nullptr, 0, 0, nullptr);
 }

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int D, const T* _
 
 }  // namespace
 
-int tcow_launch_row_reduce(hipStream_t stream, const float* part, int nrows, long ld, int N, float* out, int accumulate);
+int tcow_launch_row_reduce2(hipStream_t stream, const float* part, int nrows, long ld, int N1, float* out1, int N2, float* out2, int accumulate);
 
 static const int kLnBwdBlocks = 512;
 
@@ -189,9 +189,7 @@ int tcow_layernorm_bwd(void* stream, int dtype, int rows, int D, const void* dy,
     TCOW_CHECK_LAUNCH();
     if (want_param_grads) {
         // part is [blocks][2][D]: slab stride 2*D, dgamma partials first, dbeta partials at +D
-        int rc = tcow_launch_row_reduce((hipStream_t)stream, part, blocks, 2L * D, D, dgamma, accumulate);
-        if (rc) return rc;
-        return tcow_launch_row_reduce((hipStream_t)stream, part + D, blocks, 2L * D, D, dbeta, accumulate);
+        return tcow_launch_row_reduce2((hipStream_t)stream, part, blocks, 2L * D, D, dgamma, D, dbeta, accumulate);
     }
     return TCOW_OK;
 }

@@ -66,6 +66,22 @@ def _row_vectors(module, g, train):
     rates = torch.linspace(0, module.drop_path_rate, depth).tolist() if depth > 1 else [0.0]   # vit.py:272
     scales = []
     forced = module.forced_drop_masks
+    if forced is None and train and max(rates) > 0.:
+        # all DropPath draws of the step in one batch (vit_utils.py:150-152 per call: keep = floor(rand + 1 - r), x / (1 - r) * keep):
+        # one rand and three broadcasts instead of ~15 tiny launches per block
+        keep_p = 1.0 - torch.tensor(rates, dtype=torch.float32, device=dev)[:, None]
+        u = torch.rand(depth, B * N + B * T + B, device=dev)
+        sc = (u + keep_p).floor_() / keep_p
+        kt = sc[:, :B * N].reshape(depth, B, 1, N); ks = sc[:, B * N:B * N + B * T].reshape(depth, B, T, 1); km = sc[:, B * N + B * T:].reshape(depth, B, 1)
+        rt = torch.ones(depth, B, T, S, dtype=torch.float32, device=dev)
+        rt[:, :, :, 1:] = kt
+        rt = rt.reshape(depth, -1)
+        rsp = ks.expand(depth, B, T, S).reshape(depth, -1)
+        rml = km.expand(depth, B, T * S).reshape(depth, -1)
+        for i in range(depth):
+            live = rates[i] > 0.
+            scales.append({'t': rt[i] if live else None, 's': rsp[i] if live else None, 'm': rml[i] if live else None})
+        return mask0, scales
     for i in range(depth):
         r = rates[i]
         ent = {'t': None, 's': None, 'm': None}
