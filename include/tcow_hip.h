@@ -214,6 +214,11 @@ typedef struct {
 size_t tcow_mask_loss_workspace_bytes(long n_frames, long frame_len);
 int tcow_mask_loss(void* stream, const tcow_mask_loss_args* args);
 
+/* ------------------------------------------------------------------------------------------- IoU areas (caller row M)
+ * eval/metrics.py:19-20,55-66: for each of n_frames contiguous frames of frame_len pixels, counts[f] = {|target|,
+ * |output & target|, |output | target|} with output = logit > 0, target = value > 0.5 (int32 [n_frames][3]). */
+int tcow_iou_counts(void* stream, const float* logits, const float* target, long n_frames, long frame_len, int* counts);
+
 #ifdef __cplusplus
 }
 #endif

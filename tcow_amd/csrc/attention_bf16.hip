@@ -442,6 +442,66 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma(SeqDesc sd, int nt, cons
     }
 }
 
+// ------------------------------------------------------------------------------------------------ backward, one tile (L <= 32)
+// Temporal attention at T <= 32: the whole sequence of a (site, head) is one 32-position tile, so one wave produces dQ, dK and dV
+// from a single visit of Q, K, V, dO (wave-private LDS tiles) and computes delta = rowsum(dO * O) itself: one launch and one
+// read of every operand instead of prep + dK/dV + dQ kernels (three launches, Q/K/V/dO read twice).
+__global__ __launch_bounds__(256) void attn_bwd_one_tile(SeqDesc sd, const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
+                                                         const float* __restrict__ lse, bf16_t* __restrict__ dqkv) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const WorkId w = work_id<false>(sd, wave);
+    if (!w.valid) return;
+    const long base = seq_base(sd, w.item);
+    const long ld3 = 3L * sd.D, pse = sd.pos_stride * ld3, pso = sd.pos_stride * sd.D;
+    const bf16_t* qh = qkv + base * ld3 + w.head * ATT_HD;
+    const bf16_t* doh = dout + base * sd.D + w.head * ATT_HD;
+    const bf16_t* oh = o + base * sd.D + w.head * ATT_HD;
+    char* qt_ = smem + wave * (4 * TILE_B + 256);
+    char* kt = qt_ + TILE_B; char* vt = kt + TILE_B; char* dot_ = vt + TILE_B;
+    float2* ldw = reinterpret_cast<float2*>(dot_ + TILE_B);
+    load_tile(qh, pse, 0, sd.L, qt_, lane);
+    load_tile(qh + sd.D, pse, 0, sd.L, kt, lane);
+    load_tile(qh + 2 * sd.D, pse, 0, sd.L, vt, lane);
+    load_tile(doh, pso, 0, sd.L, dot_, lane);
+    // delta for row l31: each half-wave covers 32 of the 64 channels
+    const int qc = l31 < sd.L ? l31 : sd.L - 1;
+    float part = 0.f;
+#pragma unroll
+    for (int d = 0; d < 32; d += 4) {
+        const float4 x = ld4(oh + (size_t)qc * pso + 32 * hi + d), y = ld4(doh + (size_t)qc * pso + 32 * hi + d);
+        part += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+    }
+    const float dl = part + __shfl_xor(part, 32, 64);
+    const float lsv = lse[(base + (long)qc * sd.pos_stride) * sd.heads + w.head];
+    if (hi == 0) ldw[l31] = l31 < sd.L ? make_float2(lsv, dl) : make_float2(0.f, 0.f);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    // ---- dK, dV (this wave's keys against its queries)
+    {
+        bf16x8 kf[4], vf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { kf[ks] = frag_row(kt, l31, ks, hi); vf[ks] = frag_row(vt, l31, ks, hi); }
+        f32x16 dk0, dk1, dv0, dv1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk0[r] = 0.f; dk1[r] = 0.f; dv0[r] = 0.f; dv1[r] = 0.f; }
+        dkv_tile(sd, qt_, dot_, ldw, 0, l31, kf, vf, l31, hi, lane, dk0, dk1, dv0, dv1);
+        dkv_store(sd, base, ld3, w.head, 0, l31, hi, dk0, dk1, dv0, dv1, dqkv);
+    }
+    // ---- dQ
+    {
+        bf16x8 qf[4], dof[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { qf[ks] = frag_row(qt_, l31, ks, hi); dof[ks] = frag_row(dot_, l31, ks, hi); }
+        f32x16 dq0, dq1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dq0[r] = 0.f; dq1[r] = 0.f; }
+        dq_tile(sd, kt, vt, 0, l31, qf, dof, lsv * kLog2e, dl, l31, hi, lane, dq0, dq1);
+        dq_store(sd, base, ld3, w.head, 0, l31, hi, dq0, dq1, dqkv);
+    }
+}
+
 // ---- streaming backward kernels (any sequence length): a workgroup owns 4 key tiles (dK/dV) or 4 query tiles (dQ), one per
 // wave, and walks the other side in chunks of 4 tiles staged in 32 KiB of LDS (wave w loads tile 4c+w of the chunk).
 __global__ __launch_bounds__(256) void attn_bwd_dkv_stream(SeqDesc sd, int nt, const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
@@ -576,6 +636,13 @@ int tcow_attn_mfma_bwd(hipStream_t st, const SeqDesc& d, bool shared, const void
                        void* dqkv) {
     const int nt = (d.L + 31) / 32;
     const int pairs = d.n_outer * d.n_inner * d.heads;
+    if (!shared && nt == 1) {
+        const int lds = 4 * (4 * TILE_B + 256);
+        set_lds_attr(attn_bwd_one_tile, lds);
+        hipLaunchKernelGGL(attn_bwd_one_tile, dim3(cdiv(pairs, 4)), dim3(256), lds, st, d, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv);
+        TCOW_CHECK_LAUNCH();
+        return TCOW_OK;
+    }
     float2* ld = (float2*)ws;
     const long total = (long)pairs * nt * 32;
     int blocks = cdiv(total, 256); if (blocks > 8192) blocks = 8192;

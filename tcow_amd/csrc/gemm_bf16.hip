@@ -233,10 +233,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_ring_kernel(NtParams p) {
     nt_epilogue(p, smem, acc, b4, tid, wm, wn, l31, hi, m0, n0);
 }
 
-// ---- 256 x 256 tile, 8 waves (2 x 4, 128 x 64 each).  PMC on the 128-tile kernel (profiles/r01_pmc_gemm_sq.txt): zero LDS bank
-// conflicts, MFMA pipe busy 29 %, waves parked 39 % of their cycles in the vmcnt/barrier wait -- the 128 x 128 x 64 step pulls
-// 32 KiB per workgroup per 2.1 MFLOP, ~10 TB/s of L2->LDS traffic chip-wide.  The 256-square tile halves the bytes per FLOP
-// (64 KiB per 8.4 MFLOP) and needs 6 instead of 8 fragment reads per 8 MFMAs.  128 KiB LDS (two stages), one workgroup per CU.
+// ---- 256 x 256 tile, 8 waves (2 x 4, 128 x 64 each).  PMC on the 128-tile kernel (profiles/r01_pmc_gemm_units.txt): zero LDS bank
+// conflicts, LdsUtil ~22 %, MFMA pipe busy 41-48 %, half of all wave cycles parked in the vmcnt/barrier wait and the texture-address
+// path 58-68 % busy -- the 128 x 128 x 64 step pulls 32 KiB per workgroup per 2.1 MFLOP through the global->LDS path and is bound
+// by it.  The 256-square tile halves the bytes per FLOP (64 KiB per 8.4 MFLOP; MFMA busy 55 % at 8192^3) and needs 6 instead of 8
+// fragment reads per 8 MFMAs.  128 KiB LDS (two stages), one workgroup per CU.
 constexpr int B_BM = 256, B_BN = 256;
 constexpr int B_TILE = 256 * 128;              // 32 KiB per operand per stage
 constexpr int B_STAGE = 2 * B_TILE;

@@ -381,3 +381,38 @@ int tcow_mask_loss(void* stream, const tcow_mask_loss_args* a) {
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------ IoU area counts (caller row M)
+// eval/metrics.py:19-20,55-66: per frame, |target|, |output & target|, |output | target| with output = logit > 0 and
+// target = value > 0.5.  One pass over both tensors; integer counts, so the result is exact and order-independent.
+namespace {
+__global__ void __launch_bounds__(256) iou_counts_kernel(const float* __restrict__ logits, const float* __restrict__ target, int L4, int* __restrict__ counts) {
+    __shared__ int red[3][4];
+    const int f = blockIdx.x;
+    const float4* x = reinterpret_cast<const float4*>(logits) + (size_t)f * L4;
+    const float4* t = reinterpret_cast<const float4*>(target) + (size_t)f * L4;
+    int ta = 0, in = 0, un = 0;
+    for (int i = threadIdx.x; i < L4; i += 256) {
+        const float4 xv = x[i], tv = t[i];
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ts[4] = {tv.x, tv.y, tv.z, tv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int o = xs[e] > 0.0f, g = ts[e] > 0.5f;
+            ta += g; in += o & g; un += o | g;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) { ta += __shfl_xor(ta, o, 64); in += __shfl_xor(in, o, 64); un += __shfl_xor(un, o, 64); }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][w] = ta; red[1][w] = in; red[2][w] = un; }
+    __syncthreads();
+    if (threadIdx.x < 3) counts[f * 3 + threadIdx.x] = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+}
+}  // namespace
+
+extern "C" int tcow_iou_counts(void* stream, const float* logits, const float* target, long n_frames, long frame_len, int* counts) {
+    TCOW_CHECK_ARG(logits && target && counts && n_frames > 0 && frame_len > 0, "tcow_iou_counts: bad arguments");
+    TCOW_CHECK_ARG(frame_len % 4 == 0 && frame_len / 4 < (1L << 31) && n_frames < (1L << 31), "tcow_iou_counts: frame_len %ld must be a multiple of 4", frame_len);
+    hipLaunchKernelGGL(iou_counts_kernel, dim3((unsigned)n_frames), dim3(256), 0, (hipStream_t)stream, logits, target, (int)(frame_len / 4), counts);
+    TCOW_CHECK_LAUNCH();
+    return TCOW_OK;
+}

@@ -8,14 +8,20 @@ import torch
 def calculate_metrics_mask_track(output_mask, target_mask, plugin=False):
     """output_mask logits, target_mask in {0,1} (or -1 = unlabeled frame for plugin data), shape (B,Q,3,T,H,W)
     ((B,3,T,H,W) when plugin=True).  Returns the reference's dict: mean_* (f32, -1 when empty) and count_* (int32)."""
-    out_b = output_mask > 0.0                                              # metrics.py:19
-    tgt_b = target_mask > 0.5                                              # metrics.py:20
+    lead = tuple(target_mask.shape[:-2])                                   # (B,Q,C,T) or (B,C,T)
     if plugin:
-        out_b, tgt_b = out_b[:, None], tgt_b[:, None]                      # metrics.py:26-29
-    Cmt = tgt_b.shape[2]
-    t_area = tgt_b.sum(dim=(-1, -2)).to(torch.float64)                     # (B,Q,C,T)
-    inter = (out_b & tgt_b).sum(dim=(-1, -2)).to(torch.float64)
-    union = (out_b | tgt_b).sum(dim=(-1, -2)).to(torch.float64)
+        lead = (lead[0], 1) + lead[1:]                                     # metrics.py:26-29
+    Cmt = lead[2]
+    if output_mask.is_cuda and output_mask.dtype == torch.float32 and target_mask.dtype == torch.float32 and (output_mask.shape[-1] * output_mask.shape[-2]) % 4 == 0:
+        from . import ops                                                  # one pass over both tensors (tcow_iou_counts)
+        cnt = ops.iou_counts(output_mask.detach(), target_mask).reshape(lead + (3,)).to(torch.float64)
+        t_area, inter, union = cnt[..., 0], cnt[..., 1], cnt[..., 2]
+    else:
+        out_b = (output_mask > 0.0).reshape(lead + tuple(output_mask.shape[-2:]))      # metrics.py:19
+        tgt_b = (target_mask > 0.5).reshape(lead + tuple(target_mask.shape[-2:]))      # metrics.py:20
+        t_area = tgt_b.sum(dim=(-1, -2)).to(torch.float64)                 # (B,Q,C,T)
+        inter = (out_b & tgt_b).sum(dim=(-1, -2)).to(torch.float64)
+        union = (out_b | tgt_b).sum(dim=(-1, -2)).to(torch.float64)
     iou = inter / (union + 1e-7)                                           # metrics.py:55-66
     has = t_area > 0
     sn = has[:, :, 0]

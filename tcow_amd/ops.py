@@ -186,3 +186,15 @@ def mask_loss(logits, target, channel, pixel_w=None, frame_w=None, weighted_aot=
                        C * T * frame_len, ws.data_ptr(), ws.numel())
     L.check(lib.tcow_mask_loss(_stream(), ctypes.byref(a)), 'tcow_mask_loss')
     return loss_out
+
+
+def iou_counts(logits, target):
+    """(..., H, W) f32 logits / targets -> int32 (..., 3): target area, intersection, union per frame (see tcow_iou_counts)."""
+    _need_cuda(logits, target)
+    if logits.shape != target.shape or logits.dtype != torch.float32 or target.dtype != torch.float32:
+        raise L.TcowError('iou_counts: logits and target must be f32 tensors of one shape')
+    lo = logits.contiguous(); tg = target.contiguous()
+    frame_len = lo.shape[-1] * lo.shape[-2]
+    out = torch.empty(lo.shape[:-2] + (3,), dtype=torch.int32, device=lo.device)
+    L.check(L.lib().tcow_iou_counts(_stream(), lo.data_ptr(), tg.data_ptr(), lo.numel() // frame_len, frame_len, out.data_ptr()), 'tcow_iou_counts')
+    return out

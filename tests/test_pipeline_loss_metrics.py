@@ -171,3 +171,21 @@ def test_fused_mask_loss_edge_cases(cuda):
     assert both(x, torch.zeros_like(t), w, 0.06, False) > 0                 # empty target: Jaccard term is 0
     assert both(x, t, torch.full_like(w, 5e-5), 0.06, True) == 0.0         # mean weight below 1e-4
     assert both(x, t, torch.zeros_like(w), 0.06, True) == 0.0              # no frame selected
+
+
+@pytest.mark.gpu
+def test_iou_counts_kernel_matches_tensor_path(cuda):
+    """tcow_iou_counts (integer areas, exact) behind calculate_metrics_mask_track vs the tensor reductions on the CPU."""
+    torch.manual_seed(3)
+    out = torch.randn(2, 3, 3, 5, 24, 40); tgt = (torch.rand(2, 3, 3, 5, 24, 40) > 0.6).float()
+    tgt[0, 1] = 0; tgt[1, :, 2, 2:] = 0                                     # un-annotated instances / frames -> counts drop, means may be -1
+    from tcow_amd import ops
+    cnt = ops.iou_counts(out.cuda(), tgt.cuda()).cpu()
+    ob, tb = out > 0, tgt > 0.5
+    assert torch.equal(cnt[..., 0], tb.sum((-1, -2)).int()) and torch.equal(cnt[..., 1], (ob & tb).sum((-1, -2)).int()) and torch.equal(cnt[..., 2], (ob | tb).sum((-1, -2)).int())
+    a = calculate_metrics_mask_track(out.cuda(), tgt.cuda()); b = calculate_metrics_mask_track(out, tgt)
+    for k in b:
+        assert (int(a[k]) == int(b[k])) if 'count' in k else abs(float(a[k]) - float(b[k])) < 1e-6, k
+    ap = calculate_metrics_mask_track(out[:, 0].cuda(), tgt[:, 0].cuda(), plugin=True); bp = calculate_metrics_mask_track(out[:, 0], tgt[:, 0], plugin=True)
+    for k in bp:
+        assert (int(ap[k]) == int(bp[k])) if 'count' in k else abs(float(ap[k]) - float(bp[k])) < 1e-6, k

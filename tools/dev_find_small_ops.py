@@ -1,0 +1,29 @@
+"""Dev: which Python lines issue the small fill / copy kernels of one bench step (torch profiler with stacks)."""
+import sys, collections, torch
+sys.path.insert(0, '.')
+import numpy as np
+from tcow_amd import synth
+from tcow_amd.seeker import Seeker
+from tcow_amd.pipeline import SeekerPipeline
+from tcow_amd.tcow_loss import default_args
+from tcow_amd.optim import FusedAdamWClip
+dev = torch.device('cuda', 0)
+cfg = synth.seeker_config(causal_attention=1)
+net = Seeker(None, num_total_frames=30, frame_height=240, frame_width=320, causal_attention=1, drop_path_rate=0.1, precision='bf16')
+net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg, 900).items()}); net = net.to(dev).train()
+opt = FusedAdamWClip(list(net.parameters()), lr=1e-4, max_norm=0.3); opt.on_step.append(net.seeker.invalidate_weight_cache); net.seeker.persistent_grads = True
+data = synth.to_torch_tree(synth.make_kubric_batch(1, 30, 240, 320, seed=900, n_objects=5), dev, host_keys=synth.HOST_KEYS)
+pipe = SeekerPipeline(net, num_queries=3, train_args=default_args(), phase='train', device=dev, rng=np.random.default_rng(0))
+def step(i):
+    mr = pipe.forward_kubric(data); loss = pipe.step_losses(data, mr, i / 1000.0)['total_seeker']; loss.backward(); opt.step()
+for i in range(3): step(i)
+torch.cuda.synchronize()
+from torch.profiler import profile, ProfilerActivity
+with profile(activities=[ProfilerActivity.CPU], with_stack=True, record_shapes=True) as prof:
+    step(3); torch.cuda.synchronize()
+cnt = collections.Counter()
+for ev in prof.events():
+    if ev.name in ('aten::fill_', 'aten::zero_', 'aten::copy_', 'aten::zeros', 'aten::ones', 'aten::full'):
+        st = [s for s in ev.stack if 'tcow_amd' in s or 'bench' in s or 'tools/' in s]
+        cnt[(ev.name, st[0] if st else (ev.stack[0] if ev.stack else '?'), str(ev.input_shapes)[:60])] += 1
+for (k, v) in cnt.most_common(40): print(v, k)
