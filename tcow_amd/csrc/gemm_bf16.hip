@@ -284,37 +284,67 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_256_kernel(NtParams p) {
             glds16(w_src[j] + (size_t)kt * BK, sw + (wave * 4 + j) * 1024);
         }
     };
-    int a_off[4], a_sw[4], w_off[2], w_sw[2];
+    // Fragment reads are software-pipelined by hand: left to hipcc, the loop keeps ONE fragment register set and waits lgkmcnt(0)
+    // before every group of four MFMAs, exposing the LDS latency eight times per K-slice.  Here the six ds_read_b128 of k-step ks+1
+    // are issued (inline asm, so the compiler neither merges nor reorders them) before the eight MFMAs of k-step ks, and a counted
+    // s_waitcnt lgkmcnt(6) retires exactly the previous k-step's reads.  All four A (two W) fragments of a k-step share one address
+    // register: rows 32 apart have the same swizzle, so they differ by an immediate offset.
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(LDS_PTR(char))smem;
+    uint32_t a_ad[4], w_ad[4];
+    {
+        const int ra = wm * 128 + l31, rw = wn * 64 + l31;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { const int ra = wm * 128 + i * 32 + l31; a_off[i] = ra * 128; a_sw[i] = (ra >> 1) & 7; }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) { const int rw = wn * 64 + j * 32 + l31; w_off[j] = rw * 128; w_sw[j] = (rw >> 1) & 7; }
+        for (int ks = 0; ks < 4; ++ks) {
+            a_ad[ks] = lds0 + ra * 128 + (((2 * ks + hi) ^ ((ra >> 1) & 7)) << 4);
+            w_ad[ks] = lds0 + B_TILE + rw * 128 + (((2 * ks + hi) ^ ((rw >> 1) & 7)) << 4);
+        }
+    }
+    u32x4 fa[2][4], fw[2][2];
+#define TCOW_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
+#define TCOW_READ_FRAGS(buf, ks, so)                                            \
+    do {                                                                        \
+        const uint32_t aa = a_ad[ks] + (so), ww = w_ad[ks] + (so);              \
+        TCOW_DSR(fw[buf][0], ww, 0); TCOW_DSR(fw[buf][1], ww, 4096);            \
+        TCOW_DSR(fa[buf][0], aa, 0); TCOW_DSR(fa[buf][1], aa, 4096);            \
+        TCOW_DSR(fa[buf][2], aa, 8192); TCOW_DSR(fa[buf][3], aa, 12288);        \
+    } while (0)
+#define TCOW_MFMA8(buf)                                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                        \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                    \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[buf][i]), __builtin_bit_cast(bf16x8, fw[buf][j]), acc[i][j], 0, 0, 0)
 
     issue(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    TCOW_READ_FRAGS(0, 0, 0u);
     for (int kt = 0; kt < nk; ++kt) {
-        const int stage = kt & 1;
-        if (kt + 1 < nk) issue(kt + 1, stage ^ 1);
-        const char* sa = smem + stage * B_STAGE;
-        const char* sw = sa + B_TILE;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int c = 2 * ks + hi;
-            bf16x8 fa[4], fw[2];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) fw[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sw + w_off[j] + ((c ^ w_sw[j]) << 4)));
-#pragma unroll
-            for (int i = 0; i < 4; ++i) fa[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sa + a_off[i] + ((c ^ a_sw[i]) << 4)));
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fw[j], acc[i][j], 0, 0, 0);
-        }
+        const uint32_t so = (uint32_t)(kt & 1) * B_STAGE;
+        if (kt + 1 < nk) issue(kt + 1, (kt & 1) ^ 1);
+        TCOW_READ_FRAGS(1, 1, so);
+        asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        TCOW_MFMA8(0);
+        TCOW_READ_FRAGS(0, 2, so);
+        asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        TCOW_MFMA8(1);
+        TCOW_READ_FRAGS(1, 3, so);
+        asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        TCOW_MFMA8(0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        TCOW_MFMA8(1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if (kt + 1 < nk) TCOW_READ_FRAGS(0, 0, so ^ (uint32_t)B_STAGE);
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#undef TCOW_DSR
+#undef TCOW_READ_FRAGS
+#undef TCOW_MFMA8
 
     // ---- epilogue: every wave stages its own 128 x 64 tile through a private 16 KiB LDS region, 64 rows at a time, and writes
     // full output rows (128 B bf16 / 256 B f32 per row).  No workgroup barrier: a wave's LDS operations execute in order.
