@@ -96,14 +96,16 @@ int tcow_gemm_tn(void* stream, int dtype, int M, int N, int K, const void* dY, l
  * (nn.LayerNorm(D, eps=1e-6): vit.py:135 norm1, :142 temporal_norm1, :150 norm2, :283 norm; eps vit.py:428).
  * y has `dtype` elements; mean / rstd (f32 [rows], may be NULL in inference) are saved for the backward.
  * Backward: dx = dres + dLN(dy) (dres = gradient arriving through the residual connection, may be NULL),
- * dgamma / dbeta (+)= column sums (both NULL to skip; otherwise workspace of tcow_layernorm_bwd_workspace_bytes). */
+ * dgamma / dbeta (+)= column sums (both NULL to skip; otherwise workspace of tcow_layernorm_bwd_workspace_bytes).
+ * dx_cast (may be NULL) additionally receives dtype(dx * cast_row_scale[row]) (scale NULL = 1): the operand of the
+ * input-gradient GEMM that consumes this gradient next, without a separate tcow_scale_cast pass. */
 int tcow_layernorm_fwd(void* stream, int dtype, int rows, int D, const float* x, long ldx, const float* gamma,
                        const float* beta, float eps, void* y, long ldy, float* mean, float* rstd);
 long tcow_layernorm_bwd_workspace_bytes(int D);
 int tcow_layernorm_bwd(void* stream, int dtype, int rows, int D, const void* dy, long lddy, const float* x, long ldx,
                        const float* mean, const float* rstd, const float* gamma, const float* dres, long lddres,
                        float* dx, long lddx, float* dgamma, float* dbeta, int accumulate, void* workspace,
-                       long workspace_bytes);
+                       long workspace_bytes, void* dx_cast, long lddx_cast, const float* cast_row_scale);
 
 /* ------------------------------------------------------------------------------------------- attention
  * softmax(q k^T / 8 [mask]) v per head (head_dim 64) straight on the qkv GEMM output [rows, 3D]

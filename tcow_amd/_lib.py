@@ -57,7 +57,7 @@ SIGNATURES = {
     'tcow_gemm_tn': (_i, [_vp, _i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _vp, _i, _vp, _l]),
     'tcow_layernorm_fwd': (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _vp, _f, _vp, _l, _vp, _vp]),
     'tcow_layernorm_bwd_workspace_bytes': (_l, [_i]),
-    'tcow_layernorm_bwd': (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _l, _vp, _vp, _vp, _vp, _l, _vp, _l, _vp, _vp, _i, _vp, _l]),
+    'tcow_layernorm_bwd': (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _l, _vp, _vp, _vp, _vp, _l, _vp, _l, _vp, _vp, _i, _vp, _l, _vp, _l, _vp]),
     'tcow_attn_temporal_fwd': (_i, [_vp, _ash, _vp, _vp, _vp]),
     'tcow_attn_spatial_fwd': (_i, [_vp, _ash, _vp, _vp, _vp]),
     'tcow_attn_bwd_workspace_bytes': (_l, [_ash]),

@@ -61,7 +61,8 @@ template <typename T, int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int D, const T* __restrict__ dy, long lddy, const float* __restrict__ x, long ldx,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const float* __restrict__ dres, long lddres,
-                                                     float* __restrict__ dx, long lddx, float* __restrict__ part /* [grid][2][D] or NULL */) {
+                                                     float* __restrict__ dx, long lddx, float* __restrict__ part /* [grid][2][D] or NULL */,
+                                                     T* __restrict__ dxc, long lddxc, const float* __restrict__ cscale) {
     extern __shared__ __attribute__((aligned(16))) float red[];  // [4][2*D]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = D >> 2;
@@ -112,6 +113,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int D, const T* _
         if (row + rstep < rows) fetch(row + rstep);
         const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
         float* dxr = dx + (size_t)row * lddx;
+        const float cs_row = (dxc && cscale) ? cscale[row] : 1.0f;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = lane + i * 64;
@@ -120,6 +122,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int D, const T* _
                                        rs * (g[i].w - m1 - xh[i].w * m2));
                 if (dres) { o.x += rr[i].x; o.y += rr[i].y; o.z += rr[i].z; o.w += rr[i].w; }
                 st4(dxr + c * 4, o);
+                if (dxc) {       // the same gradient as the next GEMM's operand: dtype(dx * row scale), saves a separate cast pass
+                    const float cs = cs_row;
+                    st4(dxc + (size_t)row * lddxc + c * 4, make_float4(o.x * cs, o.y * cs, o.z * cs, o.w * cs));
+                }
             }
         }
     }
@@ -168,9 +174,10 @@ long tcow_layernorm_bwd_workspace_bytes(int D) { return (long)kLnBwdBlocks * 2 *
 
 int tcow_layernorm_bwd(void* stream, int dtype, int rows, int D, const void* dy, long lddy, const float* x, long ldx, const float* mean,
                        const float* rstd, const float* gamma, const float* dres, long lddres, float* dx, long lddx, float* dgamma, float* dbeta,
-                       int accumulate, void* workspace, long workspace_bytes) {
+                       int accumulate, void* workspace, long workspace_bytes, void* dx_cast, long lddx_cast, const float* cast_row_scale) {
     TCOW_CHECK_ARG(rows > 0 && D > 0 && D % 4 == 0 && D <= 64 * 4 * LN_MAXV, "tcow_layernorm_bwd: bad D=%d", D);
     TCOW_CHECK_ARG(dy && x && mean && rstd && gamma && dx, "tcow_layernorm_bwd: null pointer");
+    TCOW_CHECK_ARG(!dx_cast || lddx_cast % 4 == 0, "tcow_layernorm_bwd: dx_cast stride must be a multiple of 4");
     const bool want_param_grads = dgamma != nullptr || dbeta != nullptr;
     TCOW_CHECK_ARG(!want_param_grads || (dgamma && dbeta && workspace && workspace_bytes >= tcow_layernorm_bwd_workspace_bytes(D)),
                    "tcow_layernorm_bwd: parameter gradients need dgamma, dbeta and a workspace of %ld bytes", tcow_layernorm_bwd_workspace_bytes(D));
@@ -181,8 +188,8 @@ int tcow_layernorm_bwd(void* stream, int dtype, int rows, int D, const void* dy,
     const int nvl = (D / 4 + 63) / 64;
 #define LN_BWD(NVV)                                                                                                                               \
     do {                                                                                                                                          \
-        if (dtype == TCOW_BF16) hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, NVV>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, rows, D, (const bf16_t*)dy, lddy, x, ldx, mean, rstd, gamma, dres, lddres, dx, lddx, part); \
-        else hipLaunchKernelGGL((ln_bwd_kernel<float, NVV>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, rows, D, (const float*)dy, lddy, x, ldx, mean, rstd, gamma, dres, lddres, dx, lddx, part); \
+        if (dtype == TCOW_BF16) hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, NVV>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, rows, D, (const bf16_t*)dy, lddy, x, ldx, mean, rstd, gamma, dres, lddres, dx, lddx, part, (bf16_t*)dx_cast, lddx_cast, cast_row_scale); \
+        else hipLaunchKernelGGL((ln_bwd_kernel<float, NVV>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, rows, D, (const float*)dy, lddy, x, ldx, mean, rstd, gamma, dres, lddres, dx, lddx, part, (float*)dx_cast, lddx_cast, cast_row_scale); \
     } while (0)
     if (nvl <= 1) LN_BWD(1); else if (nvl == 2) LN_BWD(2); else if (nvl == 3) LN_BWD(3); else if (nvl == 4) LN_BWD(4); else LN_BWD(8);
 #undef LN_BWD

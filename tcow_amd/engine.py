@@ -334,6 +334,7 @@ def run_backward(module, sv, params, d_mask, d_flags):
 
     shape_attn = ops.attn_shape(mode, B, T, S, D, heads, ca)
     dR3 = dX
+    G3_next = None
     for i in reversed(range(module.network_depth)):
         o = 5 + i * _BLOCK_PARAMS
         q = params[o: o + _BLOCK_PARAMS]
@@ -342,8 +343,11 @@ def run_backward(module, sv, params, d_mask, d_flags):
         Hd = q[16].shape[0]
         blk_flat = bucket(range(o, o + _BLOCK_PARAMS))
         # ---- mlp
-        G3 = E(M, D)
-        ops.scale_cast(mode, dR3, dp['m'], G3)
+        if G3_next is not None:
+            G3 = G3_next                       # produced by the LayerNorm backward of the block above (fused cast)
+        else:
+            G3 = E(M, D)
+            ops.scale_cast(mode, dR3, dp['m'], G3)
         dpre = E(M, Hd)
         ops.gemm_nt(mode, G3, Wt(q[18]), dpre, act=ACT_DGELU, aux=st['pre'])
         linear_bwd(o + 18, G3, st['H'])
@@ -367,11 +371,10 @@ def run_backward(module, sv, params, d_mask, d_flags):
         ops.gemm_nt(mode, dQKV2, Wt(q[10]), dV)
         linear_bwd(o + 10, dQKV2, st['V'])
         dR1 = E(M, D, dtype=f32)
-        ops.layernorm_bwd(mode, dV, st['R1'], st['mu1'], st['rs1'], q[8].detach(), dR2, dR1, galloc(o + 8), galloc(o + 9))
+        G1 = E(M, D)                           # bf16(dR1 * mask0), written by the same LayerNorm backward pass
+        ops.layernorm_bwd(mode, dV, st['R1'], st['mu1'], st['rs1'], q[8].detach(), dR2, dR1, galloc(o + 8), galloc(o + 9), dx_cast=G1, cast_scale=mask0)
         del G2, dO2, dQKV2, dV
         # ---- temporal
-        G1 = E(M, D)
-        ops.scale_cast(mode, dR1, mask0, G1)
         dPj = E(M, D)
         ops.gemm_nt(mode, G1, Wt(q[6]), dPj, row_scale=dp['t'])
         linear_bwd(o + 6, G1, st['Pj'])
@@ -384,7 +387,9 @@ def run_backward(module, sv, params, d_mask, d_flags):
         ops.gemm_nt(mode, dQKV, Wt(q[2]), dU)
         linear_bwd(o + 2, dQKV, st['U'])
         dR0 = E(M, D, dtype=f32)
-        ops.layernorm_bwd(mode, dU, st['R0'], st['mu0'], st['rs0'], q[0].detach(), dR1, dR0, galloc(o), galloc(o + 1))
+        G3_next = E(M, D)                      # operand of the next (lower) block's MLP backward, or of the patch-embed weight gradient
+        ops.layernorm_bwd(mode, dU, st['R0'], st['mu0'], st['rs0'], q[0].detach(), dR1, dR0, galloc(o), galloc(o + 1),
+                          dx_cast=G3_next, cast_scale=(sv['dps'][i - 1]['m'] if i > 0 else mask0))
         dR3 = dR0
         sv['blocks'][i] = None   # free this block's activations
         if module.grad_hook is not None:
@@ -404,8 +409,11 @@ def run_backward(module, sv, params, d_mask, d_flags):
     if sv['time_idx'] is not None:
         grads[2].zero_()
         grads[2][0].index_add_(0, sv['time_idx'], dtime_eff)
-    Gpe = E(M, D)
-    ops.scale_cast(mode, gX, mask0, Gpe)
+    if G3_next is not None:
+        Gpe = G3_next                          # bf16(gX * mask0) from block 0's LayerNorm backward
+    else:
+        Gpe = E(M, D)
+        ops.scale_cast(mode, gX, mask0, Gpe)
     dWpe = galloc(3)
     ops.gemm_tn(mode, Gpe, sv['A_pe'], dWpe.reshape(D, -1))
     grads[4].copy_(dtime_eff.sum(0))       # bias gradient = sum over all patch rows

@@ -77,13 +77,15 @@ def layernorm_fwd(mode, x, gamma, beta, out, mean=None, rstd=None, eps=1e-6):
     return out
 
 
-def layernorm_bwd(mode, dy, x, mean, rstd, gamma, dres, dx, dgamma=None, dbeta=None, accumulate=False):
+def layernorm_bwd(mode, dy, x, mean, rstd, gamma, dres, dx, dgamma=None, dbeta=None, accumulate=False, dx_cast=None, cast_scale=None):
+    """dx = dres + dLN(dy); dx_cast (mode dtype, optional) = dx * cast_scale[row]: the next input-gradient GEMM's operand."""
     rows, D = x.shape
     lib = L.lib()
     ws = workspace(lib.tcow_layernorm_bwd_workspace_bytes(D), x.device, 'ln')
     L.check(lib.tcow_layernorm_bwd(_stream(), mode, rows, D, dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), mean.data_ptr(),
                                    rstd.data_ptr(), gamma.data_ptr(), _p(dres), dres.stride(0) if dres is not None else 0, dx.data_ptr(),
-                                   dx.stride(0), _p(dgamma), _p(dbeta), int(accumulate), ws.data_ptr(), ws.numel()), 'tcow_layernorm_bwd')
+                                   dx.stride(0), _p(dgamma), _p(dbeta), int(accumulate), ws.data_ptr(), ws.numel(),
+                                   _p(dx_cast), dx_cast.stride(0) if dx_cast is not None else 0, _p(cast_scale)), 'tcow_layernorm_bwd')
     return dx
 
 

@@ -94,6 +94,13 @@ def test_layernorm_fwd_bwd(ops, cuda, mname, tol, rows, D):
     dx = torch.empty(rows, D, device=cuda); dg = torch.empty(D, device=cuda); db = torch.empty(D, device=cuda)
     ops.layernorm_bwd(mode, dy, x, mu, rs, w, dres, dx, dg, db)
     assert rel(dx, gx + dres.double()) < 1e-4 and rel(dg, gw) < 1e-4 and rel(db, gb) < 1e-4
+    # fused operand cast: the same gradient, row-scaled, in the mode's dtype == a separate tcow_scale_cast of dx
+    sc = torch.rand(rows, device=cuda, generator=g) + 0.5
+    for scale in (sc, None):
+        dx2 = torch.empty(rows, D, device=cuda); dxc = torch.empty(rows, D, device=cuda, dtype=dt); want = torch.empty(rows, D, device=cuda, dtype=dt)
+        ops.layernorm_bwd(mode, dy, x, mu, rs, w, dres, dx2, dx_cast=dxc, cast_scale=scale)
+        ops.scale_cast(mode, dx2, scale, want)
+        assert torch.equal(dx2, dx) and torch.equal(dxc, want)
 
 
 def _ref_attn(qkv, B, T, S, D, heads, ca, spatial):
