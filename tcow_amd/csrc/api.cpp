@@ -22,6 +22,8 @@ int tcow_gemm_tn_bf16(hipStream_t stream, int M, int N, int K, const bf16_t* dY,
 int tcow_gemm_tn_f32(hipStream_t stream, int M, int N, int K, const float* dY, long ldy, const float* X, long ldx, float* dW, long lddw, int accumulate,
                      float* slab, int splits);
 int tcow_tn_splits(int M, int N, int K, int tile_outputs);
+int tcow_tn_splits_256(int M, int N, int K);
+bool tcow_tn_use_256(int M, int N, int K);
 int tcow_launch_slab_reduce(hipStream_t stream, const float* slab, int nz, long slab_stride, long rows, long cols, float* out, long ldo, int accumulate,
                             const float* bias_part, int bias_nparts, int bias_n, float* bias_out);
 int tcow_launch_row_reduce(hipStream_t stream, const float* part, int nrows, long ld, int N, float* out, int accumulate);
@@ -95,8 +97,9 @@ static int gemm_nt_dispatch(void* stream, const tcow_gemm_args* a) {
 static const int kColsumParts = 64 * 24 * 2;   // >= nz * tiles_k * 2 partial rows of the fused bias gradient (nz <= 64, K <= 3072)
 
 long tcow_gemm_tn_workspace_bytes(int M, int N, int K) {
-    const int s_bf = tcow_tn_splits(M, N, K, 128), s_f = tcow_tn_splits(M, N, K, 64);
-    const int s = s_bf > s_f ? s_bf : s_f;
+    const int s_bf = tcow_tn_splits(M, N, K, 128), s_f = tcow_tn_splits(M, N, K, 64), s_big = tcow_tn_splits_256(M, N, K);
+    int s = s_bf > s_f ? s_bf : s_f;
+    if (s_big > s) s = s_big;
     return ((long)(s + 1) * N * K + (long)kColsumParts * N) * 4 + 256;
 }
 
@@ -109,7 +112,7 @@ int tcow_gemm_tn(void* stream, int dtype, int M, int N, int K, const void* dY, l
     float* part = slab + (size_t)(workspace_bytes / 4 - (long)kColsumParts * N - 8);
     int rc;
     if (dtype == TCOW_BF16) {
-        const int splits = tcow_tn_splits(M, N, K, 128);
+        const int splits = tcow_tn_use_256(M, N, K) ? tcow_tn_splits_256(M, N, K) : tcow_tn_splits(M, N, K, 128);
         int nz = 0, nparts = 0;
         const bool fuse_bias = bias_grad != nullptr && (long)splits * ((K + 127) / 128) * 2 <= kColsumParts;
         rc = tcow_gemm_tn_bf16((hipStream_t)stream, M, N, K, (const bf16_t*)dY, ldy, (const bf16_t*)X, ldx, slab, splits, &nz, fuse_bias ? part : nullptr, &nparts);

@@ -657,6 +657,167 @@ __global__ __launch_bounds__(256, MC == 32 ? 4 : 2) void gemm_tn_bf16_kernel(TnP
 
 }  // namespace
 
+// ---- 256 x 256 output tile, 8 waves (2 x 4, 128 x 64 each), 64 token rows per stage, two stages = 128 KiB, one workgroup per CU.
+// The 128-tile kernel above is bound by the global->LDS stream (a loads-only build takes 70 % of its time,
+// profiles/r01_gemm_variants.txt); this tile moves half the bytes per FLOP.  Workgroups = tiles x slices <= 256 (one round):
+// workgroup ids are handed out so that each XCD owns a contiguous range of (slice, tile) pairs, i.e. at most two token slices.
+constexpr int T2 = 256;
+constexpr int T2_MC = 64;
+constexpr int T2_ROWB = T2 * 2;                 // 512 B per LDS row
+constexpr int T2_TILE = T2_MC * T2_ROWB;        // 32 KiB per operand per stage
+constexpr int T2_STAGE = 2 * T2_TILE;
+constexpr int T2_LDS = 2 * T2_STAGE;            // 128 KiB
+
+__device__ __forceinline__ bf16x8 tr_frag512(const char* tile, int off0) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(tile + off0));
+    const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(tile + off0 + 4 * T2_ROWB));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 v = __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+namespace {
+__global__ __launch_bounds__(512, 2) void gemm_tn_bf16_256_kernel(TnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int ntile = p.tiles_n * p.tiles_k;
+    const int pid = xcd_remap(blockIdx.x, gridDim.x);
+    const int z = pid / ntile, tile = pid - z * ntile;
+    const int pn = tile / p.tiles_k, pk = tile - pn * p.tiles_k;
+    const int n0 = pn * T2, k0 = pk * T2;
+    const int mbeg = z * p.mps;
+    const int mend = (mbeg + p.mps < p.M) ? mbeg + p.mps : p.M;
+
+    // direct-to-LDS loads: a wave-load covers 2 tile rows x 512 B; wave w issues wave-loads 4w..4w+3 of each operand per stage
+    const int lrow = lane >> 5, cl = lane & 31;
+    const bf16_t* zero = reinterpret_cast<const bf16_t*>(&g_zero16);
+    int ycol[2], xcol[2];                                         // source column of this lane for even / odd wave-loads (row & 3 differs)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int r3 = (e << 1) | lrow;                            // (tile row) & 3 for wave-load q with q & 1 == e
+        const int sc = cl ^ (r3 << 2);
+        ycol[e] = n0 + sc * 8; xcol[e] = k0 + sc * 8;
+    }
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto issue = [&](int mt, int stage) {
+        char* sy = smem + stage * T2_STAGE;
+        char* sx = sy + T2_TILE;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = wave * 4 + j;
+            const int gm = mt + q * 2 + lrow;
+            const bool ok = gm < mend;
+            const bf16_t* ys = (ok && ycol[j & 1] < p.N) ? p.dY + (size_t)gm * p.ldy + ycol[j & 1] : zero;
+            const bf16_t* xs = (ok && xcol[j & 1] < p.K) ? p.X + (size_t)gm * p.ldx + xcol[j & 1] : zero;
+            glds16(ys, sy + q * 1024);
+            glds16(xs, sx + q * 1024);
+        }
+    };
+
+    // transpose-read addressing (constant over the loop)
+    const int q16 = lane & 15, g16 = (lane >> 4) & 1, hi = lane >> 5;
+    const int rr = 8 * hi + (q16 >> 2);
+    int y_off[4], x_off[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int cy = wm * 128 + i * 32 + 16 * g16 + 4 * (q16 & 3);
+        y_off[i] = rr * T2_ROWB + ((((cy >> 3) ^ ((q16 >> 2) << 2))) << 4) + (cy & 7) * 2;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int cx = wn * 64 + j * 32 + 16 * g16 + 4 * (q16 & 3);
+        x_off[j] = rr * T2_ROWB + ((((cx >> 3) ^ ((q16 >> 2) << 2))) << 4) + (cx & 7) * 2;
+    }
+
+    // column-sum duty (bias gradient): column cs_col of the dY tile, rows [cs_r0, cs_r1) of every stage; the tiles_k workgroups
+    // that share a dY tile split its 64 rows between them, and each between its two thread halves
+    const int cs_col = tid & 255;
+    const int cs_lo = pk * p.rows_per_pk, cs_hi = (cs_lo + p.rows_per_pk < T2_MC) ? cs_lo + p.rows_per_pk : T2_MC;
+    const int cs_mid = cs_lo + (cs_hi - cs_lo + 1) / 2;
+    const int cs_r0 = (tid >> 8) ? cs_mid : cs_lo, cs_r1 = (tid >> 8) ? cs_hi : (cs_mid < cs_hi ? cs_mid : cs_hi);
+    float colsum = 0.f;
+
+    const int nmt = (mend - mbeg + T2_MC - 1) / T2_MC;
+    if (nmt > 0) {
+        issue(mbeg, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    for (int it = 0; it < nmt; ++it) {
+        const int stage = it & 1;
+        if (it + 1 < nmt) issue(mbeg + (it + 1) * T2_MC, stage ^ 1);
+        const char* sy = smem + stage * T2_STAGE;
+        const char* sx = sy + T2_TILE;
+#pragma unroll
+        for (int ks = 0; ks < T2_MC / 16; ++ks) {
+            bf16x8 fy[4], fx[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fx[j] = tr_frag512(sx, x_off[j] + ks * 16 * T2_ROWB);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fy[i] = tr_frag512(sy, y_off[i] + ks * 16 * T2_ROWB);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fy[i], fx[j], acc[i][j], 0, 0, 0);
+        }
+        if (p.bias_part) {
+#pragma unroll 4
+            for (int r = cs_r0; r < cs_r1; ++r) {
+                const int off = r * T2_ROWB + ((((cs_col >> 3) ^ ((r & 3) << 2))) << 4) + (cs_col & 7) * 2;
+                colsum += bf2f(*reinterpret_cast<const bf16_t*>(sy + off));
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    if (p.bias_part && n0 + cs_col < p.N)
+        p.bias_part[(((size_t)z * p.tiles_k + pk) * 2 + (tid >> 8)) * p.N + n0 + cs_col] = colsum;
+
+    float* out = p.slab + (size_t)z * p.N * p.K;
+    const int l31 = lane & 31;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int gk = k0 + wn * 64 + j * 32 + l31;
+            if (gk >= p.K) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int gn = n0 + wm * 128 + i * 32 + crow32(r, hi);
+                if (gn < p.N) out[(size_t)gn * p.K + gk] = acc[i][j][r];
+            }
+        }
+}
+
+}  // namespace
+
+// slices for the 256-tile kernel: as many as fit one round of workgroups (<= 256), at least 256 token rows each
+int tcow_tn_splits_256(int M, int N, int K) {
+    const int tiles = cdiv(N, T2) * cdiv(K, T2);
+    int s = 256 / tiles;
+    const int max_s = M / 256;
+    if (s > max_s) s = max_s;
+    if (s > 64) s = 64;
+    if (s < 1) s = 1;
+    return s;
+}
+bool tcow_tn_use_256(int M, int N, int K) {
+    static const int on = [] { const char* e = getenv("TCOW_GEMM_TN_BIG"); return e ? atoi(e) : 1; }();
+    const int tiles = cdiv(N, T2) * cdiv(K, T2);
+    // (a 768 x 768 weight = 9 tiles x 28 slices still wins 12 % over the 128-tile kernel despite the larger slab fold)
+    return on && M >= 4096 && N >= 256 && K >= 256 && tiles >= (on == 2 ? 1 : 9) && tiles <= 256;
+}
+
 int tcow_gemm_tn_bf16(hipStream_t stream, int M, int N, int K, const bf16_t* dY, long ldy, const bf16_t* X, long ldx, float* slab, int splits,
                       int* nz_out, float* bias_part, int* bias_parts_out) {
     TCOW_CHECK_ARG(N % 8 == 0 && K % 8 == 0 && ldy % 8 == 0 && ldx % 8 == 0, "tcow_gemm_tn(bf16): N, K, ldy, ldx must be multiples of 8");
@@ -676,6 +837,16 @@ int tcow_gemm_tn_bf16(hipStream_t stream, int M, int N, int K, const bf16_t* dY,
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_bf16_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
         attr_set = true;
+    }
+    if (tcow_tn_use_256(M, N, K)) {
+        p.tiles_n = cdiv(N, T2); p.tiles_k = cdiv(K, T2);
+        p.rows_per_pk = cdiv(T2_MC, p.tiles_k);
+        if (bias_parts_out) *bias_parts_out = nz * p.tiles_k * 2;
+        static bool attr2 = false;
+        if (!attr2) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_bf16_256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS); attr2 = true; }
+        hipLaunchKernelGGL(gemm_tn_bf16_256_kernel, dim3(nz * p.tiles_n * p.tiles_k), dim3(512), T2_LDS, stream, p);
+        TCOW_CHECK_LAUNCH();
+        return TCOW_OK;
     }
     const dim3 grid(8 * cdiv(nz, 8) * p.tiles_n * p.tiles_k);
     if (mc == 32) hipLaunchKernelGGL(gemm_tn_bf16_kernel<32>, grid, dim3(256), 32768, stream, p);

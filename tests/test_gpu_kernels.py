@@ -55,7 +55,8 @@ def test_gemm_nt_epilogues(ops, cuda, mname, tol, M, K, N):
 
 
 @pytest.mark.parametrize('mname,tol', MODES)
-@pytest.mark.parametrize('M,N,K', [(5, 64, 64), (300, 192, 256), (2057, 48, 1024), (9030, 768, 768)])
+@pytest.mark.parametrize('M,N,K', [(5, 64, 64), (300, 192, 256), (2057, 48, 1024), (9030, 768, 768),
+                                   (9030, 2304, 768), (4200, 1032, 1288), (4099, 3072, 768)])     # the last three take the 256-tile kernel (incl. ragged tiles / last slice)
 def test_gemm_tn_weight_and_bias_grad(ops, cuda, mname, tol, M, N, K):
     mode, dt = _mode(ops, mname)
     g = torch.Generator(device='cuda').manual_seed(M)
