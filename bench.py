@@ -171,7 +171,7 @@ def main():
         pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_gemm_nt.json')
         if args.precision == 'bf16' and os.path.exists(pmc_path):      # from the separate rocprofv3 --pmc passes of this command (see the file)
             traffic = json.load(open(pmc_path)).get('traffic_bytes_per_launch')
-        roof = dict(bound='mfma', kernel='gemm_nt_bf16_kernel+gemm_nt_bf16_256_kernel' if args.precision == 'bf16' else 'gemm_f32_kernel',
+        roof = dict(bound='mfma', kernel='gemm_nt_bf16_320_kernel (+ gemm_nt_bf16_256_kernel, gemm_nt_bf16_kernel)' if args.precision == 'bf16' else 'gemm_f32_kernel',
                     achieved=ks['tflops'], peak=peak, unit='TFLOP/s', frac=ks['tflops'] / peak, traffic=traffic,
                     launches_per_step=ks['launches'] / args.steps, avg_launch_us=ks['avg_us'], flops_per_launch=ks['flops_per_launch'])
         step_tflops = 3.0 * Qs * fl['total'] / (ms_per_step * 1e-3) / 1e12

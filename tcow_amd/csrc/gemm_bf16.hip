@@ -369,6 +369,153 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_256_kernel(NtParams p) {
     }
 }
 
+// ---- 320 x 256 tile, 8 waves (2 x 4, 160 x 64 each), one workgroup per CU.  Why this odd shape: the global->LDS stream bounds
+// these GEMMs, and (a) 320 x 256 moves (320+256)/(320*256) = 1/142 B per FLOP (256-square 1/128, 128-square 1/64), (b) the path's
+// M = 27 090 token rows are 84.7 x 320, so N = 768 / 2304 / 3072 give 255 / 765 / 1020 tiles = 0.996 of 1 / 3 / 4 full rounds
+// over the 256 CUs (256-square: 318 tiles = 1.24 rounds for N = 768, which is why those GEMMs had to stay on the 128-square
+// kernel).  LDS: (320 + 256) rows x 128 B x 2 stages = 144 KiB.  160 accumulator registers per lane + two fragment sets.
+// (A 4-wave version with 160 x 128 per wave needs 320 accumulator registers: hipcc then shuttles accumulators between AGPRs and
+// VGPRs around every MFMA -- 480 v_accvgpr moves per K-slice.)
+constexpr int C_BM = 320, C_BN = 256;
+constexpr int C_ATILE = C_BM * 128;             // 40 KiB
+constexpr int C_WTILE = C_BN * 128;             // 32 KiB
+constexpr int C_STAGE = C_ATILE + C_WTILE;      // 72 KiB
+constexpr int C_LDS = 2 * C_STAGE;              // 144 KiB
+
+__global__ __launch_bounds__(512, 2) void gemm_nt_bf16_320_kernel(NtParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int nblk = p.tiles_m * p.tiles_n;
+    const int pid = xcd_remap(blockIdx.x, nblk);
+    const int pm = pid / p.tiles_n, pn = pid - pm * p.tiles_n;
+    const int m0 = pm * C_BM, n0 = pn * C_BN;
+
+    // wave w issues wave-loads 5w..5w+4 of A (8 rows x 128 B each) and 4w..4w+3 of W per stage; 32-bit element offsets from the
+    // tile's first row keep the nine addresses in nine registers
+    const bf16_t* a_base = p.A + (size_t)m0 * p.lda;
+    const bf16_t* w_base = p.W + (size_t)n0 * p.ldw;
+    uint32_t a_src[5], w_src[4];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int r = (wave * 5 + j) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        const int rr = m0 + r < p.M ? r : p.M - 1 - m0;
+        a_src[j] = (uint32_t)(rr * p.lda + c * 8);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = (wave * 4 + j) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        const int rr = n0 + r < p.N ? r : p.N - 1 - n0;
+        w_src[j] = (uint32_t)(rr * p.ldw + c * 8);
+    }
+    f32x16 acc[5][2];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = p.K / BK;
+    auto issue = [&](int kt, int stage) {
+        char* sa = smem + stage * C_STAGE;
+        char* sw = sa + C_ATILE;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) glds16(a_base + a_src[j] + (size_t)kt * BK, sa + (wave * 5 + j) * 1024);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16(w_base + w_src[j] + (size_t)kt * BK, sw + (wave * 4 + j) * 1024);
+    };
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(LDS_PTR(char))smem;
+    uint32_t a_ad[4], w_ad[4];
+    {
+        const int ra = wm * 160 + l31, rw = wn * 64 + l31;       // rows 32 apart share the swizzle ((r>>1)&7)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            a_ad[ks] = lds0 + ra * 128 + (((2 * ks + hi) ^ ((ra >> 1) & 7)) << 4);
+            w_ad[ks] = lds0 + C_ATILE + rw * 128 + (((2 * ks + hi) ^ ((rw >> 1) & 7)) << 4);
+        }
+    }
+    u32x4 fa[2][5], fw[2][2];
+#define TCOW_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
+#define TCOW_READ_FRAGS(buf, ks, so)                                                                        \
+    do {                                                                                                    \
+        const uint32_t aa = a_ad[ks] + (so), ww = w_ad[ks] + (so);                                          \
+        TCOW_DSR(fw[buf][0], ww, 0); TCOW_DSR(fw[buf][1], ww, 4096);                                        \
+        TCOW_DSR(fa[buf][0], aa, 0); TCOW_DSR(fa[buf][1], aa, 4096); TCOW_DSR(fa[buf][2], aa, 8192);        \
+        TCOW_DSR(fa[buf][3], aa, 12288); TCOW_DSR(fa[buf][4], aa, 16384);                                   \
+    } while (0)
+#define TCOW_MFMA10(buf)                                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < 5; ++i)                                                                        \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                    \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[buf][i]), __builtin_bit_cast(bf16x8, fw[buf][j]), acc[i][j], 0, 0, 0)
+
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    TCOW_READ_FRAGS(0, 0, 0u);
+    for (int kt = 0; kt < nk; ++kt) {
+        const uint32_t so = (uint32_t)(kt & 1) * C_STAGE;
+        if (kt + 1 < nk) issue(kt + 1, (kt & 1) ^ 1);
+        TCOW_READ_FRAGS(1, 1, so);
+        asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        TCOW_MFMA10(0);
+        TCOW_READ_FRAGS(0, 2, so);
+        asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        TCOW_MFMA10(1);
+        TCOW_READ_FRAGS(1, 3, so);
+        asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        TCOW_MFMA10(0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        TCOW_MFMA10(1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < nk) TCOW_READ_FRAGS(0, 0, (uint32_t)((kt + 1) & 1) * C_STAGE);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#undef TCOW_DSR
+#undef TCOW_READ_FRAGS
+#undef TCOW_MFMA10
+
+    // ---- epilogue: every wave stages its 160 x 64 tile through a private 16 KiB LDS region, 64 rows at a time (the last pass 32),
+    // and writes full 64-column row segments.  No workgroup barrier: a wave's LDS operations execute in order.
+    // (explicit passes: a loop over the pass index that the optimizer declines to unroll would index acc[] dynamically -> scratch)
+    float* ct = reinterpret_cast<float*>(smem + wave * 16384);
+    const int c4 = (lane & 15) * 4;
+    const int gn = n0 + wn * 64 + c4;
+    const bool col_ok = gn < p.N;
+    const float4 b4 = (p.bias && col_ok) ? ld4(p.bias + gn) : make_float4(0.f, 0.f, 0.f, 0.f);
+    auto stage_band = [&](const f32x16 (&a)[2], int ii) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                ct[(ii * 32 + crow32(r, hi)) * 64 + j * 32 + l31] = a[j][r];
+    };
+    const int mrow = m0 + wm * 160 + (lane >> 4);
+    stage_band(acc[0], 0); stage_band(acc[1], 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (col_ok) epi_rows<16>(p, ct, 64, b4, mrow, lane >> 4, 4, c4, gn);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    stage_band(acc[2], 0); stage_band(acc[3], 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (col_ok) epi_rows<16>(p, ct, 64, b4, mrow + 64, lane >> 4, 4, c4, gn);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    stage_band(acc[4], 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (col_ok) epi_rows<8>(p, ct, 64, b4, mrow + 128, lane >> 4, 4, c4, gn);
+}
+
 __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(NtParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -474,6 +621,21 @@ int tcow_gemm_nt_bf16(hipStream_t stream, const tcow_gemm_args* a) {
         attr_set = true;
     }
     static const int big = [] { const char* e = getenv("TCOW_GEMM_BIG"); return e ? atoi(e) : 1; }();
+    static const int wide = [] { const char* e = getenv("TCOW_GEMM_320"); return e ? atoi(e) : 1; }();
+    {
+        // the 320 x 256 tile runs one workgroup per CU: take it when its tiles fill whole rounds of the 256 CUs
+        const long t320 = (long)cdiv(a->M, C_BM) * cdiv(a->N, C_BN);
+        const long rounds = (t320 + 255) / 256;
+        const bool fills = t320 * 100 >= rounds * 256 * 92;
+        if (wide && (wide == 2 || (fills && t320 >= 200))) {
+            p.tiles_m = cdiv(a->M, C_BM); p.tiles_n = cdiv(a->N, C_BN);
+            static bool attr5 = false;
+            if (!attr5) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_320_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, C_LDS); attr5 = true; }
+            hipLaunchKernelGGL(gemm_nt_bf16_320_kernel, dim3(p.tiles_m * p.tiles_n), dim3(512), C_LDS, stream, p);
+            TCOW_CHECK_LAUNCH();
+            return TCOW_OK;
+        }
+    }
     // the 256-square tile runs one workgroup per CU: it only pays when there are several full rounds of tiles (>= ~2.7 per CU)
     if (big && (long)cdiv(a->M, B_BM) * cdiv(a->N, B_BN) >= 700) {
         p.tiles_m = cdiv(a->M, B_BM); p.tiles_n = cdiv(a->N, B_BN);
