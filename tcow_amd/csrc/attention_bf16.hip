@@ -193,18 +193,33 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(SeqDesc sd, int nt, const b
 // Streaming variant for workgroup-shared sequences of ANY length: a workgroup owns 4 query tiles (one per wave) of one
 // (item, head) and walks the keys in chunks of 4 tiles (wave w loads K/V tile 4c+w of chunk c), 32 KiB of LDS -> 4
 // workgroups per CU.  K/V are re-read from L2 by the ceil(nt/4) workgroups of a sequence.
+// Work placement of the streaming kernels.  The workgroups that own different query (key) chunks of the SAME (sequence, head)
+// stream the same K / V (Q / dO) tiles, so they should run at the same time on the same XCD (private L2): workgroups are dispatched
+// round-robin over the 8 XCDs, so XCD x takes pairs x, x+8, ... and walks the chunks of one pair back to back.  (With the chunk in
+// blockIdx.y the sharers ran a whole grid row apart and every chunk re-read its K / V from HBM: FETCH_SIZE 2.3x the algorithmic bytes.)
+struct StreamWork { int pair, chunk; bool valid; };
+__device__ __forceinline__ StreamWork stream_work(int pairs, int nchunk) {
+    const int b = blockIdx.x, x = b & 7, k = b >> 3;
+    const int i = k / nchunk;
+    StreamWork w; w.chunk = k - i * nchunk; w.pair = 8 * i + x; w.valid = w.pair < pairs;
+    return w;
+}
+static inline int stream_grid(int pairs, int nchunk) { return 8 * ((pairs + 7) / 8) * nchunk; }
+
 __global__ __launch_bounds__(256) void attn_fwd_stream(SeqDesc sd, int nt, const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse) {
     __shared__ __attribute__((aligned(16))) char smem[8 * TILE_B];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
-    const int item = blockIdx.x / sd.heads, head = blockIdx.x - item * sd.heads;
+    const StreamWork sw_ = stream_work(sd.n_outer * sd.n_inner * sd.heads, (nt + 3) / 4);
+    if (!sw_.valid) return;
+    const int item = sw_.pair / sd.heads, head = sw_.pair - item * sd.heads;
     const long base = seq_base(sd, item);
     const long ld3 = 3L * sd.D, pse = sd.pos_stride * ld3;
     const bf16_t* qh = qkv + base * ld3 + head * ATT_HD;
     char* kt = smem;
     char* vt = smem + 4 * TILE_B;
-    const int qt = blockIdx.y * 4 + wave;
+    const int qt = sw_.chunk * 4 + wave;
     const bool active = qt < nt;
     const int q = 32 * qt + l31;
     const int qc = q < sd.L ? q : sd.L - 1;
@@ -217,7 +232,7 @@ __global__ __launch_bounds__(256) void attn_fwd_stream(SeqDesc sd, int nt, const
     float m = -1e30f, l = 0.f;
     const long klim = (long)32 * qt + 31 + sd.diag;
     const int kt_end = (!active) ? 0 : (klim >= (long)sd.L - 1 ? nt : (int)(klim / 32) + 1);
-    const long klim_wg = (long)32 * (blockIdx.y * 4 + 3) + 31 + sd.diag;          // last key tile any wave of this workgroup needs
+    const long klim_wg = (long)32 * (sw_.chunk * 4 + 3) + 31 + sd.diag;          // last key tile any wave of this workgroup needs
     const int kt_end_wg = klim_wg >= (long)sd.L - 1 ? nt : (int)(klim_wg / 32) + 1;
     for (int c0 = 0; c0 < kt_end_wg; c0 += 4) {
         __syncthreads();                                   // previous chunk fully consumed
@@ -510,7 +525,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_stream(SeqDesc sd, int nt, c
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
-    const int item = blockIdx.x / sd.heads, head = blockIdx.x - item * sd.heads;
+    const StreamWork sw_ = stream_work(sd.n_outer * sd.n_inner * sd.heads, (nt + 3) / 4);
+    if (!sw_.valid) return;
+    const int item = sw_.pair / sd.heads, head = sw_.pair - item * sd.heads;
     const long base = seq_base(sd, item);
     const long ld3 = 3L * sd.D, pse = sd.pos_stride * ld3, pso = sd.pos_stride * sd.D;
     const bf16_t* qh = qkv + base * ld3 + head * ATT_HD;
@@ -518,7 +535,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_stream(SeqDesc sd, int nt, c
     const float2* ldh = ld + ((size_t)item * sd.heads + head) * (nt * 32);
     char* qt_ = smem;
     char* dot_ = smem + 4 * TILE_B;
-    const int j = blockIdx.y * 4 + wave;
+    const int j = sw_.chunk * 4 + wave;
     const bool active = j < nt;
     const int key = 32 * j + l31;
     const int kc = key < sd.L ? key : sd.L - 1;
@@ -530,7 +547,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_stream(SeqDesc sd, int nt, c
     for (int r = 0; r < 16; ++r) { dk0[r] = 0.f; dk1[r] = 0.f; dv0[r] = 0.f; dv1[r] = 0.f; }
     const long qlo = (long)32 * j - sd.diag;                       // first query tile that can see this wave's keys
     const int i0 = qlo > 0 ? (int)(qlo / 32) : 0;
-    const long qlo_wg = (long)32 * (blockIdx.y * 4) - sd.diag;     // ... and any key of this workgroup
+    const long qlo_wg = (long)32 * (sw_.chunk * 4) - sd.diag;     // ... and any key of this workgroup
     const int c_start = qlo_wg > 0 ? (int)(qlo_wg / 32) & ~3 : 0;
     for (int c0 = c_start; c0 < nt; c0 += 4) {
         __syncthreads();
@@ -554,7 +571,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_stream(SeqDesc sd, int nt, co
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
-    const int item = blockIdx.x / sd.heads, head = blockIdx.x - item * sd.heads;
+    const StreamWork sw_ = stream_work(sd.n_outer * sd.n_inner * sd.heads, (nt + 3) / 4);
+    if (!sw_.valid) return;
+    const int item = sw_.pair / sd.heads, head = sw_.pair - item * sd.heads;
     const long base = seq_base(sd, item);
     const long ld3 = 3L * sd.D, pse = sd.pos_stride * ld3, pso = sd.pos_stride * sd.D;
     const bf16_t* qh = qkv + base * ld3 + head * ATT_HD;
@@ -562,7 +581,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_stream(SeqDesc sd, int nt, co
     const float2* ldh = ld + ((size_t)item * sd.heads + head) * (nt * 32);
     char* kt = smem;
     char* vt = smem + 4 * TILE_B;
-    const int qt = blockIdx.y * 4 + wave;
+    const int qt = sw_.chunk * 4 + wave;
     const bool active = qt < nt;
     const int q = 32 * qt + l31;
     const int qc = q < sd.L ? q : sd.L - 1;
@@ -576,7 +595,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_stream(SeqDesc sd, int nt, co
     for (int r = 0; r < 16; ++r) { dq0[r] = 0.f; dq1[r] = 0.f; }
     const long klim = (long)32 * qt + 31 + sd.diag;
     const int kt_end = (!active) ? 0 : (klim >= (long)sd.L - 1 ? nt : (int)(klim / 32) + 1);
-    const long klim_wg = (long)32 * (blockIdx.y * 4 + 3) + 31 + sd.diag;
+    const long klim_wg = (long)32 * (sw_.chunk * 4 + 3) + 31 + sd.diag;
     const int kt_end_wg = klim_wg >= (long)sd.L - 1 ? nt : (int)(klim_wg / 32) + 1;
     for (int c0 = 0; c0 < kt_end_wg; c0 += 4) {
         __syncthreads();
@@ -613,7 +632,7 @@ int tcow_attn_mfma_fwd(hipStream_t st, const SeqDesc& d, bool shared, const void
     const int nt = (d.L + 31) / 32;
     const int pairs = d.n_outer * d.n_inner * d.heads;
     if ((shared && shared_variant() == 2) || (!shared && nt > 2)) {
-        hipLaunchKernelGGL(attn_fwd_stream, dim3(pairs, cdiv(nt, 4)), dim3(256), 0, st, d, nt, (const bf16_t*)qkv, (bf16_t*)out, lse);
+        hipLaunchKernelGGL(attn_fwd_stream, dim3(stream_grid(pairs, cdiv(nt, 4))), dim3(256), 0, st, d, nt, (const bf16_t*)qkv, (bf16_t*)out, lse);
     } else if (shared) {
         const int lds = 2 * nt * TILE_B;
         set_lds_attr(attn_fwd_mfma<true>, lds);
@@ -649,9 +668,9 @@ int tcow_attn_mfma_bwd(hipStream_t st, const SeqDesc& d, bool shared, const void
     hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3(blocks), dim3(256), 0, st, d, nt * 32, (const bf16_t*)out, (const bf16_t*)dout, lse, ld);
     TCOW_CHECK_LAUNCH();
     if ((shared && shared_variant() == 2) || (!shared && nt > 2)) {
-        hipLaunchKernelGGL(attn_bwd_dkv_stream, dim3(pairs, cdiv(nt, 4)), dim3(256), 0, st, d, nt, (const bf16_t*)qkv, (const bf16_t*)dout, ld, (bf16_t*)dqkv);
+        hipLaunchKernelGGL(attn_bwd_dkv_stream, dim3(stream_grid(pairs, cdiv(nt, 4))), dim3(256), 0, st, d, nt, (const bf16_t*)qkv, (const bf16_t*)dout, ld, (bf16_t*)dqkv);
         TCOW_CHECK_LAUNCH();
-        hipLaunchKernelGGL(attn_bwd_dq_stream, dim3(pairs, cdiv(nt, 4)), dim3(256), 0, st, d, nt, (const bf16_t*)qkv, (const bf16_t*)dout, ld, (bf16_t*)dqkv);
+        hipLaunchKernelGGL(attn_bwd_dq_stream, dim3(stream_grid(pairs, cdiv(nt, 4))), dim3(256), 0, st, d, nt, (const bf16_t*)qkv, (const bf16_t*)dout, ld, (bf16_t*)dqkv);
     } else if (shared) {
         const int lds = 2 * nt * TILE_B;
         set_lds_attr(attn_bwd_dkv_mfma<true>, lds); set_lds_attr(attn_bwd_dq_mfma<true>, lds);
