@@ -45,6 +45,8 @@ extern "C" {
 #define TCOW_ACT_NONE 0
 #define TCOW_ACT_GELU 1      /* C = GELU_erf(v); optionally also stores v (pre-activation) to aux         */
 #define TCOW_ACT_DGELU 2     /* C = v * GELU_erf'(aux)   (backward of the fc1 activation)                 */
+#define TCOW_ACT_GELU_DSAVE 3 /* C = GELU_erf(v) and aux = GELU_erf'(v): the erf / exp are shared, so the      */
+#define TCOW_ACT_MUL_AUX 4   /* backward is C = v * aux -- one multiply instead of a second erf + exp per element */
 
 /* ABI version (bumped on any signature change) and last error text of the calling thread. */
 int tcow_version(void);
@@ -59,7 +61,9 @@ const char* tcow_last_error(void);
  * scaling (vit_utils.py:139-154) are fused through `resid` / `row_scale`.
  * A, W: `dtype` elements, K-contiguous rows (lda, ldw in elements, multiples of 8; K % 8 == 0).
  * C: `dtype` elements, or f32 when out_f32 != 0.  resid: f32 [M, ldr] or NULL (may alias C when out_f32).
- * aux: `dtype` [M, ldaux]; written for TCOW_ACT_GELU when non-NULL, read for TCOW_ACT_DGELU.
+ * aux: `dtype` [M, ldaux]; written for TCOW_ACT_GELU (when non-NULL) and TCOW_ACT_GELU_DSAVE, read for TCOW_ACT_DGELU
+ * and TCOW_ACT_MUL_AUX.  In bf16 mode erf is evaluated with Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below
+ * the bf16 rounding of the result); the f32 mode uses erff.
  */
 typedef struct {
     int M, N, K;

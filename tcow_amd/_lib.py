@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libtcow_hip.so')
 
 TCOW_F32, TCOW_BF16 = 0, 1
-ACT_NONE, ACT_GELU, ACT_DGELU = 0, 1, 2
+ACT_NONE, ACT_GELU, ACT_DGELU, ACT_GELU_DSAVE, ACT_MUL_AUX = 0, 1, 2, 3, 4
 
 
 class TcowError(RuntimeError):

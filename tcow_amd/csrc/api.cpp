@@ -84,7 +84,8 @@ static int gemm_nt_dispatch(void* stream, const tcow_gemm_args* a) {
     TCOW_CHECK_ARG(a != nullptr, "tcow_gemm_nt: null args");
     TCOW_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0, "tcow_gemm_nt: bad shape M=%d N=%d K=%d", a->M, a->N, a->K);
     TCOW_CHECK_ARG(a->A && a->W && a->C, "tcow_gemm_nt: null operand");
-    TCOW_CHECK_ARG(a->act != TCOW_ACT_DGELU || a->aux, "tcow_gemm_nt: TCOW_ACT_DGELU needs aux");
+    TCOW_CHECK_ARG((a->act != TCOW_ACT_DGELU && a->act != TCOW_ACT_GELU_DSAVE && a->act != TCOW_ACT_MUL_AUX) || a->aux, "tcow_gemm_nt: this activation needs aux");
+    TCOW_CHECK_ARG(a->act >= TCOW_ACT_NONE && a->act <= TCOW_ACT_MUL_AUX, "tcow_gemm_nt: unknown activation %d", a->act);
     if (a->dtype == TCOW_BF16) return tcow_gemm_nt_bf16((hipStream_t)stream, a);
     if (a->dtype == TCOW_F32) {
         TCOW_CHECK_ARG(a->out_f32 || true, "unreachable");

@@ -100,6 +100,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(F32Params p) {
             x = gelu_erf(x);
         } else if (p.act == TCOW_ACT_DGELU) {
             x *= gelu_erf_grad(p.aux[(size_t)gm * p.ldaux + gn]);
+        } else if (p.act == TCOW_ACT_GELU_DSAVE) {
+            p.aux[(size_t)gm * p.ldaux + gn] = gelu_erf_grad(x);
+            x = gelu_erf(x);
+        } else if (p.act == TCOW_ACT_MUL_AUX) {
+            x *= p.aux[(size_t)gm * p.ldaux + gn];
         }
         if (p.resid) x += p.resid[(size_t)gm * p.ldr + gn];
         reinterpret_cast<float*>(p.C)[(size_t)gm * p.ldc + gn] = x;

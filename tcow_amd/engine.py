@@ -17,7 +17,7 @@ The backward below is the hand-derived adjoint of exactly this schedule; nothing
 import torch
 
 from . import ops
-from .ops import ACT_DGELU, ACT_GELU
+from .ops import ACT_GELU, ACT_GELU_DSAVE, ACT_MUL_AUX
 
 _BLOCK_PARAMS = 20   # parameters per block in QueryMaskTracker.param_list()
 
@@ -206,7 +206,8 @@ def run_forward(module, rgb, qm, params, save):
         Hd = fc1_w.shape[0]
         pre = E(M, Hd) if save else None
         H = E(M, Hd)
-        ops.gemm_nt(mode, Wn, W(q[16]), H, bias=fc1_b, act=ACT_GELU, aux=pre)
+        # training saves GELU'(pre-activation) instead of the pre-activation: the backward is then one multiply per element
+        ops.gemm_nt(mode, Wn, W(q[16]), H, bias=fc1_b, act=ACT_GELU_DSAVE if save else ACT_GELU, aux=pre)
         R3 = E(M, D, dtype=f32) if save else R2
         ops.gemm_nt(mode, H, W(q[18]), R3, bias=fc2_b, row_scale=dp['m'], resid=R2)
         if save:
@@ -349,7 +350,7 @@ def run_backward(module, sv, params, d_mask, d_flags):
             G3 = E(M, D)
             ops.scale_cast(mode, dR3, dp['m'], G3)
         dpre = E(M, Hd)
-        ops.gemm_nt(mode, G3, Wt(q[18]), dpre, act=ACT_DGELU, aux=st['pre'])
+        ops.gemm_nt(mode, G3, Wt(q[18]), dpre, act=ACT_MUL_AUX, aux=st['pre'])
         linear_bwd(o + 18, G3, st['H'])
         dWn = E(M, D)
         ops.gemm_nt(mode, dpre, Wt(q[16]), dWn)

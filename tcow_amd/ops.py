@@ -11,7 +11,7 @@ import torch
 from . import _lib as L
 
 F32, BF16 = L.TCOW_F32, L.TCOW_BF16
-ACT_NONE, ACT_GELU, ACT_DGELU = L.ACT_NONE, L.ACT_GELU, L.ACT_DGELU
+ACT_NONE, ACT_GELU, ACT_DGELU, ACT_GELU_DSAVE, ACT_MUL_AUX = L.ACT_NONE, L.ACT_GELU, L.ACT_DGELU, L.ACT_GELU_DSAVE, L.ACT_MUL_AUX
 
 
 def tdtype(mode):

@@ -52,6 +52,13 @@ def test_gemm_nt_epilogues(ops, cuda, mname, tol, M, K, N):
     dg = torch.autograd.grad(F.gelu(x).sum(), x)[0]
     C = ops.gemm_nt(mode, A, W, torch.empty(M, N, device=cuda, dtype=dt), act=ops.ACT_DGELU, aux=pre)
     assert rel(C, ref0 * dg) < tol
+    # the training pair: forward saves GELU'(v) next to GELU(v), backward multiplies by it
+    C = ops.gemm_nt(mode, A, W, torch.empty(M, N, device=cuda, dtype=dt), bias=bias, act=ops.ACT_GELU_DSAVE, aux=aux)
+    xv = (ref0 + bias.double()).requires_grad_(True)
+    dgv = torch.autograd.grad(F.gelu(xv).sum(), xv)[0]
+    assert rel(C, F.gelu(xv.detach())) < tol and rel(aux, dgv) < tol
+    C = ops.gemm_nt(mode, A, W, torch.empty(M, N, device=cuda, dtype=dt), act=ops.ACT_MUL_AUX, aux=pre)
+    assert rel(C, ref0 * pre.double()) < tol
 
 
 @pytest.mark.parametrize('mname,tol', MODES)
