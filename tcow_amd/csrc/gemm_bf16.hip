@@ -83,31 +83,47 @@ __device__ __forceinline__ void gelu_both4(float4 v, float4& g, float4& d) {
 
 struct EpiRow { float4 ext; float rs; };
 
+// Epilogue configuration: ACT / ROWS < 0 = decided at run time from NtParams (the generic kernels); >= 0 = compile-time constants
+// (ROWS bit 0 = row_scale present, bit 1 = resid present).  The specialised instantiations keep the epilogue of the 320-tile
+// kernel small: with every activation inlined behind run-time branches its unrolled row loops were ~100 KB of code.
+template <int ACT, int ROWS> struct EpiCfg {
+    static constexpr bool kStatic = ACT >= 0 && ROWS >= 0;
+    static constexpr bool kRowOps = ROWS > 0 || ACT == TCOW_ACT_DGELU || ACT == TCOW_ACT_MUL_AUX;
+    static __device__ __forceinline__ int act(const NtParams& p) { return ACT < 0 ? p.act : ACT; }
+    static __device__ __forceinline__ bool rs(const NtParams& p) { return ROWS < 0 ? p.row_scale != nullptr : (ROWS & 1) != 0; }
+    static __device__ __forceinline__ bool res(const NtParams& p) { return ROWS < 0 ? p.resid != nullptr : (ROWS & 2) != 0; }
+};
+typedef EpiCfg<-1, -1> EpiAny;
+
+template <typename E = EpiAny>
 __device__ __forceinline__ EpiRow epi_row_fetch(const NtParams& p, int gm, int gn, bool ok) {
     EpiRow o; o.ext = make_float4(0.f, 0.f, 0.f, 0.f); o.rs = 1.0f;
     if (ok && gm < p.M) {
-        if (p.row_scale) o.rs = p.row_scale[gm];
-        if (p.resid) o.ext = ld4(p.resid + (size_t)gm * p.ldr + gn);
-        else if (p.act == TCOW_ACT_DGELU || p.act == TCOW_ACT_MUL_AUX) o.ext = ld4(p.aux + (size_t)gm * p.ldaux + gn);
+        if (E::rs(p)) o.rs = p.row_scale[gm];
+        if (E::res(p)) o.ext = ld4(p.resid + (size_t)gm * p.ldr + gn);
+        else if (E::act(p) == TCOW_ACT_DGELU || E::act(p) == TCOW_ACT_MUL_AUX) o.ext = ld4(p.aux + (size_t)gm * p.ldaux + gn);
     }
     return o;
 }
 
+template <typename E = EpiAny>
 __device__ __forceinline__ void epi_row_apply(const NtParams& p, const EpiRow& o, float4 v, float4 b4, int gm, int gn) {
-    v.x = (v.x + b4.x) * o.rs; v.y = (v.y + b4.y) * o.rs; v.z = (v.z + b4.z) * o.rs; v.w = (v.w + b4.w) * o.rs;
-    if (p.act == TCOW_ACT_GELU) {
+    v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+    if (E::rs(p)) { v.x *= o.rs; v.y *= o.rs; v.z *= o.rs; v.w *= o.rs; }
+    const int act = E::act(p);
+    if (act == TCOW_ACT_GELU) {
         if (p.aux) st4(p.aux + (size_t)gm * p.ldaux + gn, v);
         v = gelu4(v);
-    } else if (p.act == TCOW_ACT_DGELU) {
+    } else if (act == TCOW_ACT_DGELU) {
         v = dgelu4(v, o.ext);
-    } else if (p.act == TCOW_ACT_GELU_DSAVE) {
+    } else if (act == TCOW_ACT_GELU_DSAVE) {
         float4 g, d; gelu_both4(v, g, d);
         st4(p.aux + (size_t)gm * p.ldaux + gn, d);
         v = g;
-    } else if (p.act == TCOW_ACT_MUL_AUX) {
+    } else if (act == TCOW_ACT_MUL_AUX) {
         v.x *= o.ext.x; v.y *= o.ext.y; v.z *= o.ext.z; v.w *= o.ext.w;
     }
-    if (p.resid) { v.x += o.ext.x; v.y += o.ext.y; v.z += o.ext.z; v.w += o.ext.w; }
+    if (E::res(p)) { v.x += o.ext.x; v.y += o.ext.y; v.z += o.ext.z; v.w += o.ext.w; }
     if (p.out_f32) st4(reinterpret_cast<float*>(p.C) + (size_t)gm * p.ldc + gn, v);
     else st4(reinterpret_cast<bf16_t*>(p.C) + (size_t)gm * p.ldc + gn, v);
 }
@@ -116,25 +132,25 @@ __device__ __forceinline__ void epi_row_apply(const NtParams& p, const EpiRow& o
 // load result that sits behind younger stores -- a loop that mixes "fetch next row operands" with "store this row" therefore
 // waits for every store to complete before the next one (measured: 27 us per 256x256 tile).  So: without row operands the loop
 // contains no loads at all; with row operands ALL of them are fetched up front and the loop only stores.
-template <int NIT = 16>
+template <int NIT = 16, typename E = EpiAny>
 __device__ __forceinline__ void epi_rows(const NtParams& p, const float* ct, int ct_ld, float4 b4, int gm_first, int row_first, int row_step, int c4, int gn) {
-    const bool rowops = p.row_scale != nullptr || p.resid != nullptr || p.act == TCOW_ACT_DGELU || p.act == TCOW_ACT_MUL_AUX;
+    const bool rowops = E::rs(p) || E::res(p) || E::act(p) == TCOW_ACT_DGELU || E::act(p) == TCOW_ACT_MUL_AUX;
     if (!rowops) {
         EpiRow o; o.ext = make_float4(0.f, 0.f, 0.f, 0.f); o.rs = 1.0f;
 #pragma unroll 1
         for (int it = 0; it < NIT; ++it) {
             const int gm = gm_first + it * row_step;
             if (gm >= p.M) break;
-            epi_row_apply(p, o, *reinterpret_cast<const float4*>(ct + (row_first + it * row_step) * ct_ld + c4), b4, gm, gn);
+            epi_row_apply<E>(p, o, *reinterpret_cast<const float4*>(ct + (row_first + it * row_step) * ct_ld + c4), b4, gm, gn);
         }
     } else {
         EpiRow o[NIT];
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) o[it] = epi_row_fetch(p, gm_first + it * row_step, gn, true);
+        for (int it = 0; it < NIT; ++it) o[it] = epi_row_fetch<E>(p, gm_first + it * row_step, gn, true);
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int gm = gm_first + it * row_step;
-            if (gm < p.M) epi_row_apply(p, o[it], *reinterpret_cast<const float4*>(ct + (row_first + it * row_step) * ct_ld + c4), b4, gm, gn);
+            if (gm < p.M) epi_row_apply<E>(p, o[it], *reinterpret_cast<const float4*>(ct + (row_first + it * row_step) * ct_ld + c4), b4, gm, gn);
         }
     }
 }
@@ -411,6 +427,7 @@ constexpr int C_WTILE = C_BN * 128;             // 32 KiB
 constexpr int C_STAGE = C_ATILE + C_WTILE;      // 72 KiB
 constexpr int C_LDS = 2 * C_STAGE;              // 144 KiB
 
+template <typename E>
 __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_320_kernel(NtParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -532,17 +549,53 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_320_kernel(NtParams p) {
                 ct[(ii * 32 + crow32(r, hi)) * 64 + j * 32 + l31] = a[j][r];
     };
     const int mrow = m0 + wm * 160 + (lane >> 4);
-    stage_band(acc[0], 0); stage_band(acc[1], 1);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (col_ok) epi_rows<16>(p, ct, 64, b4, mrow, lane >> 4, 4, c4, gn);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    stage_band(acc[2], 0); stage_band(acc[3], 1);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (col_ok) epi_rows<16>(p, ct, 64, b4, mrow + 64, lane >> 4, 4, c4, gn);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    stage_band(acc[4], 0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (col_ok) epi_rows<8>(p, ct, 64, b4, mrow + 128, lane >> 4, 4, c4, gn);
+    constexpr bool kRowOps = E::kStatic && E::kRowOps;
+    if constexpr (kRowOps) {
+        // Row operands (residual / GELU' / row scale) of band b+1 are requested BEFORE band b is stored: their latency overlaps the
+        // LDS staging and the stores of the band in front, and -- vmcnt retiring in order -- no load ever queues behind a store.
+        // Pipeline unit = one 32-row accumulator band (8 row groups per lane), two operand sets and the two halves of the LDS region
+        // in rotation; registers at the peak: 128 accumulators + 2 x 8 row operands.
+        EpiRow oa[8], ob[8];
+        auto fetch = [&](EpiRow* o, int u) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) o[it] = epi_row_fetch<E>(p, mrow + u * 32 + it * 4, gn, col_ok);
+        };
+        auto apply = [&](const EpiRow* o, int u, int half) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int gm = mrow + u * 32 + it * 4;
+                if (col_ok && gm < p.M)
+                    epi_row_apply<E>(p, o[it], *reinterpret_cast<const float4*>(ct + (half * 32 + (lane >> 4) + it * 4) * 64 + c4), b4, gm, gn);
+            }
+        };
+        fetch(oa, 0); stage_band(acc[0], 0);
+        fetch(ob, 1); stage_band(acc[1], 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        apply(oa, 0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        fetch(oa, 2); stage_band(acc[2], 0);
+        apply(ob, 1, 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        fetch(ob, 3); stage_band(acc[3], 1);
+        apply(oa, 2, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        fetch(oa, 4); stage_band(acc[4], 0);
+        apply(ob, 3, 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        apply(oa, 4, 0);
+    } else {
+        stage_band(acc[0], 0); stage_band(acc[1], 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (col_ok) epi_rows<16, E>(p, ct, 64, b4, mrow, lane >> 4, 4, c4, gn);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        stage_band(acc[2], 0); stage_band(acc[3], 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (col_ok) epi_rows<16, E>(p, ct, 64, b4, mrow + 64, lane >> 4, 4, c4, gn);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        stage_band(acc[4], 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (col_ok) epi_rows<8, E>(p, ct, 64, b4, mrow + 128, lane >> 4, 4, c4, gn);
+    }
 }
 
 __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(NtParams p) {
@@ -658,9 +711,27 @@ int tcow_gemm_nt_bf16(hipStream_t stream, const tcow_gemm_args* a) {
         const bool fills = t320 * 100 >= rounds * 256 * 92;
         if (wide && (wide == 2 || (fills && t320 >= 200))) {
             p.tiles_m = cdiv(a->M, C_BM); p.tiles_n = cdiv(a->N, C_BN);
+            // epilogue specialisations for the combinations the path uses; anything else takes the run-time-configured kernel
+            typedef void (*Kern)(NtParams);
+            const int rows = (a->row_scale ? 1 : 0) | (a->resid ? 2 : 0);
+            Kern k = gemm_nt_bf16_320_kernel<EpiAny>;
+            if (a->act == TCOW_ACT_NONE && rows == 0) k = gemm_nt_bf16_320_kernel<EpiCfg<TCOW_ACT_NONE, 0>>;
+            else if (a->act == TCOW_ACT_NONE && rows == 1) k = gemm_nt_bf16_320_kernel<EpiCfg<TCOW_ACT_NONE, 1>>;
+            else if (a->act == TCOW_ACT_NONE && rows == 2) k = gemm_nt_bf16_320_kernel<EpiCfg<TCOW_ACT_NONE, 2>>;
+            else if (a->act == TCOW_ACT_NONE && rows == 3) k = gemm_nt_bf16_320_kernel<EpiCfg<TCOW_ACT_NONE, 3>>;
+            else if (a->act == TCOW_ACT_GELU_DSAVE && rows == 0) k = gemm_nt_bf16_320_kernel<EpiCfg<TCOW_ACT_GELU_DSAVE, 0>>;
+            else if (a->act == TCOW_ACT_MUL_AUX && rows == 0) k = gemm_nt_bf16_320_kernel<EpiCfg<TCOW_ACT_MUL_AUX, 0>>;
+            else if (a->act == TCOW_ACT_GELU && rows == 0) k = gemm_nt_bf16_320_kernel<EpiCfg<TCOW_ACT_GELU, 0>>;
             static bool attr5 = false;
-            if (!attr5) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_320_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, C_LDS); attr5 = true; }
-            hipLaunchKernelGGL(gemm_nt_bf16_320_kernel, dim3(p.tiles_m * p.tiles_n), dim3(512), C_LDS, stream, p);
+            if (!attr5) {
+                const Kern all[] = {gemm_nt_bf16_320_kernel<EpiAny>, gemm_nt_bf16_320_kernel<EpiCfg<TCOW_ACT_NONE, 0>>, gemm_nt_bf16_320_kernel<EpiCfg<TCOW_ACT_NONE, 1>>,
+                                    gemm_nt_bf16_320_kernel<EpiCfg<TCOW_ACT_NONE, 2>>, gemm_nt_bf16_320_kernel<EpiCfg<TCOW_ACT_NONE, 3>>,
+                                    gemm_nt_bf16_320_kernel<EpiCfg<TCOW_ACT_GELU_DSAVE, 0>>, gemm_nt_bf16_320_kernel<EpiCfg<TCOW_ACT_MUL_AUX, 0>>,
+                                    gemm_nt_bf16_320_kernel<EpiCfg<TCOW_ACT_GELU, 0>>};
+                for (Kern kk : all) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kk), hipFuncAttributeMaxDynamicSharedMemorySize, C_LDS);
+                attr5 = true;
+            }
+            hipLaunchKernelGGL(k, dim3(p.tiles_m * p.tiles_n), dim3(512), C_LDS, stream, p);
             TCOW_CHECK_LAUNCH();
             return TCOW_OK;
         }
