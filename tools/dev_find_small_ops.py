@@ -19,11 +19,9 @@ def step(i):
 for i in range(3): step(i)
 torch.cuda.synchronize()
 from torch.profiler import profile, ProfilerActivity
-with profile(activities=[ProfilerActivity.CPU], with_stack=True, record_shapes=True) as prof:
+with profile(activities=[ProfilerActivity.CPU]) as prof:
     step(3); torch.cuda.synchronize()
-cnt = collections.Counter()
-for ev in prof.events():
-    if ev.name in ('aten::fill_', 'aten::zero_', 'aten::copy_', 'aten::zeros', 'aten::ones', 'aten::full'):
-        st = [s for s in ev.stack if 'tcow_amd' in s or 'bench' in s or 'tools/' in s]
-        cnt[(ev.name, st[0] if st else (ev.stack[0] if ev.stack else '?'), str(ev.input_shapes)[:60])] += 1
-for (k, v) in cnt.most_common(40): print(v, k)
+ka = prof.key_averages()
+rows = sorted(ka, key=lambda e: -e.count)
+for e in rows[:45]:
+    print(f'{e.count:5d}  {e.key[:60]:60s} cpu_total {e.cpu_time_total/1e3:8.2f} ms')
