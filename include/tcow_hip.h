@@ -225,6 +225,27 @@ int tcow_mask_loss(void* stream, const tcow_mask_loss_args* args);
  * |output & target|, |output | target|} with output = logit > 0, target = value > 0.5 (int32 [n_frames][3]). */
 int tcow_iou_counts(void* stream, const float* logits, const float* target, long n_frames, long frame_len, int* counts);
 
+/* ------------------------------------------------------------------------------------------- query / target masks (caller row P)
+ * data/data_utils.py:414-510 for all (b, q, t) at once.  segm (B,1,T,H,W) u8 = visible instance id + 1 (0 = background),
+ * div_segm (B,M,T,H,W) u8 = amodal mask per instance; query_idx [B*Q] = queried instance; front_idx / cont_idx [B*Q*T] = instance
+ * of the frontmost occluder / outermost container of that frame or -1 (decided beforehand from the occlusion fractions and the
+ * containment DAG, data_utils.py:455-492).  Writes query_mask (B,Q,1,T,H,W) f32 (visible pixels at frame query_time only, :431),
+ * target_mask (B,Q,3,T,H,W) f32 (:441-492), snitch_occl_by_ptr (B,Q,1,T,H,W) u8 (:435-437) and counts [1 + 2*Q] int32:
+ * counts[0] = number of amodal snitch pixels (the class-balancing statistic of loss.py:100), counts[1+2q] / counts[2+2q] != 0
+ * iff query q has a non-empty query mask / target (the checks of pipeline.py:149-154).  H*W must be a multiple of 16. */
+int tcow_build_masks(void* stream, int B, int Q, int M, int T, long HW, int query_time, const unsigned char* segm,
+                     const unsigned char* div_segm, const int* query_idx, const int* front_idx, const int* cont_idx,
+                     float* query_mask, float* target_mask, unsigned char* snitch_occl_by_ptr, int* counts);
+
+/* Snitch pixel weights (loss.py:85-148) times the frame weights (loss.py:55-83): weights[f,i] = frame_w[f] * class-balance factor
+ * (from *pos_count amodal pixels out of n_seq*T*H*W) * 2 on occluded snitch pixels * hard_negative_factor on the band between the
+ * target and its k x k box dilation, k = odd(int(sqrt(H*W)/12)).  target_ch0 addresses channel 0 of a (n_seq,3,T,H,W) tensor
+ * (sequence stride in elements); weights is dense (n_seq,T,H,W). */
+size_t tcow_snitch_weights_workspace_bytes(long n_frames, int H, int W);
+int tcow_snitch_weights(void* stream, long n_seq, int T, int H, int W, const float* target_ch0, long target_seq_stride,
+                        const unsigned char* snitch_occl_by_ptr, const float* frame_w, const int* pos_count, int class_balancing,
+                        float hard_negative_factor, float* weights, void* ws, size_t ws_bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -79,6 +79,9 @@ SIGNATURES = {
     'tcow_mask_loss_workspace_bytes': (ctypes.c_size_t, [_l, _l]),
     'tcow_mask_loss': (_i, [_vp, ctypes.POINTER(MaskLossArgs)]),
     'tcow_iou_counts': (_i, [_vp, _vp, _vp, _l, _l, _vp]),
+    'tcow_build_masks': (_i, [_vp, _i, _i, _i, _i, _l, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'tcow_snitch_weights_workspace_bytes': (ctypes.c_size_t, [_l, _i, _i]),
+    'tcow_snitch_weights': (_i, [_vp, _l, _i, _i, _i, _vp, _l, _vp, _vp, _vp, _i, _f, _vp, _vp, ctypes.c_size_t]),
 }
 
 

@@ -416,3 +416,178 @@ extern "C" int tcow_iou_counts(void* stream, const float* logits, const float* t
     TCOW_CHECK_LAUNCH();
     return TCOW_OK;
 }
+
+// ------------------------------------------------------------------------------------------ query / target masks (caller row P)
+// data/data_utils.py:414-510 for all (b, q, t) in one pass over the segmentation maps: query mask = visible pixels of the queried
+// instance at the query frame (:431), target channel 0 = its amodal mask (:441), channel 1 = amodal mask of the frontmost occluder
+// when the frame has one (:455-463), channel 2 = outermost container (:468-492), snitch_occl_by_ptr = occluded snitch pixels tagged
+// with the occluder's id (:435-437).  Which instance is the occluder / container of a frame is decided beforehand on (B,Q,T)-sized
+// tensors; this kernel does the per-pixel work: 4 B read, 17 B written per pixel.
+namespace {
+struct BuildMasksArgs {
+    const uint8_t* segm; const uint8_t* div;          // (B,1,T,H,W), (B,M,T,H,W)
+    const int* qidx;                                   // [B*Q] queried instance
+    const int* front; const int* cont;                 // [B*Q*T] instance index of the frontmost occluder / outermost container, -1 = none
+    float* qmask; float* target; uint8_t* ptr;         // (B,Q,1,T,H,W), (B,Q,3,T,H,W), (B,Q,1,T,H,W)
+    int* counts;                                       // [1 + 2*Q]: amodal pixels of channel 0; per query: any(query mask), any(target)
+    int B, Q, M, T, HW16, qt;
+};
+__global__ void __launch_bounds__(256) build_masks_kernel(BuildMasksArgs a) {
+    const int f = blockIdx.y;                          // (b*Q + q)*T + t
+    const int t = f % a.T, bq = f / a.T, q = bq % a.Q, b = bq / a.Q;
+    const int qi = a.qidx[bq], fi = a.front[f], ci = a.cont[f];
+    const size_t plane = (size_t)a.HW16 * 16;
+    const uint4* seg = reinterpret_cast<const uint4*>(a.segm + ((size_t)b * a.T + t) * plane);
+    const uint4* dq = reinterpret_cast<const uint4*>(a.div + (((size_t)b * a.M + qi) * a.T + t) * plane);
+    const uint4* df = fi >= 0 ? reinterpret_cast<const uint4*>(a.div + (((size_t)b * a.M + fi) * a.T + t) * plane) : nullptr;
+    const uint4* dc = ci >= 0 ? reinterpret_cast<const uint4*>(a.div + (((size_t)b * a.M + ci) * a.T + t) * plane) : nullptr;
+    float4* qm = reinterpret_cast<float4*>(a.qmask + (size_t)f * plane);
+    float4* t0 = reinterpret_cast<float4*>(a.target + (((size_t)bq * 3 + 0) * a.T + t) * plane);
+    float4* t1 = reinterpret_cast<float4*>(a.target + (((size_t)bq * 3 + 1) * a.T + t) * plane);
+    float4* t2 = reinterpret_cast<float4*>(a.target + (((size_t)bq * 3 + 2) * a.T + t) * plane);
+    uint4* pt = reinterpret_cast<uint4*>(a.ptr + (size_t)f * plane);
+    int n_amodal = 0, any_q = 0, any_t = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < a.HW16; i += gridDim.x * 256) {
+        const uint4 sv = seg[i], qv = dq[i];
+        const uint4 fv = df ? df[i] : make_uint4(0, 0, 0, 0), cv = dc ? dc[i] : make_uint4(0, 0, 0, 0);
+        const uint32_t sw[4] = {sv.x, sv.y, sv.z, sv.w}, qw[4] = {qv.x, qv.y, qv.z, qv.w}, fw[4] = {fv.x, fv.y, fv.z, fv.w}, cw[4] = {cv.x, cv.y, cv.z, cv.w};
+        uint32_t pw[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            float qo[4], o0[4], o1[4], o2[4];
+            uint32_t pword = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t s = (sw[w] >> (8 * e)) & 255u;
+                const bool isq = s == (uint32_t)(qi + 1);
+                const bool amodal = ((qw[w] >> (8 * e)) & 255u) == 1u;
+                const bool fr = ((fw[w] >> (8 * e)) & 255u) == 1u, co = ((cw[w] >> (8 * e)) & 255u) == 1u;
+                qo[e] = (t == a.qt && isq) ? 1.f : 0.f;
+                o0[e] = amodal ? 1.f : 0.f; o1[e] = fr ? 1.f : 0.f; o2[e] = co ? 1.f : 0.f;
+                if (amodal && !isq) pword |= s << (8 * e);
+                n_amodal += amodal; any_q |= (t == a.qt && isq); any_t |= amodal | fr | co;
+            }
+            pw[w] = pword;
+            qm[i * 4 + w] = make_float4(qo[0], qo[1], qo[2], qo[3]);
+            t0[i * 4 + w] = make_float4(o0[0], o0[1], o0[2], o0[3]);
+            t1[i * 4 + w] = make_float4(o1[0], o1[1], o1[2], o1[3]);
+            t2[i * 4 + w] = make_float4(o2[0], o2[1], o2[2], o2[3]);
+        }
+        pt[i] = make_uint4(pw[0], pw[1], pw[2], pw[3]);
+    }
+    for (int o = 32; o > 0; o >>= 1) { n_amodal += __shfl_xor(n_amodal, o, 64); any_q |= __shfl_xor(any_q, o, 64); any_t |= __shfl_xor(any_t, o, 64); }
+    if ((threadIdx.x & 63) == 0) {
+        if (n_amodal) atomicAdd(&a.counts[0], n_amodal);
+        if (any_q) atomicOr(&a.counts[1 + 2 * q], 1);
+        if (any_t) atomicOr(&a.counts[2 + 2 * q], 1);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ snitch pixel weights (caller row L)
+// loss.py:85-148 times the frame weights of loss.py:55-83: class balancing (powers 0.7 / -0.3 of the rarer / commoner class
+// fraction, 5 % floor), x2 on occluded snitch pixels, x hard_negative_factor on the band = (k x k box dilation of the target) minus
+// the target, k = odd(int(sqrt(HW) / 12)) -- the reference's gaussian_blur(target, k, sigma=k) > 0.  Separable dilation: rows here,
+// columns inside the weight kernel.
+__global__ void __launch_bounds__(256) dilate_rows_kernel(const float* __restrict__ target, long frame_stride_t, int frames_per_seq, long seq_stride_t, int H, int W, int r,
+                                                          uint8_t* __restrict__ tmp) {
+    const int f = blockIdx.y;
+    const int s = f / frames_per_seq, ft = f - s * frames_per_seq;
+    const float* src = target + (size_t)s * seq_stride_t + (size_t)ft * frame_stride_t;
+    uint8_t* dst = tmp + (size_t)f * H * W;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < H * W; i += gridDim.x * 256) {
+        const int y = i / W, x = i - y * W;
+        const int x0 = x - r > 0 ? x - r : 0, x1 = x + r < W - 1 ? x + r : W - 1;
+        int any = 0;
+        for (int xx = x0; xx <= x1; ++xx) any |= src[y * W + xx] > 0.f;
+        dst[i] = (uint8_t)any;
+    }
+}
+struct WeightsArgs {
+    const float* target; long frame_stride_t; int frames_per_seq; long seq_stride_t;   // channel 0 of (BQ,3,T,H,W)
+    const uint8_t* ptr; const uint8_t* rowdil; const float* frame_w; const int* pos_count;
+    float* out; int H, W, r; long n_pixels; int class_balancing; float hard_negative_factor;
+};
+__global__ void __launch_bounds__(256) snitch_weights_kernel(WeightsArgs a) {
+    __shared__ float corr[2];
+    if (threadIdx.x == 0) {
+        float pc = 1.f, nc = 1.f;
+        if (a.class_balancing) {                                            // loss.py:100-119 (host float64 arithmetic there, double here)
+            const long pos = *a.pos_count, neg = a.n_pixels - pos;
+            float pf = (float)pos / (float)a.n_pixels, nf = (float)neg / (float)a.n_pixels;
+            pf = pf < 0.05f ? 0.05f : pf; nf = nf < 0.05f ? 0.05f : nf;
+            const double p = pf, n = nf;
+            if (p > n) { pc = (float)pow(n / p, 0.7); nc = (float)pow(n / p, -0.3); }
+            else { pc = (float)pow(p / n, -0.3); nc = (float)pow(p / n, 0.7); }
+        }
+        corr[0] = nc; corr[1] = pc;
+    }
+    __syncthreads();
+    const int f = blockIdx.y;
+    const int s = f / a.frames_per_seq, ft = f - s * a.frames_per_seq;
+    const float* tg = a.target + (size_t)s * a.seq_stride_t + (size_t)ft * a.frame_stride_t;
+    const size_t fo = (size_t)f * a.H * a.W;
+    const float fw = a.frame_w[f];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < a.H * a.W; i += gridDim.x * 256) {
+        const int y = i / a.W, x = i - y * a.W;
+        const float t = tg[i];
+        float w = 1.f;
+        if (a.class_balancing) { if (t == 0.f) w *= corr[0]; if (t == 1.f) w *= corr[1]; }
+        if (a.ptr[fo + i] != 0) w *= 2.f;
+        if (a.hard_negative_factor > 1.f && !(t >= 0.5f)) {
+            const int y0 = y - a.r > 0 ? y - a.r : 0, y1 = y + a.r < a.H - 1 ? y + a.r : a.H - 1;
+            int any = 0;
+            for (int yy = y0; yy <= y1; ++yy) any |= a.rowdil[fo + (size_t)yy * a.W + x];
+            if (any) w *= a.hard_negative_factor;
+        }
+        a.out[fo + i] = fw * w;
+    }
+}
+}  // namespace
+
+extern "C" int tcow_build_masks(void* stream, int B, int Q, int M, int T, long HW, int query_time, const uint8_t* segm, const uint8_t* div_segm,
+                                const int* query_idx, const int* front_idx, const int* cont_idx, float* query_mask, float* target_mask,
+                                uint8_t* snitch_occl_by_ptr, int* counts) {
+    TCOW_CHECK_ARG(B > 0 && Q > 0 && M > 0 && T > 0 && HW > 0 && HW % 16 == 0, "tcow_build_masks: bad shape (H*W must be a multiple of 16)");
+    TCOW_CHECK_ARG(segm && div_segm && query_idx && front_idx && cont_idx && query_mask && target_mask && snitch_occl_by_ptr && counts, "tcow_build_masks: null pointer");
+    TCOW_CHECK_ARG((long)B * Q * T < 65536, "tcow_build_masks: too many frames for one call");
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(counts, 0, sizeof(int) * (1 + 2 * Q), st);
+    if (e != hipSuccess) { tcow_set_error("tcow_build_masks: memset failed: %s", hipGetErrorString(e)); return TCOW_ERR_LAUNCH; }
+    BuildMasksArgs a;
+    a.segm = segm; a.div = div_segm; a.qidx = query_idx; a.front = front_idx; a.cont = cont_idx; a.qmask = query_mask; a.target = target_mask;
+    a.ptr = snitch_occl_by_ptr; a.counts = counts; a.B = B; a.Q = Q; a.M = M; a.T = T; a.HW16 = (int)(HW / 16); a.qt = query_time;
+    const int gx = cdiv(a.HW16, 256) < 8 ? cdiv(a.HW16, 256) : 8;
+    hipLaunchKernelGGL(build_masks_kernel, dim3(gx, B * Q * T), dim3(256), 0, st, a);
+    TCOW_CHECK_LAUNCH();
+    return TCOW_OK;
+}
+
+extern "C" size_t tcow_snitch_weights_workspace_bytes(long n_frames, int H, int W) { return (size_t)n_frames * H * W + 256; }
+
+extern "C" int tcow_snitch_weights(void* stream, long n_seq, int T, int H, int W, const float* target_ch0, long target_seq_stride, const uint8_t* snitch_occl_by_ptr,
+                                   const float* frame_w, const int* pos_count, int class_balancing, float hard_negative_factor, float* weights, void* ws,
+                                   size_t ws_bytes) {
+    TCOW_CHECK_ARG(n_seq > 0 && T > 0 && H > 0 && W > 0 && target_ch0 && snitch_occl_by_ptr && frame_w && weights, "tcow_snitch_weights: bad arguments");
+    TCOW_CHECK_ARG(!class_balancing || pos_count, "tcow_snitch_weights: class balancing needs the positive-pixel count");
+    const long frames = n_seq * T;
+    TCOW_CHECK_ARG(frames < 65536, "tcow_snitch_weights: too many frames for one call");
+    hipStream_t st = (hipStream_t)stream;
+    int k = (int)(sqrt((double)H * (double)W) / 12.0);                       // loss.py:138-140
+    if (k % 2 == 0) k += 1;
+    const int r = k / 2;
+    uint8_t* tmp = (uint8_t*)ws;
+    const int gx = cdiv((long)H * W, 256 * 8) < 1 ? 1 : cdiv((long)H * W, 256 * 8);
+    const bool band = hard_negative_factor > 1.f;
+    if (band) {
+        TCOW_CHECK_ARG(ws && ws_bytes >= tcow_snitch_weights_workspace_bytes(frames, H, W), "tcow_snitch_weights: workspace too small");
+        hipLaunchKernelGGL(dilate_rows_kernel, dim3(gx, (unsigned)frames), dim3(256), 0, st, target_ch0, (long)H * W, T, target_seq_stride, H, W, r, tmp);
+        TCOW_CHECK_LAUNCH();
+    }
+    WeightsArgs a;
+    a.target = target_ch0; a.frame_stride_t = (long)H * W; a.frames_per_seq = T; a.seq_stride_t = target_seq_stride; a.ptr = snitch_occl_by_ptr; a.rowdil = tmp;
+    a.frame_w = frame_w; a.pos_count = pos_count; a.out = weights; a.H = H; a.W = W; a.r = r; a.n_pixels = frames * H * W; a.class_balancing = class_balancing;
+    a.hard_negative_factor = band ? hard_negative_factor : 1.f;
+    hipLaunchKernelGGL(snitch_weights_kernel, dim3(gx, (unsigned)frames), dim3(256), 0, st, a);
+    TCOW_CHECK_LAUNCH();
+    return TCOW_OK;
+}

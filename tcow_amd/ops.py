@@ -200,3 +200,37 @@ def iou_counts(logits, target):
     out = torch.empty(lo.shape[:-2] + (3,), dtype=torch.int32, device=lo.device)
     L.check(L.lib().tcow_iou_counts(_stream(), lo.data_ptr(), tg.data_ptr(), lo.numel() // frame_len, frame_len, out.data_ptr()), 'tcow_iou_counts')
     return out
+
+
+def build_masks(segm, div_segm, query_idx, front_idx, cont_idx, query_time):
+    """segm (B,1,T,H,W) u8, div_segm (B,M,T,H,W) u8, query_idx (B,Q) int32, front_idx / cont_idx (B,Q,T) int32 (-1 = none).
+    Returns query_mask (B,Q,1,T,H,W) f32, target (B,Q,3,T,H,W) f32, snitch_occl_by_ptr (B,Q,1,T,H,W) u8, counts int32 [1 + 2Q]
+    (see tcow_build_masks)."""
+    _need_cuda(segm, div_segm, query_idx, front_idx, cont_idx)
+    B, _, T, H, W = segm.shape
+    M = div_segm.shape[1]; Q = query_idx.shape[1]
+    if segm.dtype != torch.uint8 or div_segm.dtype != torch.uint8 or not segm.is_contiguous() or not div_segm.is_contiguous():
+        raise L.TcowError('build_masks: segmentation maps must be contiguous uint8 tensors')
+    dev = segm.device
+    qm = torch.empty(B, Q, 1, T, H, W, dtype=torch.float32, device=dev); tg = torch.empty(B, Q, 3, T, H, W, dtype=torch.float32, device=dev)
+    pt = torch.empty(B, Q, 1, T, H, W, dtype=torch.uint8, device=dev); counts = torch.empty(1 + 2 * Q, dtype=torch.int32, device=dev)
+    qi = query_idx.to(torch.int32).contiguous(); fi = front_idx.to(torch.int32).contiguous(); ci = cont_idx.to(torch.int32).contiguous()
+    L.check(L.lib().tcow_build_masks(_stream(), B, Q, M, T, H * W, int(query_time), segm.data_ptr(), div_segm.data_ptr(), qi.data_ptr(), fi.data_ptr(),
+                                     ci.data_ptr(), qm.data_ptr(), tg.data_ptr(), pt.data_ptr(), counts.data_ptr()), 'tcow_build_masks')
+    return qm, tg, pt, counts
+
+
+def snitch_weights(target, snitch_occl_by_ptr, frame_w, pos_count, class_balancing=True, hard_negative_factor=3.0):
+    """target (B,Q,3,T,H,W) f32 (channel 0 is used), snitch_occl_by_ptr (B,Q,1,T,H,W) u8, frame_w (B,Q,T) f32, pos_count int32 [>=1]
+    -> (B,Q,T,H,W) f32 pixel weights of the track loss (see tcow_snitch_weights)."""
+    _need_cuda(target, snitch_occl_by_ptr, frame_w, pos_count)
+    B, Q, C, T, H, W = target.shape
+    if not target.is_contiguous() or not snitch_occl_by_ptr.is_contiguous() or target.dtype != torch.float32 or snitch_occl_by_ptr.dtype != torch.uint8:
+        raise L.TcowError('snitch_weights: target must be contiguous f32 and snitch_occl_by_ptr contiguous u8')
+    out = torch.empty(B, Q, T, H, W, dtype=torch.float32, device=target.device)
+    fw = frame_w.to(torch.float32).contiguous()
+    lib = L.lib()
+    ws = workspace(lib.tcow_snitch_weights_workspace_bytes(B * Q * T, H, W), target.device, 'snitch_w')
+    L.check(lib.tcow_snitch_weights(_stream(), B * Q, T, H, W, target.data_ptr(), C * T * H * W, snitch_occl_by_ptr.data_ptr(), fw.data_ptr(), pos_count.data_ptr(),
+                                    1 if class_balancing else 0, float(hard_negative_factor), out.data_ptr(), ws.data_ptr(), ws.numel()), 'tcow_snitch_weights')
+    return out

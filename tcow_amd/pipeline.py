@@ -83,6 +83,30 @@ def fill_kubric_query_target_mask_flags(segm, div_segm, query_idx, qt_idx, occl_
     return query_mask, snitch_occl_by_ptr, ids, target, flags
 
 
+def frame_decisions(occl_fracs, dag, sel, args):
+    """The per-frame decisions of data_utils.py:455-492 for all (b, q, t) at once (tiny tensors): sel (B,Q) query instances ->
+    front_idx / cont_idx (B,Q,T) int64 (-1 = the frame has no frontmost occluder / outermost container), full_occl_cont_id
+    (B,Q,T,2) u8 and target flags (B,Q,T,3) f32, identical to the per-query results of fill_kubric_query_target_mask_flags."""
+    B, Q = sel.shape
+    dev = dag.device
+    bidx = torch.arange(B, device=dev)[:, None].expand(B, Q)
+    of_q = occl_fracs[bidx, sel]                                            # (B,Q,T,3)
+    dq = dag[bidx, :, sel]                                                  # (B,Q,T,M,3): row of the snitch
+    fmax, farg = dq[..., 2].max(dim=-1)
+    has_front = (of_q[..., 0] >= args.front_occl_thres) & (fmax >= args.front_occl_thres / 2.0)
+    cont = dq[..., 0]
+    cand = cont >= args.outer_cont_thres
+    has_cont = cand.any(dim=-1)
+    self_contained = dag[..., 0].max(dim=-1)[0][:, None].expand(cont.shape)
+    score = torch.where(cand, self_contained, torch.full_like(self_contained, float('inf')))
+    outer = score.argmin(dim=-1)
+    outer = torch.where(cand.sum(dim=-1) <= 1, cont.argmax(dim=-1), outer)
+    neg1 = torch.full_like(farg, -1)
+    ids = torch.stack([torch.where(has_front, farg + 1, torch.zeros_like(farg)), torch.where(has_cont, outer + 1, torch.zeros_like(outer))], dim=-1).to(torch.uint8)
+    flags = torch.stack([has_front.float(), has_cont.float(), of_q[..., 0].float()], dim=-1)
+    return torch.where(has_front, farg, neg1), torch.where(has_cont, outer, neg1), ids, flags
+
+
 class SeekerPipeline:
     """Counterpart of MyTrainPipeline (pipeline.py:15-258) around a tcow_amd (or any) Seeker module."""
 
@@ -105,22 +129,35 @@ class SeekerPipeline:
         qt = int(tr['query_time'][0].item())                               # pipeline.py:140: only [0] is used
         if sel_query_inds is None:
             sel_query_inds = sample_query_inds(B, Qs, kr['pv_inst_count'], des, self.phase, self.rng)
-        qms, ptrs, idss, tgts, nonzero = [], [], [], [], []
-        for q in range(Qs):                                                # cheap tensor ops; the model call below is batched
-            qm, ptr, ids, tgt, _ = fill_kubric_query_target_mask_flags(segm, div, sel_query_inds[:, q], qt, occl_fracs, dag, self.args)
-            nonzero += [qm.any(), tgt.any()]
-            qms.append(qm); ptrs.append(ptr); idss.append(ids); tgts.append(tgt)
+        pos_count = None
+        if segm.is_cuda and segm.dtype == torch.uint8 and div.dtype == torch.uint8 and (H * W) % 16 == 0:
+            # one HIP pass over the segmentation maps for all queries (tcow_build_masks); the per-frame occluder / container choice
+            # stays a handful of tensor ops on (B,Qs,T,M)-sized data
+            from . import ops
+            sel_d = to_dev(sel_query_inds, dev)
+            front_idx, cont_idx, ids_all, _ = frame_decisions(occl_fracs, dag, sel_d, self.args)
+            query_mask, target, ptr_all, counts = ops.build_masks(segm.contiguous(), div.contiguous(), sel_d, front_idx, cont_idx, qt)
+            nonzero = counts[1:] != 0
+            pos_count = counts[0:1]
+            snitch_ptr, ids_stack = ptr_all, ids_all
+        else:
+            qms, ptrs, idss, tgts, nonzero = [], [], [], [], []
+            for q in range(Qs):                                            # cheap tensor ops; the model call below is batched
+                qm, ptr, ids, tgt, _ = fill_kubric_query_target_mask_flags(segm, div, sel_query_inds[:, q], qt, occl_fracs, dag, self.args)
+                nonzero += [qm.any(), tgt.any()]
+                qms.append(qm); ptrs.append(ptr); idss.append(ids); tgts.append(tgt)
+            nonzero = torch.stack(nonzero)
+            query_mask = torch.stack(qms, 1); target = torch.stack(tgts, 1)    # (B,Qs,1,T,H,W), (B,Qs,3,T,H,W)
+            snitch_ptr, ids_stack = torch.stack(ptrs, 1), torch.stack(idss, 1)
         # pipeline.py:149-154 raises on an all-zero query / target mask.  The flags travel to pinned host memory behind the
         # mask kernels and are inspected after the model call has been queued: same error, before any loss / update, but the
         # host never waits on an empty stream.
-        nonzero = torch.stack(nonzero)
         if nonzero.is_cuda:
             host_flags = torch.empty(nonzero.shape, dtype=torch.bool, pin_memory=True)
             host_flags.copy_(nonzero, non_blocking=True)
             flags_ready = torch.cuda.Event(); flags_ready.record()
         else:
             host_flags, flags_ready = nonzero, None
-        query_mask = torch.stack(qms, 1); target = torch.stack(tgts, 1)    # (B,Qs,1,T,H,W), (B,Qs,3,T,H,W)
         rgb_rep = rgb[:, None].expand(B, Qs, 3, T, H, W).reshape(B * Qs, 3, T, H, W)
         out_mask, _ = self.seeker(rgb_rep, query_mask.reshape(B * Qs, 1, T, H, W))   # pipeline.py:157-158, Qs calls in one
         if flags_ready is not None:
@@ -137,7 +174,7 @@ class SeekerPipeline:
             'sel_occl_fracs': torch.stack([occl_fracs[bi_dev, sel_dev[:, q]] for q in range(Qs)], 1),         # (B,Qs,T,3)
             'sel_desirability': torch.stack([des_dev[bi_dev, sel_dev[:, q], 0] for q in range(Qs)], 1),
             'seeker_input': rgb, 'seeker_query_mask': query_mask,
-            'snitch_occl_by_ptr': torch.stack(ptrs, 1), 'full_occl_cont_id': torch.stack(idss, 1),
+            'snitch_occl_by_ptr': snitch_ptr, 'full_occl_cont_id': ids_stack, '_target_pos_count': pos_count,
             'target_mask': target, 'output_mask': out_mask.reshape(B, Qs, 3, T, H, W),
         }
 

@@ -172,8 +172,13 @@ class TcowLosses:
         sw = None; fws = [None, None]
         if a.track_lw > 0.0:
             fw = self.frame_weights(model_retval['sel_occl_fracs'], query_time)
-            pw = self.pixel_weights(tgt[:, :, 0], model_retval['snitch_occl_by_ptr'][:, :, 0])
-            sw = (fw[..., None, None] * pw).contiguous()
+            pos_count = model_retval.get('_target_pos_count')
+            if pos_count is not None and tgt.is_contiguous():
+                from . import ops                                           # class balancing, x2 occluded, dilation band and frame weights in two passes
+                sw = ops.snitch_weights(tgt, model_retval['snitch_occl_by_ptr'], fw, pos_count, bool(a.class_balancing), float(a.hard_negative_factor))
+            else:
+                pw = self.pixel_weights(tgt[:, :, 0], model_retval['snitch_occl_by_ptr'][:, :, 0])
+                sw = (fw[..., None, None] * pw).contiguous()
             model_retval['snitch_weights'] = sw
         for i, (ch, lw) in enumerate(((1, a.occl_mask_lw), (2, a.cont_mask_lw))):
             if lw > 0.0:

@@ -189,3 +189,30 @@ def test_iou_counts_kernel_matches_tensor_path(cuda):
     ap = calculate_metrics_mask_track(out[:, 0].cuda(), tgt[:, 0].cuda(), plugin=True); bp = calculate_metrics_mask_track(out[:, 0], tgt[:, 0], plugin=True)
     for k in bp:
         assert (int(ap[k]) == int(bp[k])) if 'count' in k else abs(float(ap[k]) - float(bp[k])) < 1e-6, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('phase', ['test', 'train'])
+def test_mask_builder_and_weight_kernels_match_tensor_path(cuda, phase):
+    """tcow_build_masks / tcow_snitch_weights (HIP) vs the tensor-op restatement that the goldens pin: query / target masks, occluder
+    tags and ids bit-exact; pixel weights (class balancing, x2 occluded, 7x7 dilation band at 64x64, frame weights) to rounding."""
+    _, g = load_golden('g5_pipeline_cfg1')
+    sel = torch.from_numpy(g[f'{phase}::sel_query_inds'])
+    ref_out = torch.from_numpy(g[f'{phase}::output_mask'])
+    args = default_args()                                                   # hard_negative_factor = 3: the band is exercised
+    res = {}
+    for dev in ('cpu', 'cuda'):
+        pipe = SeekerPipeline(_Replay(ref_out.to(dev)), num_queries=Qs, train_args=args, phase=phase, device=dev)
+        mr = pipe.forward_kubric(_data(dev if dev == 'cuda' else None), sel_query_inds=sel)
+        out = pipe.step_losses(_data(dev if dev == 'cuda' else None), mr, 0.3)
+        res[dev] = (mr, out)
+    mc, mg = res['cpu'][0], res['cuda'][0]
+    assert mg['_target_pos_count'] is not None and mc['_target_pos_count'] is None      # the HIP builder ran on the GPU side only
+    for k in ('seeker_query_mask', 'snitch_occl_by_ptr', 'full_occl_cont_id', 'target_mask', 'sel_occl_fracs'):
+        assert mg[k].shape == mc[k].shape and mg[k].dtype == mc[k].dtype and torch.equal(mg[k].cpu(), mc[k]), k
+    assert int(mg['_target_pos_count'][0]) == int((mc['target_mask'][:, :, 0] == 1).sum())
+    wc, wg = mc['snitch_weights'], mg['snitch_weights'].cpu()
+    assert wc.shape == wg.shape and float((wc - wg).abs().max()) < 1e-5 * float(wc.abs().max())
+    assert int((wc != wc[0, 0, 0, 0, 0]).sum()) > 0                          # (not a constant map)
+    for k in ('track', 'occl_mask', 'cont_mask', 'total_seeker'):
+        assert abs(float(res['cuda'][1][k]) - float(res['cpu'][1][k])) < 5e-6, k
