@@ -565,8 +565,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_stream(SeqDesc sd, int nt, c
     if (active) dkv_store(sd, base, ld3, head, j, l31, hi, dk0, dk1, dv0, dv1, dqkv);
 }
 
-__global__ __launch_bounds__(256) void attn_bwd_dq_stream(SeqDesc sd, int nt, const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
-                                                          const float2* __restrict__ ld, bf16_t* __restrict__ dqkv) {
+// (This kernel runs FIRST in the streaming backward: every wave owns a query tile, so it also computes delta = rowsum(dO * O) of
+// its queries and publishes the packed (lse, delta) table that the dK / dV kernel reads -- no separate preparation launch.)
+__global__ __launch_bounds__(256) void attn_bwd_dq_stream(SeqDesc sd, int nt, const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
+                                                          const float* __restrict__ lse, float2* __restrict__ ld, bf16_t* __restrict__ dqkv) {
     __shared__ __attribute__((aligned(16))) char smem[8 * TILE_B];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -578,7 +580,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_stream(SeqDesc sd, int nt, co
     const long ld3 = 3L * sd.D, pse = sd.pos_stride * ld3, pso = sd.pos_stride * sd.D;
     const bf16_t* qh = qkv + base * ld3 + head * ATT_HD;
     const bf16_t* doh = dout + base * sd.D + head * ATT_HD;
-    const float2* ldh = ld + ((size_t)item * sd.heads + head) * (nt * 32);
+    float2* ldh = ld + ((size_t)item * sd.heads + head) * (nt * 32);
     char* kt = smem;
     char* vt = smem + 4 * TILE_B;
     const int qt = sw_.chunk * 4 + wave;
@@ -588,8 +590,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_stream(SeqDesc sd, int nt, co
     bf16x8 qf[4], dof[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) { qf[ks] = frag_row_global(qh, pse, qc, ks, hi); dof[ks] = frag_row_global(doh, pso, qc, ks, hi); }
-    const float2 lq = active ? ldh[32 * qt + l31] : make_float2(0.f, 0.f);
-    const float ls = lq.x * kLog2e, dl = lq.y;
+    // delta of row q: each half-wave covers 32 of the 64 channels
+    const bf16_t* oh = o + base * sd.D + head * ATT_HD;
+    float part = 0.f;
+#pragma unroll
+    for (int d = 0; d < 32; d += 4) {
+        const float4 x = ld4(oh + (size_t)qc * pso + 32 * hi + d), y = ld4(doh + (size_t)qc * pso + 32 * hi + d);
+        part += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+    }
+    const float dl = part + __shfl_xor(part, 32, 64);
+    const float lsn = lse[(base + (long)qc * sd.pos_stride) * sd.heads + head];
+    if (active && hi == 0) ldh[32 * qt + l31] = q < sd.L ? make_float2(lsn, dl) : make_float2(0.f, 0.f);
+    const float ls = lsn * kLog2e;
     f32x16 dq0, dq1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dq0[r] = 0.f; dq1[r] = 0.f; }
@@ -665,13 +677,17 @@ int tcow_attn_mfma_bwd(hipStream_t st, const SeqDesc& d, bool shared, const void
     float2* ld = (float2*)ws;
     const long total = (long)pairs * nt * 32;
     int blocks = cdiv(total, 256); if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3(blocks), dim3(256), 0, st, d, nt * 32, (const bf16_t*)out, (const bf16_t*)dout, lse, ld);
-    TCOW_CHECK_LAUNCH();
     if ((shared && shared_variant() == 2) || (!shared && nt > 2)) {
+        hipLaunchKernelGGL(attn_bwd_dq_stream, dim3(stream_grid(pairs, cdiv(nt, 4))), dim3(256), 0, st, d, nt, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, ld,
+                           (bf16_t*)dqkv);
+        TCOW_CHECK_LAUNCH();
         hipLaunchKernelGGL(attn_bwd_dkv_stream, dim3(stream_grid(pairs, cdiv(nt, 4))), dim3(256), 0, st, d, nt, (const bf16_t*)qkv, (const bf16_t*)dout, ld, (bf16_t*)dqkv);
         TCOW_CHECK_LAUNCH();
-        hipLaunchKernelGGL(attn_bwd_dq_stream, dim3(stream_grid(pairs, cdiv(nt, 4))), dim3(256), 0, st, d, nt, (const bf16_t*)qkv, (const bf16_t*)dout, ld, (bf16_t*)dqkv);
-    } else if (shared) {
+        return TCOW_OK;
+    }
+    hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3(blocks), dim3(256), 0, st, d, nt * 32, (const bf16_t*)out, (const bf16_t*)dout, lse, ld);
+    TCOW_CHECK_LAUNCH();
+    if (shared) {
         const int lds = 2 * nt * TILE_B;
         set_lds_attr(attn_bwd_dkv_mfma<true>, lds); set_lds_attr(attn_bwd_dq_mfma<true>, lds);
         hipLaunchKernelGGL(attn_bwd_dkv_mfma<true>, dim3(pairs), dim3(256), lds, st, d, nt, (const bf16_t*)qkv, (const bf16_t*)dout, ld, (bf16_t*)dqkv);
