@@ -89,6 +89,11 @@ __device__ __forceinline__ WorkId work_id(const SeqDesc& sd, int wave) {
 }
 
 // One 32-key tile against one 32-query tile (forward): S^T = K Q^T, online softmax, O^T += V^T P^T.
+// VALU budget: the MFMAs of a step take 256 cycles per wave, the softmax arithmetic used to take ~850, so every operation counts:
+// the score scale is folded into the exp2 argument (one fma per element), masks are only evaluated on boundary tiles, masked
+// elements rely on exp2 underflow (no select), and the running maximum is LAZY: accumulators are rescaled only when some row's
+// maximum grew by more than 2^8 since the reference maximum was set (probabilities then stay <= 256, harmless in bf16 / f32, and
+// the final O / l and log-sum-exp are independent of the reference) -- after the first key tile that almost never happens.
 __device__ __forceinline__ void fwd_tile(const SeqDesc& sd, const char* ktile, const char* vtile, const bf16x8 (&qf)[4], int j, int qt, int q, int l31, int hi, int lane,
                                          float& m, float& l, f32x16& o0, f32x16& o1) {
     const float sc = kScale * kLog2e;
@@ -98,27 +103,35 @@ __device__ __forceinline__ void fwd_tile(const SeqDesc& sd, const char* ktile, c
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(ktile, l31, ks, hi), qf[ks], s, 0, 0, 0);
     const bool need_mask = (32 * j + 31 >= sd.L) || ((long)32 * j + 31 > (long)32 * qt + sd.diag);
-    float mx = -1e30f;
-    float p[16];
+    if (need_mask) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        float v = s[r] * sc;
-        if (need_mask) {
+        for (int r = 0; r < 16; ++r) {
             const int key = 32 * j + crow32(r, hi);
-            if (key >= sd.L || (long)key > (long)q + sd.diag) v = -1e30f;
+            if (key >= sd.L || (long)key > (long)q + sd.diag) s[r] = -1e30f;
         }
-        p[r] = v; mx = fmaxf(mx, v);
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float mn = fmaxf(m, mx);
-    const float alpha = exp2f(m - mn);
+    float mx = s[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * sc;            // (sc > 0: the maximum commutes with the scale)
+    if (__any(mx > m + 8.0f)) {
+        const float mn = fmaxf(m, mx);
+        const float alpha = exp2f(m - mn);
+        l *= alpha;
+        m = mn;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+    }
+    float p[16];
     float ps = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { const float e = (p[r] <= -1e29f) ? 0.f : exp2f(p[r] - mn); p[r] = e; ps += e; }
-    l = l * alpha + ps;
-    m = mn;
+    for (int r = 0; r < 16; ++r) { p[r] = __builtin_amdgcn_exp2f(fmaf(s[r], sc, -m)); ps += p[r]; }
+    if (need_mask) {                                        // a fully masked row (m still at its start value) must contribute nothing
+        ps = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+        for (int r = 0; r < 16; ++r) { if (s[r] <= -1e29f) p[r] = 0.f; ps += p[r]; }
+    }
+    l += ps;
     const bf16x8 pb0 = pack8(p), pb1 = pack8(p + 8);
     o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(vtile, 0, 0, lane), pb0, o0, 0, 0, 0);
     o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(vtile, 1, 0, lane), pb1, o0, 0, 0, 0);
@@ -280,7 +293,10 @@ __device__ __forceinline__ void dkv_tile(const SeqDesc& sd, const char* qtile, c
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(qtile, l31, ks, hi), kf[ks], s, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(dotile, l31, ks, hi), vf[ks], dp, 0, 0, 0);
     }
-    // rows of the accumulators are queries q = 32*i + 8*(r>>2) + 4*hi + (r&3); lse/delta for 4 consecutive q per group
+    // rows of the accumulators are queries q = 32*i + 8*(r>>2) + 4*hi + (r&3); lse/delta for 4 consecutive q per group.
+    // (VALU diet: masks only on boundary tiles -- masked scores are pushed to -1e30 so that exp2 underflows to 0; the 1/sqrt(d)
+    // factor of dS is applied once to the finished dK / dQ tiles in dkv_store / dq_store instead of per element here.)
+    const bool need_mask = (32 * i + 31 >= sd.L) || (key - l31 + 31 >= sd.L) || ((long)(key - l31) + 31 > (long)32 * i + sd.diag);
     float pv[16], dsv[16];
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
@@ -290,11 +306,14 @@ __device__ __forceinline__ void dkv_tile(const SeqDesc& sd, const char* qtile, c
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int r = 4 * gq + e;
-            const int q = 32 * i + 8 * gq + 4 * hi + e;
-            const bool ok = q < sd.L && key < sd.L && (long)key <= (long)q + sd.diag;
-            const float p = ok ? exp2f(s[r] * (kScale * kLog2e) - ls[e] * kLog2e) : 0.f;
+            float sv = s[r];
+            if (need_mask) {
+                const int q = 32 * i + 8 * gq + 4 * hi + e;
+                if (!(q < sd.L && key < sd.L && (long)key <= (long)q + sd.diag)) sv = -1e30f;
+            }
+            const float p = __builtin_amdgcn_exp2f(fmaf(sv, kScale * kLog2e, -ls[e] * kLog2e));
             pv[r] = p;
-            dsv[r] = p * (dp[r] - dl[e]) * kScale;
+            dsv[r] = p * (dp[r] - dl[e]);
         }
     }
     const bf16x8 pa0 = pack8(pv), pa1 = pack8(pv + 8), da0 = pack8(dsv), da1 = pack8(dsv + 8);
@@ -323,7 +342,7 @@ __device__ __forceinline__ void dkv_store(const SeqDesc& sd, long base, long ld3
     const int kr = 32 * j + l31;
     if (kr < sd.L) {
         bf16_t* drow = dqkv + (base + (long)kr * sd.pos_stride) * ld3 + head * ATT_HD;
-        store_rowT(drow + sd.D, hi, dk0, dk1);
+        store_rowT(drow + sd.D, hi, dk0 * kScale, dk1 * kScale);        // dS was accumulated without its 1/sqrt(d) factor
         store_rowT(drow + 2 * sd.D, hi, dv0, dv1);
     }
 }
@@ -339,13 +358,17 @@ __device__ __forceinline__ void dq_tile(const SeqDesc& sd, const char* ktile, co
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(ktile, l31, ks, hi), qf[ks], s, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(vtile, l31, ks, hi), dof[ks], dp, 0, 0, 0);
     }
+    const bool need_mask = (32 * j + 31 >= sd.L) || (q - l31 + 31 >= sd.L) || ((long)32 * j + 31 > (long)(q - l31) + sd.diag);
     float dsv[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int key = 32 * j + crow32(r, hi);
-        const bool ok = q < sd.L && key < sd.L && (long)key <= (long)q + sd.diag;
-        const float p = ok ? exp2f(s[r] * (kScale * kLog2e) - ls) : 0.f;
-        dsv[r] = p * (dp[r] - dl) * kScale;
+        float sv = s[r];
+        if (need_mask) {
+            const int key = 32 * j + crow32(r, hi);
+            if (!(q < sd.L && key < sd.L && (long)key <= (long)q + sd.diag)) sv = -1e30f;
+        }
+        const float p = __builtin_amdgcn_exp2f(fmaf(sv, kScale * kLog2e, -ls));
+        dsv[r] = p * (dp[r] - dl);
     }
     const bf16x8 da0 = pack8(dsv), da1 = pack8(dsv + 8);
     dq0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(ktile, 0, 0, lane), da0, dq0, 0, 0, 0);
@@ -357,7 +380,7 @@ __device__ __forceinline__ void dq_tile(const SeqDesc& sd, const char* ktile, co
 __device__ __forceinline__ void dq_store(const SeqDesc& sd, long base, long ld3, int head, int qt, int l31, int hi, const f32x16& dq0, const f32x16& dq1,
                                          bf16_t* __restrict__ dqkv) {
     const int qr = 32 * qt + l31;
-    if (qr < sd.L) store_rowT(dqkv + (base + (long)qr * sd.pos_stride) * ld3 + head * ATT_HD, hi, dq0, dq1);
+    if (qr < sd.L) store_rowT(dqkv + (base + (long)qr * sd.pos_stride) * ld3 + head * ATT_HD, hi, dq0 * kScale, dq1 * kScale);
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
@@ -590,13 +613,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_stream(SeqDesc sd, int nt, co
     bf16x8 qf[4], dof[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) { qf[ks] = frag_row_global(qh, pse, qc, ks, hi); dof[ks] = frag_row_global(doh, pso, qc, ks, hi); }
-    // delta of row q: each half-wave covers 32 of the 64 channels
+    // delta of row q = sum_d dO * O: the dO fragments are already in registers (this half-wave's 32 of the 64 channels); O is
+    // fetched with the same fragment pattern
     const bf16_t* oh = o + base * sd.D + head * ATT_HD;
     float part = 0.f;
 #pragma unroll
-    for (int d = 0; d < 32; d += 4) {
-        const float4 x = ld4(oh + (size_t)qc * pso + 32 * hi + d), y = ld4(doh + (size_t)qc * pso + 32 * hi + d);
-        part += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+    for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 of = frag_row_global(oh, pso, qc, ks, hi);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) part = fmaf((float)of[e], (float)dof[ks][e], part);
     }
     const float dl = part + __shfl_xor(part, 32, 64);
     const float lsn = lse[(base + (long)qc * sd.pos_stride) * sd.heads + head];
