@@ -159,7 +159,7 @@ __device__ __forceinline__ void fwd_store(const SeqDesc& sd, long base, int head
 
 // ------------------------------------------------------------------------------------------------ forward
 template <bool SHARED>
-__global__ __launch_bounds__(256) void attn_fwd_mfma(SeqDesc sd, int nt, const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse) {
+__global__ __launch_bounds__(256, 2) void attn_fwd_mfma(SeqDesc sd, int nt, const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -219,7 +219,7 @@ __device__ __forceinline__ StreamWork stream_work(int pairs, int nchunk) {
 }
 static inline int stream_grid(int pairs, int nchunk) { return 8 * ((pairs + 7) / 8) * nchunk; }
 
-__global__ __launch_bounds__(256) void attn_fwd_stream(SeqDesc sd, int nt, const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse) {
+__global__ __launch_bounds__(256, 2) void attn_fwd_stream(SeqDesc sd, int nt, const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse) {
     __shared__ __attribute__((aligned(16))) char smem[8 * TILE_B];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -385,7 +385,7 @@ __device__ __forceinline__ void dq_store(const SeqDesc& sd, long base, long ld3,
 
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
 template <bool SHARED>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_mfma(SeqDesc sd, int nt, const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma(SeqDesc sd, int nt, const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                          const float2* __restrict__ ld, bf16_t* __restrict__ dqkv) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -433,7 +433,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma(SeqDesc sd, int nt, con
 
 // ------------------------------------------------------------------------------------------------ backward: dQ
 template <bool SHARED>
-__global__ __launch_bounds__(256) void attn_bwd_dq_mfma(SeqDesc sd, int nt, const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma(SeqDesc sd, int nt, const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                         const float2* __restrict__ ld, bf16_t* __restrict__ dqkv) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma(SeqDesc sd, int nt, cons
 // Temporal attention at T <= 32: the whole sequence of a (site, head) is one 32-position tile, so one wave produces dQ, dK and dV
 // from a single visit of Q, K, V, dO (wave-private LDS tiles) and computes delta = rowsum(dO * O) itself: one launch and one
 // read of every operand instead of prep + dK/dV + dQ kernels (three launches, Q/K/V/dO read twice).
-__global__ __launch_bounds__(256) void attn_bwd_one_tile(SeqDesc sd, const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
+__global__ __launch_bounds__(256, 2) void attn_bwd_one_tile(SeqDesc sd, const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
                                                          const float* __restrict__ lse, bf16_t* __restrict__ dqkv) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -542,7 +542,7 @@ __global__ __launch_bounds__(256) void attn_bwd_one_tile(SeqDesc sd, const bf16_
 
 // ---- streaming backward kernels (any sequence length): a workgroup owns 4 key tiles (dK/dV) or 4 query tiles (dQ), one per
 // wave, and walks the other side in chunks of 4 tiles staged in 32 KiB of LDS (wave w loads tile 4c+w of the chunk).
-__global__ __launch_bounds__(256) void attn_bwd_dkv_stream(SeqDesc sd, int nt, const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_stream(SeqDesc sd, int nt, const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                            const float2* __restrict__ ld, bf16_t* __restrict__ dqkv) {
     __shared__ __attribute__((aligned(16))) char smem[8 * TILE_B];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -590,7 +590,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_stream(SeqDesc sd, int nt, c
 
 // (This kernel runs FIRST in the streaming backward: every wave owns a query tile, so it also computes delta = rowsum(dO * O) of
 // its queries and publishes the packed (lse, delta) table that the dK / dV kernel reads -- no separate preparation launch.)
-__global__ __launch_bounds__(256) void attn_bwd_dq_stream(SeqDesc sd, int nt, const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_stream(SeqDesc sd, int nt, const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
                                                           const float* __restrict__ lse, float2* __restrict__ ld, bf16_t* __restrict__ dqkv) {
     __shared__ __attribute__((aligned(16))) char smem[8 * TILE_B];
     const int tid = threadIdx.x, lane = tid & 63;
