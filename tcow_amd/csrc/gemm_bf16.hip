@@ -1014,24 +1014,57 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_bf16_256_kernel(TnParams p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
+    // Transpose reads software-pipelined by hand, as in the NT kernels: the 12 ds_read_b64_tr_b16 of k-step ks+1 are issued
+    // before the 8 MFMAs of k-step ks (inline asm + counted lgkmcnt; hipcc alone waits for each group right before its use).
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(LDS_PTR(char))smem;
+    uint32_t ya[4], xa[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ya[i] = lds0 + (uint32_t)y_off[i];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) xa[j] = lds0 + (uint32_t)x_off[j];
+    u32x2 fyl[2][4], fyh[2][4], fxl[2][2], fxh[2][2];
+#define TCOW_TRR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
+#define TCOW_TN_READ(buf, ks, so)                                                                                          \
+    do {                                                                                                                   \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                    \
+            TCOW_TRR(fxl[buf][j], xa[j] + (so), T2_TILE + (ks) * 16 * T2_ROWB);                                            \
+            TCOW_TRR(fxh[buf][j], xa[j] + (so), T2_TILE + (ks) * 16 * T2_ROWB + 4 * T2_ROWB);                              \
+        }                                                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                    \
+            TCOW_TRR(fyl[buf][i], ya[i] + (so), (ks) * 16 * T2_ROWB);                                                      \
+            TCOW_TRR(fyh[buf][i], ya[i] + (so), (ks) * 16 * T2_ROWB + 4 * T2_ROWB);                                        \
+        }                                                                                                                  \
+    } while (0)
+#define TCOW_TN_FRAG(lo, hi) __builtin_bit_cast(bf16x8, (u32x4){(lo).x, (lo).y, (hi).x, (hi).y})
+#define TCOW_TN_MFMA8(buf)                                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                          \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                      \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(TCOW_TN_FRAG(fyl[buf][i], fyh[buf][i]), TCOW_TN_FRAG(fxl[buf][j], fxh[buf][j]), acc[i][j], 0, 0, 0)
+
+    if (nmt > 0) TCOW_TN_READ(0, 0, 0u);
     for (int it = 0; it < nmt; ++it) {
         const int stage = it & 1;
+        const uint32_t so = (uint32_t)stage * T2_STAGE;
         if (it + 1 < nmt) issue(mbeg + (it + 1) * T2_MC, stage ^ 1);
         const char* sy = smem + stage * T2_STAGE;
-        const char* sx = sy + T2_TILE;
-#pragma unroll
-        for (int ks = 0; ks < T2_MC / 16; ++ks) {
-            bf16x8 fy[4], fx[2];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) fx[j] = tr_frag512(sx, x_off[j] + ks * 16 * T2_ROWB);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) fy[i] = tr_frag512(sy, y_off[i] + ks * 16 * T2_ROWB);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fy[i], fx[j], acc[i][j], 0, 0, 0);
-        }
+        TCOW_TN_READ(1, 1, so);
+        asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        TCOW_TN_MFMA8(0);
+        TCOW_TN_READ(0, 2, so);
+        asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        TCOW_TN_MFMA8(1);
+        TCOW_TN_READ(1, 3, so);
+        asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        TCOW_TN_MFMA8(0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        TCOW_TN_MFMA8(1);
         if (p.bias_part) {
 #pragma unroll 4
             for (int r = cs_r0; r < cs_r1; ++r) {
@@ -1039,9 +1072,15 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_bf16_256_kernel(TnParams p) {
                 colsum += bf2f(*reinterpret_cast<const bf16_t*>(sy + off));
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();
+        if (it + 1 < nmt) TCOW_TN_READ(0, 0, so ^ (uint32_t)T2_STAGE);
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#undef TCOW_TRR
+#undef TCOW_TN_READ
+#undef TCOW_TN_FRAG
+#undef TCOW_TN_MFMA8
     if (p.bias_part && n0 + cs_col < p.N)
         p.bias_part[(((size_t)z * p.tiles_k + pk) * 2 + (tid >> 8)) * p.N + n0 + cs_col] = colsum;
 
