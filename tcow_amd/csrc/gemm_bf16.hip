@@ -708,7 +708,7 @@ int tcow_gemm_nt_bf16(hipStream_t stream, const tcow_gemm_args* a) {
         // the 320 x 256 tile runs one workgroup per CU: take it when its tiles fill whole rounds of the 256 CUs
         const long t320 = (long)cdiv(a->M, C_BM) * cdiv(a->N, C_BN);
         const long rounds = (t320 + 255) / 256;
-        const bool fills = t320 * 100 >= rounds * 256 * 92;
+        const bool fills = t320 * 100 >= rounds * 256 * 80;   // (measured: still ahead of the 256 / 128 tiles at 88 % -- configs[3], configs[4])
         if (wide && (wide == 2 || (fills && t320 >= 200))) {
             p.tiles_m = cdiv(a->M, C_BM); p.tiles_n = cdiv(a->N, C_BN);
             // epilogue specialisations for the combinations the path uses; anything else takes the run-time-configured kernel
