@@ -549,23 +549,61 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_320_kernel(NtParams p) {
                 ct[(ii * 32 + crow32(r, hi)) * 64 + j * 32 + l31] = a[j][r];
     };
     const int mrow = m0 + wm * 160 + (lane >> 4);
+    const int mrow8 = m0 + wm * 160 + (lane >> 3);
     constexpr bool kRowOps = E::kStatic && E::kRowOps;
     if constexpr (kRowOps) {
         // Row operands (residual / GELU' / row scale) of band b+1 are requested BEFORE band b is stored: their latency overlaps the
         // LDS staging and the stores of the band in front, and -- vmcnt retiring in order -- no load ever queues behind a store.
         // Pipeline unit = one 32-row accumulator band (8 row groups per lane), two operand sets and the two halves of the LDS region
         // in rotation; registers at the peak: 128 accumulators + 2 x 8 row operands.
-        EpiRow oa[8], ob[8];
-        auto fetch = [&](EpiRow* o, int u) {
+        // Each lane handles 8 consecutive columns of a row (16-byte bf16 / 2 x 16-byte f32 accesses): half as many global
+        // instructions per byte as the 4-column mapping, i.e. twice the bytes in flight for these latency-bound operand reads.
+        struct Row8 { float4 e0, e1; float rs; };
+        const int c8 = (lane & 7) * 8, r8 = lane >> 3;                       // 8 lanes x 8 columns = 64 columns, 8 rows per pass
+        const int gn8 = n0 + wn * 64 + c8;
+        const bool ok8 = gn8 < p.N;                                          // N % 8 == 0 in bf16 mode
+        float4 b40 = make_float4(0.f, 0.f, 0.f, 0.f), b41 = b40;
+        if (p.bias && ok8) { b40 = ld4(p.bias + gn8); b41 = ld4(p.bias + gn8 + 4); }
+        Row8 oa[4], ob[4];
+        auto fetch = [&](Row8* o, int u) {
 #pragma unroll
-            for (int it = 0; it < 8; ++it) o[it] = epi_row_fetch<E>(p, mrow + u * 32 + it * 4, gn, col_ok);
+            for (int it = 0; it < 4; ++it) {
+                const int gm = mrow8 + u * 32 + it * 8;
+                Row8 r; r.e0 = make_float4(0.f, 0.f, 0.f, 0.f); r.e1 = r.e0; r.rs = 1.0f;
+                if (ok8 && gm < p.M) {
+                    if (E::rs(p)) r.rs = p.row_scale[gm];
+                    if (E::res(p)) { const float* q = p.resid + (size_t)gm * p.ldr + gn8; r.e0 = ld4(q); r.e1 = ld4(q + 4); }
+                    else if (E::act(p) == TCOW_ACT_MUL_AUX || E::act(p) == TCOW_ACT_DGELU) {
+                        const uint4 u4 = *reinterpret_cast<const uint4*>(p.aux + (size_t)gm * p.ldaux + gn8);
+                        r.e0 = make_float4(bflo(u4.x), bfhi(u4.x), bflo(u4.y), bfhi(u4.y)); r.e1 = make_float4(bflo(u4.z), bfhi(u4.z), bflo(u4.w), bfhi(u4.w));
+                    }
+                }
+                o[it] = r;
+            }
         };
-        auto apply = [&](const EpiRow* o, int u, int half) {
+        auto fin = [&](float4 v, float4 bb, float4 e, float rs) {
+            v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+            if (E::rs(p)) { v.x *= rs; v.y *= rs; v.z *= rs; v.w *= rs; }
+            if (E::act(p) == TCOW_ACT_MUL_AUX) { v.x *= e.x; v.y *= e.y; v.z *= e.z; v.w *= e.w; }
+            else if (E::act(p) == TCOW_ACT_DGELU) v = dgelu4(v, e);
+            if (E::res(p)) { v.x += e.x; v.y += e.y; v.z += e.z; v.w += e.w; }
+            return v;
+        };
+        auto apply = [&](const Row8* o, int u, int half) {
 #pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int gm = mrow + u * 32 + it * 4;
-                if (col_ok && gm < p.M)
-                    epi_row_apply<E>(p, o[it], *reinterpret_cast<const float4*>(ct + (half * 32 + (lane >> 4) + it * 4) * 64 + c4), b4, gm, gn);
+            for (int it = 0; it < 4; ++it) {
+                const int gm = mrow8 + u * 32 + it * 8;
+                if (!(ok8 && gm < p.M)) continue;
+                const float* cr = ct + (half * 32 + r8 + it * 8) * 64 + c8;
+                const float4 v0 = fin(*reinterpret_cast<const float4*>(cr), b40, o[it].e0, o[it].rs);
+                const float4 v1 = fin(*reinterpret_cast<const float4*>(cr + 4), b41, o[it].e1, o[it].rs);
+                if (p.out_f32) {
+                    float* d = reinterpret_cast<float*>(p.C) + (size_t)gm * p.ldc + gn8;
+                    st4(d, v0); st4(d + 4, v1);
+                } else {
+                    uint4 w; w.x = pack_bf2(v0.x, v0.y); w.y = pack_bf2(v0.z, v0.w); w.z = pack_bf2(v1.x, v1.y); w.w = pack_bf2(v1.z, v1.w);
+                    *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)gm * p.ldc + gn8) = w;
+                }
             }
         };
         fetch(oa, 0); stage_band(acc[0], 0);
@@ -715,7 +753,9 @@ int tcow_gemm_nt_bf16(hipStream_t stream, const tcow_gemm_args* a) {
             typedef void (*Kern)(NtParams);
             const int rows = (a->row_scale ? 1 : 0) | (a->resid ? 2 : 0);
             Kern k = gemm_nt_bf16_320_kernel<EpiAny>;
-            if (a->act == TCOW_ACT_NONE && rows == 0) k = gemm_nt_bf16_320_kernel<EpiCfg<TCOW_ACT_NONE, 0>>;
+            const bool vec8 = a->N % 8 == 0 && a->ldc % 8 == 0 && a->ldr % 8 == 0 && a->ldaux % 8 == 0;   // the row-operand epilogues move 8 columns per lane
+            if (!vec8) { /* run-time configured kernel */ }
+            else if (a->act == TCOW_ACT_NONE && rows == 0) k = gemm_nt_bf16_320_kernel<EpiCfg<TCOW_ACT_NONE, 0>>;
             else if (a->act == TCOW_ACT_NONE && rows == 1) k = gemm_nt_bf16_320_kernel<EpiCfg<TCOW_ACT_NONE, 1>>;
             else if (a->act == TCOW_ACT_NONE && rows == 2) k = gemm_nt_bf16_320_kernel<EpiCfg<TCOW_ACT_NONE, 2>>;
             else if (a->act == TCOW_ACT_NONE && rows == 3) k = gemm_nt_bf16_320_kernel<EpiCfg<TCOW_ACT_NONE, 3>>;
