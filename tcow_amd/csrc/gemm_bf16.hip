@@ -621,6 +621,54 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_320_kernel(NtParams p) {
         apply(ob, 3, 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         apply(oa, 4, 0);
+    } else if constexpr (E::kStatic) {
+        // no row operands: a rolled, load-free loop (gfx9 counts stores in vmcnt), again 8 columns per lane: one 16-byte bf16 store
+        // per row piece (two for f32), plus the GELU' store of TCOW_ACT_GELU_DSAVE
+        const int c8 = (lane & 7) * 8, r8 = lane >> 3;
+        const int gn8 = n0 + wn * 64 + c8;
+        const bool ok8 = gn8 < p.N;
+        float4 b40 = make_float4(0.f, 0.f, 0.f, 0.f), b41 = b40;
+        if (p.bias && ok8) { b40 = ld4(p.bias + gn8); b41 = ld4(p.bias + gn8 + 4); }
+        auto rows8 = [&](int row0, int nit) {
+#pragma unroll 1
+            for (int it = 0; it < nit; ++it) {
+                const int gm = mrow8 + row0 + it * 8;
+                if (!(ok8 && gm < p.M)) break;
+                const float* cr = ct + (r8 + it * 8) * 64 + c8;
+                float4 v0 = *reinterpret_cast<const float4*>(cr), v1 = *reinterpret_cast<const float4*>(cr + 4);
+                v0.x += b40.x; v0.y += b40.y; v0.z += b40.z; v0.w += b40.w; v1.x += b41.x; v1.y += b41.y; v1.z += b41.z; v1.w += b41.w;
+                if (E::act(p) == TCOW_ACT_GELU_DSAVE) {
+                    float4 g0, d0, g1, d1; gelu_both4(v0, g0, d0); gelu_both4(v1, g1, d1);
+                    uint4 w; w.x = pack_bf2(d0.x, d0.y); w.y = pack_bf2(d0.z, d0.w); w.z = pack_bf2(d1.x, d1.y); w.w = pack_bf2(d1.z, d1.w);
+                    *reinterpret_cast<uint4*>(p.aux + (size_t)gm * p.ldaux + gn8) = w;
+                    v0 = g0; v1 = g1;
+                } else if (E::act(p) == TCOW_ACT_GELU) {
+                    if (p.aux) {
+                        uint4 w; w.x = pack_bf2(v0.x, v0.y); w.y = pack_bf2(v0.z, v0.w); w.z = pack_bf2(v1.x, v1.y); w.w = pack_bf2(v1.z, v1.w);
+                        *reinterpret_cast<uint4*>(p.aux + (size_t)gm * p.ldaux + gn8) = w;
+                    }
+                    v0 = gelu4(v0); v1 = gelu4(v1);
+                }
+                if (p.out_f32) {
+                    float* d = reinterpret_cast<float*>(p.C) + (size_t)gm * p.ldc + gn8;
+                    st4(d, v0); st4(d + 4, v1);
+                } else {
+                    uint4 w; w.x = pack_bf2(v0.x, v0.y); w.y = pack_bf2(v0.z, v0.w); w.z = pack_bf2(v1.x, v1.y); w.w = pack_bf2(v1.z, v1.w);
+                    *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)gm * p.ldc + gn8) = w;
+                }
+            }
+        };
+        stage_band(acc[0], 0); stage_band(acc[1], 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        rows8(0, 8);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        stage_band(acc[2], 0); stage_band(acc[3], 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        rows8(64, 8);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        stage_band(acc[4], 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        rows8(128, 4);
     } else {
         stage_band(acc[0], 0); stage_band(acc[1], 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
