@@ -499,7 +499,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_320_kernel(NtParams p) {
 #define TCOW_MFMA10(buf)                                                                                                  \
     _Pragma("unroll") for (int i = 0; i < 5; ++i)                                                                        \
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                    \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[buf][i]), __builtin_bit_cast(bf16x8, fw[buf][j]), acc[i][j], 0, 0, 0)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[buf][j]), __builtin_bit_cast(bf16x8, fa[buf][i]), acc[i][j], 0, 0, 0)
 
     issue(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -536,7 +536,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_320_kernel(NtParams p) {
     // ---- epilogue: every wave stages its 160 x 64 tile through a private 16 KiB LDS region, 64 rows at a time (the last pass 32),
     // and writes full 64-column row segments.  No workgroup barrier: a wave's LDS operations execute in order.
     // (explicit passes: a loop over the pass index that the optimizer declines to unroll would index acc[] dynamically -> scratch)
-    float* ct = reinterpret_cast<float*>(smem + wave * 16384);
+    // The MFMAs were issued as (W fragment, A fragment), i.e. the accumulators hold C^T: lane (l31, hi) owns output ROW l31 of
+    // each 32-row band and, per register quad, four consecutive COLUMNS 8g + 4hi .. +3 -- a 16-byte LDS store per quad (40 per
+    // lane and tile instead of 160 four-byte ones).  LDS rows are padded to 68 floats: conflict-free for these writes and for
+    // the 8-columns-per-lane row reads below.
+    constexpr int CT_LD = 68;
+    float* ct = reinterpret_cast<float*>(smem + wave * (64 * CT_LD * 4));
     const int c4 = (lane & 15) * 4;
     const int gn = n0 + wn * 64 + c4;
     const bool col_ok = gn < p.N;
@@ -545,8 +550,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_320_kernel(NtParams p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                ct[(ii * 32 + crow32(r, hi)) * 64 + j * 32 + l31] = a[j][r];
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(ct + (ii * 32 + l31) * CT_LD + j * 32 + 8 * g + 4 * hi) = make_float4(a[j][4 * g], a[j][4 * g + 1], a[j][4 * g + 2], a[j][4 * g + 3]);
     };
     const int mrow = m0 + wm * 160 + (lane >> 4);
     const int mrow8 = m0 + wm * 160 + (lane >> 3);
@@ -594,7 +599,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_320_kernel(NtParams p) {
             for (int it = 0; it < 4; ++it) {
                 const int gm = mrow8 + u * 32 + it * 8;
                 if (!(ok8 && gm < p.M)) continue;
-                const float* cr = ct + (half * 32 + r8 + it * 8) * 64 + c8;
+                const float* cr = ct + (half * 32 + r8 + it * 8) * CT_LD + c8;
                 const float4 v0 = fin(*reinterpret_cast<const float4*>(cr), b40, o[it].e0, o[it].rs);
                 const float4 v1 = fin(*reinterpret_cast<const float4*>(cr + 4), b41, o[it].e1, o[it].rs);
                 if (p.out_f32) {
@@ -634,7 +639,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_320_kernel(NtParams p) {
             for (int it = 0; it < nit; ++it) {
                 const int gm = mrow8 + row0 + it * 8;
                 if (!(ok8 && gm < p.M)) break;
-                const float* cr = ct + (r8 + it * 8) * 64 + c8;
+                const float* cr = ct + (r8 + it * 8) * CT_LD + c8;
                 float4 v0 = *reinterpret_cast<const float4*>(cr), v1 = *reinterpret_cast<const float4*>(cr + 4);
                 v0.x += b40.x; v0.y += b40.y; v0.z += b40.z; v0.w += b40.w; v1.x += b41.x; v1.y += b41.y; v1.z += b41.z; v1.w += b41.w;
                 if (E::act(p) == TCOW_ACT_GELU_DSAVE) {
@@ -672,15 +677,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_320_kernel(NtParams p) {
     } else {
         stage_band(acc[0], 0); stage_band(acc[1], 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (col_ok) epi_rows<16, E>(p, ct, 64, b4, mrow, lane >> 4, 4, c4, gn);
+        if (col_ok) epi_rows<16, E>(p, ct, CT_LD, b4, mrow, lane >> 4, 4, c4, gn);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         stage_band(acc[2], 0); stage_band(acc[3], 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (col_ok) epi_rows<16, E>(p, ct, 64, b4, mrow + 64, lane >> 4, 4, c4, gn);
+        if (col_ok) epi_rows<16, E>(p, ct, CT_LD, b4, mrow + 64, lane >> 4, 4, c4, gn);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         stage_band(acc[4], 0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (col_ok) epi_rows<8, E>(p, ct, 64, b4, mrow + 128, lane >> 4, 4, c4, gn);
+        if (col_ok) epi_rows<8, E>(p, ct, CT_LD, b4, mrow + 128, lane >> 4, 4, c4, gn);
     }
 }
 
