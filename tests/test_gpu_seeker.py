@@ -196,3 +196,39 @@ def test_persistent_gradient_buckets(cuda):
         if persistent:
             assert ptrs[0] == ptrs[1]
     assert all(torch.equal(a, b) for a, b in zip(grads[False], grads[True]))
+
+
+def test_training_is_bitwise_reproducible(cuda):
+    """Two runs of the full training step (pipeline, HIP forward / backward, TCOW objective, fused clip + AdamW, seeded DropPath)
+    give bit-identical loss curves: no kernel on the path accumulates floating-point data with atomics, and a race in the
+    hand-synchronised kernels (counted waits, barrier-free epilogues) would show up here as a difference."""
+    from tcow_amd.optim import FusedAdamWClip
+    from tcow_amd.pipeline import SeekerPipeline
+    from tcow_amd.seeker import Seeker
+    from tcow_amd.tcow_loss import default_args
+    T, H, W, depth, steps = 30, 240, 320, 4, 5
+
+    def run():
+        torch.manual_seed(0)
+        cfg = synth.seeker_config(num_total_frames=T, frame_height=H, frame_width=W, depth=depth, causal_attention=1)
+        net = Seeker(None, num_total_frames=T, frame_height=H, frame_width=W, causal_attention=1, drop_path_rate=0.1, network_depth=depth, embed_dim=768, num_heads=12,
+                     precision='bf16')
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg, 900).items()})
+        net = net.cuda().train()
+        opt = FusedAdamWClip(list(net.parameters()), lr=1e-4, max_norm=0.3)
+        opt.on_step.append(net.seeker.invalidate_weight_cache); net.seeker.persistent_grads = True
+        data = synth.to_torch_tree(synth.make_kubric_batch(1, T, H, W, seed=900, n_objects=5), 'cuda', host_keys=synth.HOST_KEYS)
+        pipe = SeekerPipeline(net, num_queries=3, train_args=default_args(), phase='train', device='cuda', rng=np.random.default_rng(0))
+        losses = []
+        for i in range(steps):
+            mr = pipe.forward_kubric(data)
+            loss = pipe.step_losses(data, mr, 0.1 + i / 100.0)['total_seeker']          # progress > 0: the radix top-k path is active
+            loss.backward(); opt.step()
+            losses.append(loss.detach())
+        w = net.seeker.tracker_post_linear.weight.detach().clone()
+        return torch.stack(losses).cpu().numpy(), w.cpu().numpy()
+
+    (la, wa), (lb, wb) = run(), run()
+    assert np.isfinite(la).all()
+    assert np.array_equal(la, lb), (la, lb)
+    assert np.array_equal(wa, wb)
