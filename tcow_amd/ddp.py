@@ -43,25 +43,42 @@ class GradSync:
     per completed bucket and drains it (`finish()`) before handing the gradients to autograd, so after `loss.backward()`
     every param.grad is already the mean over ranks."""
 
-    def __init__(self, world_size=None, group=None):
+    def __init__(self, world_size=None, group=None, overlap=None):
+        """overlap: launch each bucket's all-reduce as soon as the backward has produced it (default; `TCOW_DDP_OVERLAP=0` or
+        overlap=False issues them all after the last bucket instead -- the fallback should RCCL kernels holding CUs during the
+        backward cost more than they hide)."""
         self.group = group
         self.world = world_size if world_size is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
+        self.overlap = (os.environ.get('TCOW_DDP_OVERLAP', '1') != '0') if overlap is None else bool(overlap)
+        # sum + one scale pass by default (works on every backend); TCOW_DDP_AVG=1 lets RCCL average inside the collective
+        self.native_avg = os.environ.get('TCOW_DDP_AVG', '0') == '1' and dist.is_initialized() and dist.get_backend(group) == 'nccl'
         self.pending = []
+        self.deferred = []
         self.bytes = 0
         self.launched = []
+
+    def _launch(self, flat):
+        op = dist.ReduceOp.AVG if self.native_avg else dist.ReduceOp.SUM
+        self.pending.append((dist.all_reduce(flat, op=op, group=self.group, async_op=True), flat))
 
     def __call__(self, name, flat):
         if self.world <= 1 or flat.numel() == 0:
             return
         self.launched.append(name)
         self.bytes += flat.numel() * flat.element_size()
-        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        self.pending.append((work, flat))
+        if self.overlap:
+            self._launch(flat)
+        else:
+            self.deferred.append(flat)
 
     def finish(self):
+        for flat in self.deferred:
+            self._launch(flat)
+        self.deferred = []
         for work, flat in self.pending:
             work.wait()                      # makes the current stream wait for the collective
-            flat.mul_(1.0 / self.world)      # sum -> mean (loss.py:356-369 averages the per-replica losses)
+            if not self.native_avg:
+                flat.mul_(1.0 / self.world)  # sum -> mean (loss.py:356-369 averages the per-replica losses)
         self.pending = []
 
 
