@@ -22,6 +22,13 @@ def _worker(rank, world, port, q):
         sync(name, flat)                       # engine.run_backward fires the hook in exactly this way, bucket by bucket
     sync.finish()
     ok = all(torch.allclose(flat, torch.full_like(flat, 1.5 * (i + 1))) for i, flat in enumerate(buckets.values()))
+    late = ddp.GradSync(world, overlap=False)          # the non-overlapped fallback: nothing is sent before finish()
+    b2 = {name: torch.full((n,), float(rank + 1) * (i + 1)) for i, (name, n) in enumerate([('head', 5), (0, 64)])}
+    for name, flat in b2.items():
+        late(name, flat)
+    ok = ok and len(late.pending) == 0 and all(torch.equal(flat, torch.full_like(flat, float(rank + 1) * (i + 1))) for i, flat in enumerate(b2.values()))
+    late.finish()
+    ok = ok and all(torch.allclose(flat, torch.full_like(flat, 1.5 * (i + 1))) for i, flat in enumerate(b2.values()))
     lin = torch.nn.Linear(4, 4)
     torch.manual_seed(rank); torch.nn.init.normal_(lin.weight)
     ddp.broadcast_parameters(lin)
