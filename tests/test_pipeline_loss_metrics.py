@@ -216,3 +216,22 @@ def test_mask_builder_and_weight_kernels_match_tensor_path(cuda, phase):
     assert int((wc != wc[0, 0, 0, 0, 0]).sum()) > 0                          # (not a constant map)
     for k in ('track', 'occl_mask', 'cont_mask', 'total_seeker'):
         assert abs(float(res['cuda'][1][k]) - float(res['cpu'][1][k])) < 5e-6, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('class_balancing,factor', [(True, 3.0), (False, 3.0), (True, 1.0), (False, 1.0)])
+def test_snitch_weight_kernel_options(cuda, class_balancing, factor):
+    """tcow_snitch_weights with class balancing / the hard-negative band switched on and off vs TcowLosses.pixel_weights * frame weights."""
+    from tcow_amd import ops
+    from tcow_amd.tcow_loss import TcowLosses
+    torch.manual_seed(11)
+    Bn, Qn, Tn, Hn, Wn = 1, 2, 3, 48, 80
+    tgt = torch.zeros(Bn, Qn, 3, Tn, Hn, Wn)
+    tgt[:, :, 0, :, 10:30, 20:50] = 1.0; tgt[0, 1, 0, 1] = 0.0              # one frame without the snitch
+    ptr = (torch.rand(Bn, Qn, 1, Tn, Hn, Wn) > 0.9).to(torch.uint8) * 3
+    fw = torch.rand(Bn, Qn, Tn) + 0.5
+    L = TcowLosses(default_args(class_balancing=class_balancing, hard_negative_factor=factor))
+    want = fw[..., None, None] * L.pixel_weights(tgt[:, :, 0], ptr[:, :, 0])
+    pos = (tgt[:, :, 0] == 1).sum().to(torch.int32).reshape(1)
+    got = ops.snitch_weights(tgt.cuda(), ptr.cuda(), fw.cuda(), pos.cuda(), class_balancing, factor).cpu()
+    assert got.shape == want.shape and float((got - want).abs().max()) < 1e-5 * float(want.abs().max())
