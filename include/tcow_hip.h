@@ -180,6 +180,11 @@ int tcow_flags_fwd(void* stream, int BT, int S, int D, int F, const float* x, co
 int tcow_scale_cast(void* stream, int dtype, long rows, int D, const float* src, long ld_src, const float* row_scale,
                     void* dst, long ld_dst);
 int tcow_cast_transpose(void* stream, int dtype, int N, int K, const float* W, void* Wc, void* Wt);
+/* The same for many weights in one launch: `table` is a device array of n records {const float* W; void* Wc; void* Wt; int N;
+ * int K; int tile_begin; int pad} (tcow_cast_desc_bytes() bytes each, 8-byte aligned), tile_begin = running sum of
+ * ceil(N/32) * ceil(K/32) over the preceding records, total_tiles = that sum over all records.  Wc / Wt may be NULL per record. */
+long tcow_cast_desc_bytes(void);
+int tcow_cast_transpose_batched(void* stream, int dtype, const void* table, int n, int total_tiles);
 
 /* ------------------------------------------------------------------------------------------- optimizer step
  * clip_grad_norm_(params, max_norm) followed by AdamW.step() (train.py:99-102; torch defaults) in three

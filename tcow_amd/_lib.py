@@ -74,6 +74,8 @@ SIGNATURES = {
     'tcow_flags_fwd': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'tcow_scale_cast': (_i, [_vp, _i, _l, _i, _vp, _l, _vp, _vp, _l]),
     'tcow_cast_transpose': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
+    'tcow_cast_desc_bytes': (_l, []),
+    'tcow_cast_transpose_batched': (_i, [_vp, _i, _vp, _i, _i]),
     'tcow_adamw_chunk_bytes': (_l, []),
     'tcow_adamw_clip_step': (_i, [_vp, _vp, _i, _f, _f, _f, _f, _f, _i, _f, _vp]),
     'tcow_mask_loss_workspace_bytes': (ctypes.c_size_t, [_l, _l]),

@@ -257,6 +257,34 @@ __global__ __launch_bounds__(1024) void flags_fwd_kernel(int S, int D, int F, co
     }
 }
 
+// All operand copies of a step in ONE launch: a device-resident table of (W, Wc, Wt, N, K, first tile) records, one 32x32 tile per
+// workgroup; the workgroup finds its record by bisection on the first-tile column (86 weights -> 7 steps).
+struct CastDesc { const float* W; void* Wc; void* Wt; int N, K, tile_begin, pad; };
+template <typename T>
+__global__ __launch_bounds__(256) void cast_transpose_batched_kernel(const CastDesc* __restrict__ tab, int n) {
+    __shared__ float tile[32][33];
+    int lo = 0, hi = n - 1;
+    const int b = blockIdx.x;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (tab[mid].tile_begin <= b) lo = mid; else hi = mid - 1; }
+    const CastDesc d = tab[lo];
+    const int t = b - d.tile_begin, tiles_k = (d.K + 31) / 32;
+    const int n0 = (t / tiles_k) * 32, k0 = (t - (t / tiles_k) * tiles_k) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    T* Wc = reinterpret_cast<T*>(d.Wc); T* Wt = reinterpret_cast<T*>(d.Wt);
+    for (int r = ty; r < 32; r += 8) {
+        const int nn = n0 + r, k = k0 + tx;
+        float v = 0.f;
+        if (nn < d.N && k < d.K) { v = d.W[(size_t)nn * d.K + k]; if (Wc) Elem<T>::st(Wc + (size_t)nn * d.K + k, v); }
+        tile[r][tx] = v;
+    }
+    __syncthreads();
+    if (Wt)
+        for (int r = ty; r < 32; r += 8) {
+            const int k = k0 + r, nn = n0 + tx;
+            if (k < d.K && nn < d.N) Elem<T>::st(Wt + (size_t)k * d.N + nn, tile[tx][r]);
+        }
+}
+
 // ------------------------------------------------------------------------------------------ casts
 // dst = T(src * row_scale[row])  (f32 -> T), used to turn residual-stream gradients into GEMM operands
 template <typename T>
@@ -388,6 +416,17 @@ int tcow_cast_transpose(void* stream, int dtype, int N, int K, const float* W, v
     if (dtype == TCOW_BF16) hipLaunchKernelGGL(cast_transpose_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, N, K, W, (bf16_t*)Wc, (bf16_t*)Wt);
     else if (dtype == TCOW_F32) hipLaunchKernelGGL(cast_transpose_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, N, K, W, (float*)Wc, (float*)Wt);
     else { tcow_set_error("tcow_cast_transpose: unknown dtype %d", dtype); return TCOW_ERR_INVALID_ARG; }
+    TCOW_CHECK_LAUNCH();
+    return TCOW_OK;
+}
+
+long tcow_cast_desc_bytes(void) { return (long)sizeof(CastDesc); }
+
+int tcow_cast_transpose_batched(void* stream, int dtype, const void* table, int n, int total_tiles) {
+    TCOW_CHECK_ARG(table && n > 0 && total_tiles > 0, "tcow_cast_transpose_batched: bad arguments");
+    if (dtype == TCOW_BF16) hipLaunchKernelGGL(cast_transpose_batched_kernel<bf16_t>, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, (const CastDesc*)table, n);
+    else if (dtype == TCOW_F32) hipLaunchKernelGGL(cast_transpose_batched_kernel<float>, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, (const CastDesc*)table, n);
+    else { tcow_set_error("tcow_cast_transpose_batched: unknown dtype %d", dtype); return TCOW_ERR_INVALID_ARG; }
     TCOW_CHECK_LAUNCH();
     return TCOW_OK;
 }

@@ -48,7 +48,45 @@ def _get_weight(module, p, train):
             Wt = torch.empty(K, N, dtype=dt, device=w.device)
             ops.cast_transpose(mode, Wc, None, Wt)
     module._wcache[key] = (ver, mode, Wc, Wt)
+    if train:
+        # remember the buffers: after an optimizer step refresh_weights() re-casts ALL registered weights in one launch
+        reg = module.__dict__.setdefault('_wreg', {})
+        reg[key] = (p, Wc if mode == ops.BF16 else None, Wt, N, K)
     return Wc, Wt
+
+
+def refresh_weights(module):
+    """Re-cast every registered GEMM weight (bf16 copy + transposed copy) with ONE kernel launch instead of one per weight;
+    called by QueryMaskTracker.invalidate_weight_cache() right after the optimizer has written the f32 master weights."""
+    import struct
+    reg = getattr(module, '_wreg', None)
+    if not reg:
+        return False
+    mode = module.mode
+    ents = list(reg.items())
+    sig = tuple((k, p.data_ptr(), 0 if Wc is None else Wc.data_ptr(), 0 if Wt is None else Wt.data_ptr()) for k, (p, Wc, Wt, N, K) in ents) + (mode,)
+    tab = module.__dict__.get('_wtab')
+    if tab is None or tab[0] != sig:
+        rec, tiles = [], 0
+        for k, (p, Wc, Wt, N, K) in ents:
+            rec.append(struct.pack('<QQQiiii', p.data_ptr(), 0 if Wc is None else Wc.data_ptr(), 0 if Wt is None else Wt.data_ptr(), N, K, tiles, 0))
+            tiles += ((N + 31) // 32) * ((K + 31) // 32)
+        assert len(rec[0]) == L_cast_desc_bytes()
+        dev = ents[0][1][0].device
+        buf = torch.frombuffer(bytearray(b''.join(rec)), dtype=torch.uint8).to(dev)
+        tab = (sig, buf, len(rec), tiles)
+        module.__dict__['_wtab'] = tab
+    ops.cast_transpose_batched(mode, tab[1], tab[2], tab[3])
+    epoch = getattr(module, '_wepoch', 0)
+    for k, (p, Wc, Wt, N, K) in ents:
+        w = _w2d(p.detach())
+        module._wcache[k] = ((p._version, epoch), mode, Wc if Wc is not None else w.contiguous(), Wt)
+    return True
+
+
+def L_cast_desc_bytes():
+    from . import _lib
+    return int(_lib.lib().tcow_cast_desc_bytes())
 
 
 def _row_vectors(module, g, train):

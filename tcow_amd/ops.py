@@ -164,6 +164,11 @@ def cast_transpose(mode, W, Wc=None, Wt=None):
     L.check(L.lib().tcow_cast_transpose(_stream(), mode, N, K, W.data_ptr(), _p(Wc), _p(Wt)), 'tcow_cast_transpose')
 
 
+def cast_transpose_batched(mode, table, n, total_tiles):
+    """One launch for all operand copies; `table` is the uint8 device tensor of tcow_cast_desc records (see tcow_cast_transpose_batched)."""
+    L.check(L.lib().tcow_cast_transpose_batched(_stream(), mode, table.data_ptr(), int(n), int(total_tiles)), 'tcow_cast_transpose_batched')
+
+
 def mask_loss(logits, target, channel, pixel_w=None, frame_w=None, weighted_aot=False, aot_loss=0.8, topk_frac=1.0,
               loss_weight=1.0, loss_out=None, total=None, dlogits=None):
     """Channel `channel` of the TCOW mask objective on (BQ, C, T, H, W) f32 logits / targets (see tcow_mask_loss):

@@ -200,15 +200,20 @@ class QueryMaskTracker(nn.Module):
         self.precision = precision
         self.mode = ops.BF16 if precision == 'bf16' else ops.F32
         self._wcache = {}
+        self.__dict__.pop('_wreg', None); self.__dict__.pop('_wtab', None)
         return self
 
     def invalidate_weight_cache(self):
         """Call after updating parameters through raw pointers (tcow_amd.optim.FusedAdamWClip does): in-place torch ops bump the
         parameters' autograd version counters, which the operand cache checks on its own."""
         self._wepoch = getattr(self, '_wepoch', 0) + 1
+        if self.__dict__.get('_wreg'):
+            from . import engine
+            engine.refresh_weights(self)       # all operand copies of the next step in one launch
 
     def _apply(self, fn, *a, **k):
         self._wcache = {}
+        self.__dict__.pop('_wreg', None); self.__dict__.pop('_wtab', None)
         self._gbufs = {}
         return super()._apply(fn, *a, **k)
 
