@@ -169,22 +169,34 @@ __device__ __forceinline__ void bil_src(int dst, int in, int out, int& i0, int& 
     i1 = i0 + ((i0 < in - 1) ? 1 : 0);
     w1 = src - (float)i0; w0 = 1.0f - w1;
 }
+// one workgroup column per (b, c, t) frame (blockIdx.y), 4 consecutive output pixels per thread (W is a multiple of st; a 16-byte
+// store when W % 4 == 0), 32-bit index arithmetic only
 __global__ void upsample_fwd_kernel(int B, int T_, int C, int h, int w, int st, int bilinear, const float* __restrict__ pooled, float* __restrict__ out) {
     const int H = h * st, W = w * st;
-    const long total = (long)B * C * T_ * H * W;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int x = (int)(i % W); const int y = (int)((i / W) % H); const int t = (int)((i / ((long)W * H)) % T_);
-        const int c = (int)((i / ((long)W * H * T_)) % C); const int b = (int)(i / ((long)W * H * T_ * C));
-        const float* src = pooled + (((size_t)(b * T_ + t)) * C + c) * h * w;
-        float v;
-        if (bilinear) {
-            int y0, y1, x0, x1; float wy0, wy1, wx0, wx1;
-            bil_src(y, h, H, y0, y1, wy0, wy1); bil_src(x, w, W, x0, x1, wx0, wx1);
-            v = wy0 * (wx0 * src[y0 * w + x0] + wx1 * src[y0 * w + x1]) + wy1 * (wx0 * src[y1 * w + x0] + wx1 * src[y1 * w + x1]);
-        } else {
-            v = src[(y / st) * w + (x / st)];
+    const int f = blockIdx.y;                                   // (b*C + c)*T_ + t  (output layout B,C,T,H,W)
+    const int t = f % T_, bc = f / T_, c = bc % C, b = bc / C;
+    const float* src = pooled + (((size_t)(b * T_ + t)) * C + c) * h * w;
+    float* dst = out + (size_t)f * H * W;
+    const int Wq = (W + 3) / 4;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < H * Wq; i += gridDim.x * blockDim.x) {
+        const int y = i / Wq, x0q = (i - y * Wq) * 4;
+        float v[4];
+        int y0, y1; float wy0, wy1;
+        if (bilinear) bil_src(y, h, H, y0, y1, wy0, wy1);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int x = x0q + e < W ? x0q + e : W - 1;
+            if (bilinear) {
+                int x0, x1; float wx0, wx1;
+                bil_src(x, w, W, x0, x1, wx0, wx1);
+                v[e] = wy0 * (wx0 * src[y0 * w + x0] + wx1 * src[y0 * w + x1]) + wy1 * (wx0 * src[y1 * w + x0] + wx1 * src[y1 * w + x1]);
+            } else {
+                v[e] = src[(y / st) * w + (x / st)];
+            }
         }
-        out[i] = v;
+        float* o = dst + (size_t)y * W + x0q;
+        if ((W & 3) == 0) st4(o, make_float4(v[0], v[1], v[2], v[3]));
+        else for (int e = 0; e < 4 && x0q + e < W; ++e) o[e] = v[e];
     }
 }
 // gather-form backward: one thread per pooled pixel sums the output pixels that read it
@@ -198,8 +210,13 @@ __global__ void upsample_bwd_kernel(int B, int T_, int C, int h, int w, int st, 
         float a = 0.f;
         if (bilinear) {
             // candidate output rows: those whose i0 or i1 can equal Y
-            int ylo = (Y - 1) * st - st, yhi = (Y + 1) * st + st; if (ylo < 0) ylo = 0; if (yhi > H - 1) yhi = H - 1;
-            int xlo = (X - 1) * st - st, xhi = (X + 1) * st + st; if (xlo < 0) xlo = 0; if (xhi > W - 1) xhi = W - 1;
+            // an output row y reads pooled rows floor(s*y) and floor(s*y)+1, s = (h-1)/(H-1): Y is among them only for
+            // (Y-1)/s < y < (Y+1)/s -- about 2/s + 1 rows (9 at stride 4) instead of the 4*st + 1 of the safe bound
+            const float isy = (h > 1) ? (float)(H - 1) / (float)(h - 1) : 0.f, isx = (w > 1) ? (float)(W - 1) / (float)(w - 1) : 0.f;
+            int ylo = (int)((float)(Y - 1) * isy) - 1, yhi = (int)((float)(Y + 1) * isy) + 2; if (ylo < 0) ylo = 0; if (yhi > H - 1) yhi = H - 1;
+            int xlo = (int)((float)(X - 1) * isx) - 1, xhi = (int)((float)(X + 1) * isx) + 2; if (xlo < 0) xlo = 0; if (xhi > W - 1) xhi = W - 1;
+            if (h <= 1) { ylo = 0; yhi = H - 1; }
+            if (w <= 1) { xlo = 0; xhi = W - 1; }
             for (int y = ylo; y <= yhi; ++y) {
                 int y0, y1; float wy0, wy1; bil_src(y, h, H, y0, y1, wy0, wy1);
                 float wy = 0.f; if (y0 == Y) wy += wy0; if (y1 == Y) wy += wy1;
@@ -380,7 +397,9 @@ int tcow_unpatchify_pool_bwd(void* stream, int dtype, int BT, int Hp, int Wp, in
 
 int tcow_upsample_fwd(void* stream, int B, int T_, int C, int h, int w, int st, int bilinear, const float* pooled, float* out) {
     TCOW_CHECK_ARG(B > 0 && T_ > 0 && C > 0 && h > 0 && w > 0 && st > 0 && pooled && out, "tcow_upsample_fwd: bad arguments");
-    hipLaunchKernelGGL(upsample_fwd_kernel, dim3(gs_blocks((long)B * C * T_ * h * w * st * st)), dim3(256), 0, (hipStream_t)stream, B, T_, C, h, w, st, bilinear, pooled, out);
+    TCOW_CHECK_ARG((long)B * C * T_ < 65536, "tcow_upsample_fwd: too many frames for one call");
+    { const int per = h * st * ((w * st + 3) / 4); int gx = cdiv(per, 256); if (gx > 64) gx = 64;
+      hipLaunchKernelGGL(upsample_fwd_kernel, dim3(gx, B * C * T_), dim3(256), 0, (hipStream_t)stream, B, T_, C, h, w, st, bilinear, pooled, out); }
     TCOW_CHECK_LAUNCH();
     return TCOW_OK;
 }
