@@ -34,6 +34,8 @@ def parse():
     ap.add_argument('--height', type=int, default=240)
     ap.add_argument('--width', type=int, default=320)
     ap.add_argument('--depth', type=int, default=12)
+    ap.add_argument('--grad-dtype', default='f32', choices=['f32', 'bf16'], help='dtype of the all-reduced gradient buckets (N > 1)')
+    ap.add_argument('--launch-selftest', action='store_true', help='only start the ranks, all-reduce one number and print the rank count (CPU-runnable check of the N > 1 launch path)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-budget-s', type=float, default=25.0)
     return ap.parse_args()
@@ -94,12 +96,38 @@ def cpu_baseline(cfg, budget_s):
                 f'optimizer step not included')
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks ourselves (one process per GPU, RCCL) as a CHILD
+    process -- never exec: a process that may have touched the GPU must not replace itself -- relay its output and return its exit
+    code.  Nothing in this process has initialised HIP at this point (torch is imported, torch.cuda is untouched)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0)); port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ); env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(args))
     from tcow_amd import ddp, flops, ops, synth
     from tcow_amd.seeker import Seeker
     rank, local_rank, world = ddp.init_distributed()
-    assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    if args.launch_selftest:
+        one = torch.ones(1)
+        if world > 1:
+            torch.distributed.all_reduce(one.cuda() if torch.distributed.get_backend() == 'nccl' else one)
+        if rank == 0:
+            print(json.dumps(dict(selftest='launch', n_gpus=world, ranks_seen=(torch.distributed.get_world_size() if world > 1 else 1), gpus_arg=args.gpus)), flush=True)
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the rank count must match (torch.distributed.run --nproc-per-node {args.gpus})')
     ndev = max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank % ndev)              # (% ndev only matters for the single-GPU gloo dry run of the N>1 path)
     dev = torch.device('cuda', local_rank % ndev)
@@ -114,10 +142,9 @@ def main():
     ddp.broadcast_parameters(net)
     params = [p for p in net.parameters()]
     from tcow_amd.optim import FusedAdamWClip
-    opt = FusedAdamWClip(params, lr=1e-4, max_norm=0.3)                    # train.py:99-102,239-241: clip_grad_norm_(0.3) + AdamW(lr 1e-4), fused
-    opt.on_step.append(net.seeker.invalidate_weight_cache)
+    opt = FusedAdamWClip(params, lr=1e-4, max_norm=0.3, module=net)        # train.py:99-102,239-241: clip_grad_norm_(0.3) + AdamW(lr 1e-4), fused
     net.seeker.persistent_grads = True                                     # one backward per step: gradients live in persistent flat buckets
-    sync = ddp.GradSync(world)
+    sync = ddp.GradSync(world, bucket_dtype=args.grad_dtype)
     net.seeker.grad_hook = sync
 
     # synthetic Kubric-shaped batch for this rank: 1 clip, Qs queries chosen by desirability, query_time 0 (README.md:42)
@@ -175,7 +202,7 @@ def main():
                     achieved=ks['tflops'], peak=peak, unit='TFLOP/s', frac=ks['tflops'] / peak, traffic=traffic,
                     launches_per_step=ks['launches'] / args.steps, avg_launch_us=ks['avg_us'], flops_per_launch=ks['flops_per_launch'])
         step_tflops = 3.0 * Qs * fl['total'] / (ms_per_step * 1e-3) / 1e12
-        res = dict(metric='train clips/sec (T=30, 240x320)', value=clips_per_s, unit='clips/s', n_gpus=world, steps=args.steps,
+        res = dict(metric='train clips/sec (T=30, 240x320)', value=clips_per_s, unit='clips/s', n_gpus=world, ranks_seen=(torch.distributed.get_world_size() if world > 1 else 1), steps=args.steps,
                    warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True, scaling='weak', vs_baseline=None,
                    dtype='bf16' if args.precision == 'bf16' else 'f32', data='synthetic',
                    config=dict(workload=f'TCOW Seeker train step: T={args.frames} {args.height}x{args.width} patch16, {args.depth}-layer divided '

@@ -76,6 +76,7 @@ typedef struct {
     const float* resid; long ldr;
     int act;
     void* aux; long ldaux;
+    int tile;              /* 0 = choose by shape; 128 / 256 / 320 = force that bf16 NT tile kernel (tests and A/B runs) */
 } tcow_gemm_args;
 int tcow_gemm_nt(void* stream, const tcow_gemm_args* args);
 

@@ -93,7 +93,7 @@ def load():
     return _loaded
 
 
-def build_reference_seeker(cfg, np_state_dict):
+def build_reference_seeker(cfg, np_state_dict, drop_path_rate=0.0):
     """Instantiate the reference Seeker for a tcow_amd.synth config and load our synthetic weights.
     Non-{12,18,24} depths are not constructible through Seeker(network_depth=...) (vit.py:424-449), so
     for those a VisionTransformer of the requested geometry is grafted in."""
@@ -106,7 +106,7 @@ def build_reference_seeker(cfg, np_state_dict):
     kw = dict(num_total_frames=cfg['num_total_frames'], frame_height=cfg['frame_height'],
               frame_width=cfg['frame_width'], tracker_pretrained=False, attention_type='divided_space_time',
               patch_size=cfg['patch_size'], causal_attention=cfg['causal_attention'],
-              norm_embeddings=cfg['norm_embeddings'], drop_path_rate=0.0,
+              norm_embeddings=cfg['norm_embeddings'], drop_path_rate=drop_path_rate,
               network_depth=depth if native else 12, track_map_stride=cfg['track_map_stride'],
               track_map_resize=cfg['track_map_resize'], query_channels=cfg['query_channels'],
               output_channels=cfg['output_channels'], flag_channels=cfg['flag_channels'])
@@ -121,7 +121,7 @@ def build_reference_seeker(cfg, np_state_dict):
             img_size=(cfg['frame_height'], cfg['frame_width']), patch_size=cfg['patch_size'],
             in_chans=3 + cfg['query_channels'], num_classes=0, embed_dim=D, depth=depth, num_heads=heads,
             mlp_ratio=cfg['mlp_ratio'], qkv_bias=True, norm_layer=partial(torch.nn.LayerNorm, eps=1e-6),
-            drop_path_rate=0., num_frames=cfg['num_total_frames'], attention_type='divided_space_time',
+            drop_path_rate=drop_path_rate, num_frames=cfg['num_total_frames'], attention_type='divided_space_time',
             causal_attention=cfg['causal_attention'])
         bb = qt.tracker_backbone
         bb.timesformer.model = vt

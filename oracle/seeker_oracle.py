@@ -228,3 +228,13 @@ def seeker_forward(sd, cfg, input_frames, query_mask, drop_masks=None, taps=None
 
 def to_torch_state_dict(np_sd, dtype=torch.float32):
     return {k: torch.from_numpy(v).to(dtype) for k, v in np_sd.items()}
+
+
+def grad_sample(g):
+    """Strided sample of a large gradient (numpy): every 7th row x every 5th column of its 2-D view [shape[0] (or, for a leading
+    1, the flattened middle dims), last dims] -- co-prime strides so that no tile / lane pattern of a kernel is systematically
+    skipped.  Used by oracle/make_golden_r2.py (g7) and by the GPU test that checks against it."""
+    import numpy as np
+    g = np.asarray(g)
+    g2 = g.reshape(g.shape[0], -1) if g.shape[0] > 1 else g.reshape(-1, g.shape[-1])
+    return np.ascontiguousarray(g2[::7, ::5])

@@ -27,7 +27,7 @@ class GemmArgs(ctypes.Structure):
                 ('A', ctypes.c_void_p), ('lda', ctypes.c_long), ('W', ctypes.c_void_p), ('ldw', ctypes.c_long),
                 ('C', ctypes.c_void_p), ('ldc', ctypes.c_long), ('out_f32', ctypes.c_int),
                 ('bias', ctypes.c_void_p), ('row_scale', ctypes.c_void_p), ('resid', ctypes.c_void_p),
-                ('ldr', ctypes.c_long), ('act', ctypes.c_int), ('aux', ctypes.c_void_p), ('ldaux', ctypes.c_long)]
+                ('ldr', ctypes.c_long), ('act', ctypes.c_int), ('aux', ctypes.c_void_p), ('ldaux', ctypes.c_long), ('tile', ctypes.c_int)]
 
 
 class MaskLossArgs(ctypes.Structure):

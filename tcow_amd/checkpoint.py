@@ -16,21 +16,37 @@ import torch.nn.functional as F
 from ._lib import TcowError
 
 
-def pretrained_surgery(state_dict, in_chans, num_patches, num_frames):
-    """helpers.py:117-199 on a plain ViT state dict (keys relative to the VisionTransformer)."""
+def _conv_filter(sd, patch_size=16):
+    """vit.py:381-390: a patch-embedding weight stored as a flattened linear projection becomes a (D, 3, P, P) conv weight."""
+    out = {}
+    for k, v in sd.items():
+        if 'patch_embed.proj.weight' in k:
+            if v.shape[-1] != patch_size:
+                patch_size = v.shape[-1]
+            v = v.reshape((v.shape[0], 3, patch_size, patch_size))
+        out[k] = v
+    return out
+
+
+def pretrained_surgery(state_dict, in_chans, num_patches, num_frames, patch_size=16):
+    """helpers.py:100-205 (`load_pretrained` as TimeSformer.__init__ calls it, vit.py:462-464: num_classes = 0, filter_fn =
+    _conv_filter, attention_type = 'divided_space_time') on a plain image-ViT state dict; returns the dict that is then loaded
+    non-strictly.  Pinned key-for-key against the reference's own function in tests/golden/g10_pretrained.npz."""
     sd = dict(state_dict)
     if 'model' in sd and isinstance(sd['model'], dict):
         sd = dict(sd['model'])                                            # helpers.py:113-114
+    sd = _conv_filter(sd, patch_size)                                     # helpers.py:116-117
     w = sd.get('patch_embed.proj.weight')
     if w is not None and in_chans != 3:
+        conv_type = w.dtype
         w = w.float()
         if w.shape[1] != 3:
             del sd['patch_embed.proj.weight']                             # helpers.py:141-144
         else:
             rep = int(math.ceil(in_chans / 3))
             w = w.repeat(1, rep, 1, 1)[:, :in_chans] * (3 / float(in_chans))   # helpers.py:146-150
-            sd['patch_embed.proj.weight'] = w
-    for k in ('head.weight', 'head.bias'):                                # num_classes == 0 -> dropped (helpers.py:160-165)
+            sd['patch_embed.proj.weight'] = w.to(conv_type)
+    for k in ('head.weight', 'head.bias'):                                # num_classes == 0 != 1000 -> classifier dropped (helpers.py:160-165)
         sd.pop(k, None)
     if 'pos_embed' in sd and num_patches + 1 != sd['pos_embed'].size(1):  # helpers.py:169-176
         pe = sd['pos_embed']
@@ -54,28 +70,62 @@ def pretrained_surgery(state_dict, in_chans, num_patches, num_frames):
     return out
 
 
+def _torch_load(path):
+    """Reference checkpoints are ordinary pickles: train.py:269-283 stores `train_args` as an argparse.Namespace next to the
+    tensors, and the image-ViT files are plain dicts.  torch >= 2.6 defaults to weights_only=True, which rejects both."""
+    return torch.load(path, map_location='cpu', weights_only=False)
+
+
+def load_state_dict_file(path):
+    """helpers.py:24-52: unwrap 'state_dict' (stripping a leading 'module') / 'model_state' (stripping a leading 'model')."""
+    ck = _torch_load(path)
+    if isinstance(ck, dict) and 'state_dict' in ck:
+        return {(k[7:] if k.startswith('module') else k): v for k, v in ck['state_dict'].items()}
+    if isinstance(ck, dict) and 'model_state' in ck:
+        return {(k[6:] if k.startswith('model') else k): v for k, v in ck['model_state'].items()}
+    return ck
+
+
 def load_pretrained_vit(tracker, path, logger=None):
     if not path:
         raise TcowError('tracker_pretrained=True needs the ImageNet ViT-B/16 weights from the network (vit.py:35); '
                         'pass a checkpoint file path as tracker_pretrained instead, or False')
-    sd = torch.load(path, map_location='cpu')
-    if 'state_dict' in sd:
-        sd = sd['state_dict']
+    sd = load_state_dict_file(path)
     vit = tracker.vit
     n_patches = vit.pos_embed.shape[1] - 1
-    sd = pretrained_surgery(sd, tracker.input_channels, n_patches, tracker.num_total_frames)
+    sd = pretrained_surgery(sd, tracker.input_channels, n_patches, tracker.num_total_frames, tracker.patch_size)
     missing, unexpected = vit.load_state_dict(sd, strict=False)           # helpers.py:202
     if logger is not None:
         logger.info(f'(tcow_amd) pretrained ViT loaded: {len(missing)} missing, {len(unexpected)} unexpected keys')
     return missing, unexpected
 
 
+def parse_tracker_pretrained(value):
+    """mask_tracker.py:55-67: (flag, path) of a `tracker_pretrained` constructor argument."""
+    if isinstance(value, bool):
+        return value, ''
+    if isinstance(value, str):
+        if value.lower() in ['1', 'y', 'yes', 't', 'true']:
+            return True, ''
+        if len(value) <= 5:
+            return False, ''
+        return True, value
+    raise ValueError(f'Invalid tracker_pretrained value: {value}.')
+
+
 def load_tcow_checkpoint(path, logger=None, device='cuda', precision='bf16'):
-    """eval/inference.py:38-54: checkpoint['seeker_args'] -> Seeker(**args); load_state_dict(net_seeker)."""
+    """eval/inference.py:38-54: checkpoint['seeker_args'] -> Seeker(**args); load_state_dict(net_seeker).
+
+    The reference passes `seeker_args` through unchanged, so a model trained from the ImageNet ViT (`tracker_pretrained='1'`, the CLI
+    default args.py:150) is rebuilt with `pretrained=True`: that re-downloads weights which the checkpoint then overwrites, and --
+    the part that matters -- keeps the (rgb - 0.45) / 0.225 input normalisation of vision_tf.py:81-89 switched on.  Here the module is
+    constructed without the (offline-impossible, redundant) download and the parsed flag is restored afterwards."""
     from .seeker import Seeker
-    ck = torch.load(path, map_location='cpu')
+    ck = _torch_load(path)
     args = dict(ck['seeker_args'])
-    args['tracker_pretrained'] = False        # weights come from the checkpoint itself (inference.py:46-47 does the same)
+    flag, _ = parse_tracker_pretrained(args.get('tracker_pretrained', False))
+    args['tracker_pretrained'] = False
     net = Seeker(logger, precision=precision, **args)
     net.load_state_dict(ck['net_seeker'], strict=True)
+    net.seeker.tracker_pretrained = flag
     return net.to(device)

@@ -2,6 +2,9 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <mutex>
+#include <set>
+#include <utility>
 #include <vector>
 
 #include "common.h"
@@ -13,6 +16,18 @@ void tcow_set_error(const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-device property of a kernel: remember (device, kernel) pairs so that a
+// process driving several GPUs (torch.nn.DataParallel replicas are threads of one process, train.py:222-223) sets it on each.
+void tcow_ensure_lds(const void* kernel, int bytes) {
+    static std::mutex mu;
+    static std::set<std::pair<int, const void*>> done;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.insert(std::make_pair(dev, kernel)).second)
+        (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
 int tcow_gemm_nt_bf16(hipStream_t stream, const tcow_gemm_args* a);
@@ -31,7 +46,7 @@ int tcow_launch_colsum(hipStream_t stream, int dtype, const void* Y, long ldy, i
 
 extern "C" {
 
-int tcow_version(void) { return 1; }
+int tcow_version(void) { return 2; }
 const char* tcow_last_error(void) { return g_err; }
 
 // ---- optional low-overhead HIP-event timing of the dominant kernel (the NT GEMM), on the launch stream
@@ -39,9 +54,11 @@ static std::vector<hipEvent_t> g_prof_events;
 static std::vector<double> g_prof_flops;
 static size_t g_prof_used = 0;
 static bool g_prof_on = false;
+static std::mutex g_prof_mu;   // the profiling aid is process-wide: one measuring thread at a time, launches from others are serialised here
 
 int tcow_prof_gemm_begin(int max_launches) {
     TCOW_CHECK_ARG(max_launches > 0, "tcow_prof_gemm_begin: max_launches must be positive");
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     while (g_prof_events.size() < (size_t)max_launches * 2) {
         hipEvent_t e;
         if (hipEventCreate(&e) != hipSuccess) { tcow_set_error("tcow_prof_gemm_begin: hipEventCreate failed"); return TCOW_ERR_LAUNCH; }
@@ -54,6 +71,7 @@ int tcow_prof_gemm_begin(int max_launches) {
 }
 
 int tcow_prof_gemm_end(double* total_ms, double* total_flops, long* launches) {
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     g_prof_on = false;
     double ms = 0.0, fl = 0.0;
     for (size_t i = 0; i < g_prof_used; ++i) {
@@ -71,6 +89,8 @@ int tcow_prof_gemm_end(double* total_ms, double* total_flops, long* launches) {
 static int gemm_nt_dispatch(void* stream, const tcow_gemm_args* a);
 
 int tcow_gemm_nt(void* stream, const tcow_gemm_args* a) {
+    if (!g_prof_on) return gemm_nt_dispatch(stream, a);
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     if (!g_prof_on || a == nullptr || g_prof_used >= g_prof_flops.size()) return gemm_nt_dispatch(stream, a);
     const size_t i = g_prof_used++;
     g_prof_flops[i] = 2.0 * a->M * (double)a->N * a->K;

@@ -650,7 +650,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_stream(SeqDesc sd, int nt,
 
 template <typename K>
 static void set_lds_attr(K kernel, int bytes) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    tcow_ensure_lds(reinterpret_cast<const void*>(kernel), bytes);
 }
 
 }  // namespace

@@ -92,4 +92,7 @@ __device__ __forceinline__ float wave_max(float v) {
 // MFMA C/D layout of the 32x32 tiles: register r of lane (l&31, hi=l>>5) holds row crow(r,hi), col l&31.
 __host__ __device__ __forceinline__ constexpr int crow32(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
+// raises the dynamic-LDS limit of a kernel once per (device, kernel); thread-safe (api.cpp)
+void tcow_ensure_lds(const void* kernel, int bytes);
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

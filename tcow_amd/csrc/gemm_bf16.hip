@@ -788,11 +788,7 @@ int tcow_gemm_nt_bf16(hipStream_t stream, const tcow_gemm_args* a) {
     p.C = a->C; p.ldc = a->ldc; p.out_f32 = a->out_f32; p.bias = a->bias; p.row_scale = a->row_scale;
     p.resid = a->resid; p.ldr = a->ldr; p.act = a->act; p.aux = (bf16_t*)a->aux; p.ldaux = a->ldaux;
     p.tiles_m = cdiv(a->M, BM); p.tiles_n = cdiv(a->N, BN);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
-        attr_set = true;
-    }
+    TCOW_CHECK_ARG(a->tile == 0 || a->tile == 128 || a->tile == 256 || a->tile == 320, "tcow_gemm_nt(bf16): tile must be 0, 128, 256 or 320 (got %d)", a->tile);
     static const int big = [] { const char* e = getenv("TCOW_GEMM_BIG"); return e ? atoi(e) : 1; }();
     static const int wide = [] { const char* e = getenv("TCOW_GEMM_320"); return e ? atoi(e) : 1; }();
     {
@@ -800,7 +796,7 @@ int tcow_gemm_nt_bf16(hipStream_t stream, const tcow_gemm_args* a) {
         const long t320 = (long)cdiv(a->M, C_BM) * cdiv(a->N, C_BN);
         const long rounds = (t320 + 255) / 256;
         const bool fills = t320 * 100 >= rounds * 256 * 80;   // (measured: still ahead of the 256 / 128 tiles at 88 % -- configs[3], configs[4])
-        if (wide && (wide == 2 || (fills && t320 >= 200))) {
+        if (a->tile == 320 || (a->tile == 0 && wide && (wide == 2 || (fills && t320 >= 200)))) {
             p.tiles_m = cdiv(a->M, C_BM); p.tiles_n = cdiv(a->N, C_BN);
             // epilogue specialisations for the combinations the path uses; anything else takes the run-time-configured kernel
             typedef void (*Kern)(NtParams);
@@ -815,25 +811,16 @@ int tcow_gemm_nt_bf16(hipStream_t stream, const tcow_gemm_args* a) {
             else if (a->act == TCOW_ACT_GELU_DSAVE && rows == 0) k = gemm_nt_bf16_320_kernel<EpiCfg<TCOW_ACT_GELU_DSAVE, 0>>;
             else if (a->act == TCOW_ACT_MUL_AUX && rows == 0) k = gemm_nt_bf16_320_kernel<EpiCfg<TCOW_ACT_MUL_AUX, 0>>;
             else if (a->act == TCOW_ACT_GELU && rows == 0) k = gemm_nt_bf16_320_kernel<EpiCfg<TCOW_ACT_GELU, 0>>;
-            static bool attr5 = false;
-            if (!attr5) {
-                const Kern all[] = {gemm_nt_bf16_320_kernel<EpiAny>, gemm_nt_bf16_320_kernel<EpiCfg<TCOW_ACT_NONE, 0>>, gemm_nt_bf16_320_kernel<EpiCfg<TCOW_ACT_NONE, 1>>,
-                                    gemm_nt_bf16_320_kernel<EpiCfg<TCOW_ACT_NONE, 2>>, gemm_nt_bf16_320_kernel<EpiCfg<TCOW_ACT_NONE, 3>>,
-                                    gemm_nt_bf16_320_kernel<EpiCfg<TCOW_ACT_GELU_DSAVE, 0>>, gemm_nt_bf16_320_kernel<EpiCfg<TCOW_ACT_MUL_AUX, 0>>,
-                                    gemm_nt_bf16_320_kernel<EpiCfg<TCOW_ACT_GELU, 0>>};
-                for (Kern kk : all) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kk), hipFuncAttributeMaxDynamicSharedMemorySize, C_LDS);
-                attr5 = true;
-            }
+            tcow_ensure_lds(reinterpret_cast<const void*>(k), C_LDS);
             hipLaunchKernelGGL(k, dim3(p.tiles_m * p.tiles_n), dim3(512), C_LDS, stream, p);
             TCOW_CHECK_LAUNCH();
             return TCOW_OK;
         }
     }
     // the 256-square tile runs one workgroup per CU: it only pays when there are several full rounds of tiles (>= ~2.7 per CU)
-    if (big && (long)cdiv(a->M, B_BM) * cdiv(a->N, B_BN) >= 700) {
+    if (a->tile == 256 || (a->tile == 0 && big && (long)cdiv(a->M, B_BM) * cdiv(a->N, B_BN) >= 700)) {
         p.tiles_m = cdiv(a->M, B_BM); p.tiles_n = cdiv(a->N, B_BN);
-        static bool attr3 = false;
-        if (!attr3) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, B_LDS); attr3 = true; }
+        tcow_ensure_lds(reinterpret_cast<const void*>(gemm_nt_bf16_256_kernel), B_LDS);
         hipLaunchKernelGGL(gemm_nt_bf16_256_kernel, dim3(p.tiles_m * p.tiles_n), dim3(512), B_LDS, stream, p);
         TCOW_CHECK_LAUNCH();
         return TCOW_OK;
@@ -843,10 +830,10 @@ int tcow_gemm_nt_bf16(hipStream_t stream, const tcow_gemm_args* a) {
     // with 4 workgroups per CU (10-30 % slower: 64-byte rows, twice the barriers) and a single-stage BK=64 variant with 4 workgroups per CU
     // (+-5 %: latency hiding is not the limit, L2->LDS bytes per FLOP are) were also tried and dropped.
     if (variant == 2) {
-        static bool attr2 = false;
-        if (!attr2) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_ring_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES); attr2 = true; }
+        tcow_ensure_lds(reinterpret_cast<const void*>(gemm_nt_bf16_ring_kernel), NT_LDS_BYTES);
         hipLaunchKernelGGL(gemm_nt_bf16_ring_kernel, dim3(p.tiles_m * p.tiles_n), dim3(256), NT_LDS_BYTES, stream, p);
     } else {
+        tcow_ensure_lds(reinterpret_cast<const void*>(gemm_nt_bf16_kernel), NT_LDS_BYTES);
         hipLaunchKernelGGL(gemm_nt_bf16_kernel, dim3(p.tiles_m * p.tiles_n), dim3(256), NT_LDS_BYTES, stream, p);
     }
     TCOW_CHECK_LAUNCH();
@@ -1227,17 +1214,12 @@ int tcow_gemm_tn_bf16(hipStream_t stream, int M, int N, int K, const bf16_t* dY,
     p.bias_part = bias_part;
     p.rows_per_pk = cdiv(mc, p.tiles_k);
     if (bias_parts_out) *bias_parts_out = nz * p.tiles_k * 2;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_bf16_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-        attr_set = true;
-    }
+    tcow_ensure_lds(reinterpret_cast<const void*>(gemm_tn_bf16_kernel<64>), 65536);
     if (tcow_tn_use_256(M, N, K)) {
         p.tiles_n = cdiv(N, T2); p.tiles_k = cdiv(K, T2);
         p.rows_per_pk = cdiv(T2_MC, p.tiles_k);
         if (bias_parts_out) *bias_parts_out = nz * p.tiles_k * 2;
-        static bool attr2 = false;
-        if (!attr2) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_bf16_256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS); attr2 = true; }
+        tcow_ensure_lds(reinterpret_cast<const void*>(gemm_tn_bf16_256_kernel), T2_LDS);
         hipLaunchKernelGGL(gemm_tn_bf16_256_kernel, dim3(nz * p.tiles_n * p.tiles_k), dim3(512), T2_LDS, stream, p);
         TCOW_CHECK_LAUNCH();
         return TCOW_OK;

@@ -43,15 +43,21 @@ class GradSync:
     per completed bucket and drains it (`finish()`) before handing the gradients to autograd, so after `loss.backward()`
     every param.grad is already the mean over ranks."""
 
-    def __init__(self, world_size=None, group=None, overlap=None):
+    def __init__(self, world_size=None, group=None, overlap=None, bucket_dtype='f32'):
         """overlap: launch each bucket's all-reduce as soon as the backward has produced it (default; `TCOW_DDP_OVERLAP=0` or
         overlap=False issues them all after the last bucket instead -- the fallback should RCCL kernels holding CUs during the
-        backward cost more than they hide)."""
+        backward cost more than they hide).
+        bucket_dtype: 'f32' moves the f32 buckets as they are (488.6 MB per step at ViT-B); 'bf16' all-reduces a bf16 copy of each
+        bucket (244.3 MB: half the per-link xGMI time) and widens the mean back into the f32 bucket -- master weights, moments and
+        the clip norm stay f32 (AdamW reads the f32 bucket)."""
         self.group = group
         self.world = world_size if world_size is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
         self.overlap = (os.environ.get('TCOW_DDP_OVERLAP', '1') != '0') if overlap is None else bool(overlap)
-        # sum + one scale pass by default (works on every backend); TCOW_DDP_AVG=1 lets RCCL average inside the collective
-        self.native_avg = os.environ.get('TCOW_DDP_AVG', '0') == '1' and dist.is_initialized() and dist.get_backend(group) == 'nccl'
+        # RCCL averages inside the collective (ReduceOp.AVG); gloo has no AVG: sum + one scale pass there (TCOW_DDP_AVG=0 forces that path)
+        self.native_avg = os.environ.get('TCOW_DDP_AVG', '1') != '0' and dist.is_initialized() and dist.get_backend(group) == 'nccl'
+        if bucket_dtype not in ('f32', 'bf16'):
+            raise ValueError("bucket_dtype must be 'f32' or 'bf16'")
+        self.bucket_dtype = bucket_dtype
         self.pending = []
         self.deferred = []
         self.bytes = 0
@@ -59,13 +65,14 @@ class GradSync:
 
     def _launch(self, flat):
         op = dist.ReduceOp.AVG if self.native_avg else dist.ReduceOp.SUM
-        self.pending.append((dist.all_reduce(flat, op=op, group=self.group, async_op=True), flat))
+        wire = flat.to(torch.bfloat16) if self.bucket_dtype == 'bf16' else flat
+        self.bytes += wire.numel() * wire.element_size()
+        self.pending.append((dist.all_reduce(wire, op=op, group=self.group, async_op=True), flat, wire))
 
     def __call__(self, name, flat):
         if self.world <= 1 or flat.numel() == 0:
             return
         self.launched.append(name)
-        self.bytes += flat.numel() * flat.element_size()
         if self.overlap:
             self._launch(flat)
         else:
@@ -75,8 +82,10 @@ class GradSync:
         for flat in self.deferred:
             self._launch(flat)
         self.deferred = []
-        for work, flat in self.pending:
+        for work, flat, wire in self.pending:
             work.wait()                      # makes the current stream wait for the collective
+            if wire is not flat:
+                flat.copy_(wire)             # bf16 mean -> f32 bucket
             if not self.native_avg:
                 flat.mul_(1.0 / self.world)  # sum -> mean (loss.py:356-369 averages the per-replica losses)
         self.pending = []

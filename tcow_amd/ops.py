@@ -32,14 +32,14 @@ def _need_cuda(*ts):
             raise L.TcowError('libtcow_hip kernels need CUDA/HIP tensors (no CPU fallback on this path)')
 
 
-def gemm_nt(mode, A, W, out, bias=None, row_scale=None, resid=None, act=ACT_NONE, aux=None):
+def gemm_nt(mode, A, W, out, bias=None, row_scale=None, resid=None, act=ACT_NONE, aux=None, tile=0):
     """out[M,N] = epilogue(A[M,K] @ W[N,K]^T); see tcow_gemm_nt. `out` dtype f32 or the mode's dtype."""
     _need_cuda(A, W, out)
     M, K = A.shape
     N = W.shape[0]
     a = L.GemmArgs(M, N, K, mode, A.data_ptr(), A.stride(0), W.data_ptr(), W.stride(0), out.data_ptr(), out.stride(0),
                    1 if out.dtype == torch.float32 else 0, _p(bias), _p(row_scale), _p(resid),
-                   resid.stride(0) if resid is not None else 0, act, _p(aux), aux.stride(0) if aux is not None else 0)
+                   resid.stride(0) if resid is not None else 0, act, _p(aux), aux.stride(0) if aux is not None else 0, int(tile))
     L.check(L.lib().tcow_gemm_nt(_stream(), ctypes.byref(a)), 'tcow_gemm_nt')
     return out
 

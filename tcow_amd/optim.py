@@ -3,7 +3,17 @@
 Same arithmetic as torch.nn.utils.clip_grad_norm_(params, max_norm) followed by torch.optim.AdamW(params, lr).step()
 (betas (0.9, 0.999), eps 1e-8, weight_decay 0.01 on every parameter -- the reference builds one parameter group with torch's
 defaults), but as three kernel launches over a device-resident chunk table instead of ~250 per-tensor
-foreach operations.  Parameters without a gradient are skipped, like torch does."""
+foreach operations.  Parameters without a gradient are skipped, like torch does.
+
+It IS a torch.optim.Optimizer: `param_groups` carries lr / betas / eps / weight_decay (read every step, so the reference's
+MultiStepLR, train.py:236-243, attaches unchanged), and `state_dict()` / `load_state_dict()` use torch.optim.AdamW's layout
+(per-parameter 'step', 'exp_avg', 'exp_avg_sq'), so a reference checkpoint's 'optim_seeker' (train.py:282) loads and what is
+saved here loads into torch.optim.AdamW.
+
+The kernels write the parameters through raw pointers; after every step the parameters' autograd version counters are bumped
+(torch.autograd.graph.increment_version), so anything that caches derived copies keyed on `p._version` -- the Seeker's bf16
+operand copies are -- can never serve stale weights.  `on_step` callbacks (e.g. QueryMaskTracker.invalidate_weight_cache, which
+re-casts all GEMM operands in ONE launch) are an optimisation on top of that, not a correctness requirement."""
 import numpy as np
 import torch
 
@@ -12,68 +22,86 @@ from . import _lib as L
 CHUNK = 65536
 
 
-class FusedAdamWClip:
-    def __init__(self, params, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, max_norm=0.3):
-        self.params = [p for p in params]
-        self.lr, self.betas, self.eps, self.weight_decay, self.max_norm = lr, betas, eps, weight_decay, max_norm
-        self.state = {}            # id(p) -> (exp_avg, exp_avg_sq)
-        self.step_count = 0
+class FusedAdamWClip(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, max_norm=0.3, module=None):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        if len(self.param_groups) != 1:
+            raise L.TcowError('FusedAdamWClip takes one parameter group (train.py:239-241 builds exactly one)')
+        self.max_norm = max_norm
         self._table = None
         self._key = None
         self.scratch = None
-        self.on_step = []          # callables run after every step (e.g. QueryMaskTracker.invalidate_weight_cache)
+        self.on_step = []          # callables run after every step
+        if module is not None:     # a Seeker / QueryMaskTracker: batch re-cast of its GEMM operand copies right after the update
+            tracker = getattr(module, 'seeker', module)
+            if hasattr(tracker, 'invalidate_weight_cache'):
+                self.on_step.append(tracker.invalidate_weight_cache)
         assert L.lib().tcow_adamw_chunk_bytes() == 40
 
-    def zero_grad(self, set_to_none=True):
+    @property
+    def params(self):
+        return self.param_groups[0]['params']
+
+    @property
+    def lr(self):
+        return self.param_groups[0]['lr']
+
+    @property
+    def step_count(self):
         for p in self.params:
-            if set_to_none:
-                p.grad = None
-            elif p.grad is not None:
-                p.grad.zero_()
+            st = self.state.get(p)
+            if st:
+                return int(st['step'])
+        return 0
 
     def _build(self, live):
         rows = []
         for p in live:
-            if id(p) not in self.state:
-                self.state[id(p)] = (torch.zeros_like(p, dtype=torch.float32), torch.zeros_like(p, dtype=torch.float32))
-            m, v = self.state[id(p)]
+            st = self.state[p]
+            if 'exp_avg' not in st:
+                st['step'] = torch.tensor(0.0, dtype=torch.float32)
+                st['exp_avg'] = torch.zeros_like(p, dtype=torch.float32, memory_format=torch.preserve_format)
+                st['exp_avg_sq'] = torch.zeros_like(p, dtype=torch.float32, memory_format=torch.preserve_format)
+            m, v = st['exp_avg'], st['exp_avg_sq']
             g = p.grad
-            if not (p.is_contiguous() and g.is_contiguous() and p.dtype == torch.float32 and g.dtype == torch.float32):
-                raise L.TcowError('FusedAdamWClip needs contiguous f32 parameters and gradients')
+            if not (p.is_contiguous() and g.is_contiguous() and m.is_contiguous() and v.is_contiguous() and p.dtype == torch.float32 and g.dtype == torch.float32
+                    and m.dtype == torch.float32 and v.dtype == torch.float32):
+                raise L.TcowError('FusedAdamWClip needs contiguous f32 parameters, gradients and moments')
             n = p.numel()
             for off in range(0, n, CHUNK):
                 rows.append((p.data_ptr() + 4 * off, g.data_ptr() + 4 * off, m.data_ptr() + 4 * off, v.data_ptr() + 4 * off, min(CHUNK, n - off)))
-        tab = torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(live[0].device)
-        self._table = tab
+        self._table = torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(live[0].device)
         self.scratch = torch.empty(len(rows) + 2, dtype=torch.float32, device=live[0].device)
 
-    def step(self):
-        live = [p for p in self.params if p.grad is not None]
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        grp = self.param_groups[0]
+        live = [p for p in grp['params'] if p.grad is not None]
         if not live:
-            return
-        key = tuple((id(p), p.grad.data_ptr()) for p in live)
-        if key != self._key:                     # gradient buffers are re-allocated by the backward: rebuild the pointer table
+            return loss
+        key = tuple((id(p), p.grad.data_ptr(), self.state[p]['exp_avg'].data_ptr() if 'exp_avg' in self.state[p] else 0) for p in live)
+        if key != self._key:                     # gradient / moment buffers moved (first step, re-allocated grads, load_state_dict): rebuild the pointer table
             self._build(live)
-            self._key = key
-        self.step_count += 1
-        L.check(L.lib().tcow_adamw_clip_step(torch.cuda.current_stream().cuda_stream, self._table.data_ptr(), self._table.shape[0], self.lr,
-                                             self.betas[0], self.betas[1], self.eps, self.weight_decay, self.step_count, float(self.max_norm or 0.0),
-                                             self.scratch.data_ptr()), 'tcow_adamw_clip_step')
-        # parameters were updated in place through raw pointers: tell whoever caches derived copies (the Seeker's bf16 operand
-        # copies are keyed on this) -- cheaper than bumping 250 autograd version counters with dummy in-place ops
+            self._key = tuple((id(p), p.grad.data_ptr(), self.state[p]['exp_avg'].data_ptr()) for p in live)
+        step = int(self.state[live[0]]['step']) + 1
+        L.check(L.lib().tcow_adamw_clip_step(torch.cuda.current_stream().cuda_stream, self._table.data_ptr(), self._table.shape[0], float(grp['lr']),
+                                             float(grp['betas'][0]), float(grp['betas'][1]), float(grp['eps']), float(grp['weight_decay']), step,
+                                             float(self.max_norm or 0.0), self.scratch.data_ptr()), 'tcow_adamw_clip_step')
+        for p in live:
+            self.state[p]['step'] += 1           # CPU scalars, like torch.optim.AdamW keeps them
+        torch.autograd.graph.increment_version(live)   # the kernels wrote through raw pointers: make the update visible to version checks
         for cb in self.on_step:
             cb()
+        return loss
+
     def grad_norm(self):
         """Total gradient norm of the last step (device tensor, no sync)."""
         return self.scratch[-1]
 
-    def state_dict(self):
-        return {'step': self.step_count, 'state': [(self.state[id(p)] if id(p) in self.state else None) for p in self.params],
-                'lr': self.lr, 'betas': self.betas, 'eps': self.eps, 'weight_decay': self.weight_decay, 'max_norm': self.max_norm}
-
     def load_state_dict(self, sd):
-        self.step_count = sd['step']
-        for p, st in zip(self.params, sd['state']):
-            if st is not None:
-                self.state[id(p)] = (st[0].to(p.device), st[1].to(p.device))
+        super().load_state_dict(sd)
         self._key = None

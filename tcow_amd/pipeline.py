@@ -187,6 +187,18 @@ class SeekerPipeline:
         out_mask, out_flags = self.seeker(rgb, qm)
         return {'seeker_input': rgb, 'seeker_query_mask': qm, 'target_mask': tgt, 'output_mask': out_mask, 'output_flags': out_flags}
 
+    def forward_plugin_items(self, items, max_batch=32):
+        """All (query, usage-mode) clips of a plugin video in as few Seeker calls as fit (`max_batch` clips each) instead of one
+        B = 1 forward per item (eval/test.py forces batch_size 1, args.py:276; data_plugin.py:141-156 makes every (query frame,
+        stride) pair its own dataset item).  `items`: dicts from tcow_amd.plugin_data.build_plugin_item / eval_items.  Batch rows
+        are independent, so the result equals the sequential one bit for bit."""
+        outs = []
+        for i in range(0, len(items), max_batch):
+            chunk = items[i:i + max_batch]
+            batch = {k: torch.stack([torch.as_tensor(it[k]) for it in chunk]) for k in ('pv_rgb_tf', 'pv_query_tf', 'pv_target_tf')}
+            outs.append(self.forward_plugin(batch))
+        return {k: torch.cat([o[k] for o in outs]) for k in outs[0]}
+
     def step_losses(self, data_retval, model_retval, progress=0.0):
         qt = int(data_retval['kubric_retval']['traject_retval_tf']['query_time'][0].item())
         return self.losses.entire_batch(self.losses.per_example(model_retval, qt, progress))

@@ -138,19 +138,8 @@ class QueryMaskTracker(nn.Module):
         self.input_channels = 3 + query_channels
         self.set_precision(precision)
 
-        self.pretrained_path = ''                                         # mask_tracker.py:55-67
-        if isinstance(tracker_pretrained, bool):
-            self.tracker_pretrained = tracker_pretrained
-        elif isinstance(tracker_pretrained, str):
-            if tracker_pretrained.lower() in ['1', 'y', 'yes', 't', 'true']:
-                self.tracker_pretrained = True
-            elif len(tracker_pretrained) <= 5:
-                self.tracker_pretrained = False
-            else:
-                self.tracker_pretrained = True
-                self.pretrained_path = tracker_pretrained
-        else:
-            raise ValueError(f'Invalid tracker_pretrained value: {tracker_pretrained}.')
+        from .checkpoint import parse_tracker_pretrained
+        self.tracker_pretrained, self.pretrained_path = parse_tracker_pretrained(tracker_pretrained)   # mask_tracker.py:55-67
         if logger is not None:
             logger.info(f'(QueryMaskTracker) tracker_pretrained: {self.tracker_pretrained} '
                         f'pretrained_path: {self.pretrained_path}')
@@ -251,10 +240,18 @@ class QueryMaskTracker(nn.Module):
         assert Hf == self.frame_height and Wf == self.frame_width         # vision_tf.py:97 (W' check)
         if not input_frames.is_cuda:
             raise TcowError('Seeker (tcow_amd) runs on the GPU only: move inputs and module to cuda')
+        if query_mask.device != input_frames.device or self.vit.pos_embed.device != input_frames.device:
+            raise TcowError(f'Seeker (tcow_amd): inputs ({input_frames.device}, {query_mask.device}) and parameters ({self.vit.pos_embed.device}) must share one device')
+        if getattr(self, '_is_replica', False):
+            # torch.nn.DataParallel (train.py:222-223) re-creates shallow replicas every forward: their dicts alias the original's, so give
+            # each replica private operand / gradient caches for this call instead of growing the shared ones with dead entries
+            self._wcache, self._gbufs = {}, {}
+            self.__dict__.pop('_wreg', None); self.__dict__.pop('_wtab', None)
         rgb = input_frames.to(torch.float32).contiguous()                 # mask_tracker.py:103-104 (inputs not mutated)
         qm = query_mask.to(torch.float32).contiguous()
         from .engine import SeekerFunction
-        out_mask, out_flags = SeekerFunction.apply(self, rgb, qm, *self.param_list())
+        with torch.cuda.device(input_frames.device):                      # kernels launch on the tensors' device and its current stream
+            out_mask, out_flags = SeekerFunction.apply(self, rgb, qm, *self.param_list())
         if self.flag_channels <= 0:
             out_flags = None
         return (out_mask, out_flags)

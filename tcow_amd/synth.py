@@ -205,6 +205,15 @@ def make_kubric_batch(B, T, H, W, seed=900, n_objects=5, M=36):
     }
 
 
+def make_plugin_video(Tv, H, W, seed=900, n_objects=5, annot_every=5, query_frames=(0,)):
+    """Synthetic 'plugin' video (data/data_plugin.py:52-140): Tv rgb frames, the visible segmentation and amodal instance masks of a
+    Kubric-shaped scene, query annotations at `query_frames` and sparse target annotations every `annot_every`-th frame -- what
+    the reference reads from <video> + *_query.png / *_snitch.png files, as arrays."""
+    kb = make_kubric_batch(1, Tv, H, W, seed=seed, n_objects=n_objects)['kubric_retval']
+    return dict(rgb=kb['pv_rgb_tf'][0], segm=kb['pv_segm_tf'][0, 0], div=kb['pv_div_segm_tf'][0, :n_objects],
+                annot_frames=list(range(0, Tv, annot_every)), query_frames=list(query_frames))
+
+
 HOST_KEYS = ('query_time', 'pv_inst_count', 'desirability_tf')
 
 

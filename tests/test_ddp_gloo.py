@@ -29,6 +29,10 @@ def _worker(rank, world, port, q):
     ok = ok and len(late.pending) == 0 and all(torch.equal(flat, torch.full_like(flat, float(rank + 1) * (i + 1))) for i, flat in enumerate(b2.values()))
     late.finish()
     ok = ok and all(torch.allclose(flat, torch.full_like(flat, 1.5 * (i + 1))) for i, flat in enumerate(b2.values()))
+    half = ddp.GradSync(world, bucket_dtype='bf16')    # bf16 on the wire, f32 bucket in and out
+    b3 = torch.full((300,), float(rank + 1) * 0.25)
+    half('blk', b3); half.finish()
+    ok = ok and b3.dtype == torch.float32 and torch.equal(b3, torch.full_like(b3, 0.375)) and half.bytes == 300 * 2
     lin = torch.nn.Linear(4, 4)
     torch.manual_seed(rank); torch.nn.init.normal_(lin.weight)
     ddp.broadcast_parameters(lin)
@@ -67,3 +71,22 @@ def test_backward_drains_the_hook_before_returning_grads():
     from tcow_amd import engine
     src = inspect.getsource(engine.run_backward)
     assert src.index("module.grad_hook('embed', emb_flat)") < src.index('module.grad_hook.finish()') < src.rindex('return grads')
+
+
+def test_bench_self_launches_n_ranks():
+    """`python bench.py --gpus 2` with no launcher around it must start two ranks itself (it silently ran one) --
+    exercised on CPU through the launch self-test (gloo), which stops before any GPU work."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ); env.pop('WORLD_SIZE', None); env.pop('RANK', None); env['TCOW_DIST_BACKEND'] = 'gloo'
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--launch-selftest'], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith('{')][-1]
+    res = json.loads(line)
+    assert res['n_gpus'] == 2 and res['ranks_seen'] == 2
+    # a rank count that does not match --gpus is an error, not a silent single-GPU run
+    env2 = dict(env, WORLD_SIZE='1', RANK='0')
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1'], env=env2, capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and 'WORLD_SIZE' in (bad.stderr + bad.stdout)

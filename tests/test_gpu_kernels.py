@@ -61,6 +61,41 @@ def test_gemm_nt_epilogues(ops, cuda, mname, tol, M, K, N):
     assert rel(C, ref0 * pre.double()) < tol
 
 
+@pytest.mark.parametrize('N,K', [(768, 768), (2304, 768), (3072, 768), (768, 3072)])
+def test_gemm_nt_every_tile_kernel_at_bench_size(ops, cuda, N, K):
+    """The benchmarked instantiations against an f64 product: M = 27 090 token rows (3 queries x 30 frames x 301 slots, BASELINE
+    configs[1]) with the four weight shapes of a block, on each bf16 tile kernel (forced through tcow_gemm_args.tile: 320 x 256
+    incl. its compile-time epilogues, 256 x 256, 128 x 128) and every epilogue combination the engine issues.  Operands are bf16
+    values, so the only error is f32 accumulation order + the output rounding: bf16 outputs within 2^-8 of the tile maximum, f32
+    outputs within 2e-5."""
+    M = 27090
+    g = torch.Generator(device='cuda').manual_seed(N + K)
+    A = torch.randn(M, K, device=cuda, generator=g).bfloat16(); W = (torch.randn(N, K, device=cuda, generator=g) * 0.05).bfloat16()
+    bias = torch.randn(N, device=cuda, generator=g); rs = torch.rand(M, device=cuda, generator=g) + 0.5; rs[::7] = 0.0
+    resid = torch.randn(M, N, device=cuda, generator=g); pre = torch.randn(M, N, device=cuda, generator=g).bfloat16()
+    ref0 = A.double() @ W.double().t()
+    refb = ref0 + bias.double()
+    xv = refb.clone().requires_grad_(True)
+    gel = F.gelu(xv); dgel = torch.autograd.grad(gel.sum(), xv)[0]; gel = gel.detach()
+    BF, F32 = 4e-3, 2e-5
+    bf = lambda: torch.empty(M, N, device=cuda, dtype=torch.bfloat16)
+    f32 = lambda: torch.empty(M, N, device=cuda)
+    for tile in (320, 256, 128, 0):
+        t = dict(tile=tile)
+        assert rel(ops.gemm_nt(ops.BF16, A, W, bf(), bias=bias, **t), refb) < BF                                              # EpiCfg<NONE, 0>: qkv, proj-input grads
+        assert rel(ops.gemm_nt(ops.BF16, A, W, f32(), **t), ref0) < F32                                                     # f32 output (dFeat)
+        assert rel(ops.gemm_nt(ops.BF16, A, W, bf(), bias=bias, row_scale=rs, **t), refb * rs.double()[:, None]) < BF         # <NONE, 1>: temporal proj + DropPath row scale
+        assert rel(ops.gemm_nt(ops.BF16, A, W, f32(), bias=bias, resid=resid, **t), refb + resid.double()) < F32             # <NONE, 2>: residual
+        assert rel(ops.gemm_nt(ops.BF16, A, W, f32(), bias=bias, row_scale=rs, resid=resid, **t), refb * rs.double()[:, None] + resid.double()) < F32   # <NONE, 3>
+        inplace = resid.clone()
+        ops.gemm_nt(ops.BF16, A, W, inplace, bias=bias, row_scale=rs, resid=inplace, **t)                                    # eval: residual aliases the output
+        assert rel(inplace, refb * rs.double()[:, None] + resid.double()) < F32
+        aux = bf()
+        assert rel(ops.gemm_nt(ops.BF16, A, W, bf(), bias=bias, act=ops.ACT_GELU_DSAVE, aux=aux, **t), gel) < BF and rel(aux, dgel) < BF   # <GELU_DSAVE, 0>: fc1 (training)
+        assert rel(ops.gemm_nt(ops.BF16, A, W, bf(), bias=bias, act=ops.ACT_GELU, **t), gel) < BF                            # <GELU, 0>: fc1 (inference)
+        assert rel(ops.gemm_nt(ops.BF16, A, W, bf(), act=ops.ACT_MUL_AUX, aux=pre, **t), ref0 * pre.double()) < BF           # <MUL_AUX, 0>: fc2 input gradient x GELU'
+
+
 @pytest.mark.parametrize('mname,tol', MODES)
 @pytest.mark.parametrize('M,N,K', [(5, 64, 64), (300, 192, 256), (2057, 48, 1024), (9030, 768, 768),
                                    (9030, 2304, 768), (4200, 1032, 1288), (4099, 3072, 768)])     # the last three take the 256-tile kernel (incl. ragged tiles / last slice)
@@ -131,7 +166,8 @@ def _ref_attn(qkv, B, T, S, D, heads, ca, spatial):
 @pytest.mark.parametrize('mname,tol', [('f32', 2e-5), ('bf16', 1.5e-2)])
 @pytest.mark.parametrize('spatial,B,T,S,heads,ca', [
     (False, 1, 4, 17, 4, 1), (False, 2, 30, 21, 2, 1), (False, 1, 30, 9, 2, 0), (False, 1, 7, 9, 2, 3), (False, 1, 40, 9, 2, 1), (False, 1, 70, 5, 1, 2),
-    (True, 1, 2, 17, 4, 1), (True, 2, 3, 301, 2, 1), (True, 1, 2, 77, 2, 2), (True, 1, 1, 2, 1, 0), (True, 1, 1, 333, 1, 1)])
+    (True, 1, 2, 17, 4, 1), (True, 2, 3, 301, 2, 1), (True, 1, 2, 77, 2, 2), (True, 1, 1, 2, 1, 0), (True, 1, 1, 333, 1, 1),
+    (True, 1, 2, 1201, 12, 1)])          # last: the spatial sequence of BASELINE configs[3] (480x640: 1200 patches + cls)
 def test_attention_fwd_bwd(ops, cuda, mname, tol, spatial, B, T, S, heads, ca):
     """Empty / ragged cases included: S=2 (one patch), T not a multiple of 32, sequences longer than the MFMA limits
     (T=70, S=333 take the f32-arithmetic kernels), causal windows 0 / 1 / look-ahead."""

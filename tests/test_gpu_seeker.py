@@ -96,6 +96,205 @@ def test_causality_is_bit_exact_on_gpu(cuda, precision, ca, leak):
     assert float(diff[: t0 - leak].max()) == 0.0 and bool((diff[t0:] > 0).all())
 
 
+def _droppath_masks(g):
+    masks = {}
+    for k in g:
+        if k.startswith('keep::'):
+            _, i, kind = k.split('::')
+            masks[(int(i), kind)] = (torch.from_numpy(g[k]), float(g[f'rate::{i}']))
+    return masks
+
+
+@pytest.mark.parametrize('name', ['g12_droppath_ca1', 'g12_droppath_ca0'])
+@pytest.mark.parametrize('precision,tol,gtol', [('fp32', FP32_TOL, 2e-4), ('bf16', None, 4e-2)])
+def test_droppath_forced_masks_vs_reference_train_mode(cuda, name, precision, tol, gtol):
+    """K9b (vit_utils.py:139-164; vit.py:172-174,186,216,272-273): the keep masks the REFERENCE drew in train mode (golden g12) are
+    forced into the HIP engine; outputs and gradients must equal the reference's -- temporal DropPath per site before temporal_fc (a
+    dropped site still receives + b_fc), spatial per frame (incl. the cls row), MLP per sample."""
+    meta, g = load_golden(name)
+    cfg, sd, rgb, qm = golden_inputs(meta)
+    net = build_hip_seeker(cfg, sd, precision, drop_path_rate=meta['drop_path_rate']).cuda().train()
+    net.seeker.forced_drop_masks = _droppath_masks(g)
+    om, fl = net(rgb.cuda(), qm.cuda())
+    d = np.abs(om.detach().cpu().numpy() - g['output_mask']).max(); df = np.abs(fl.detach().cpu().numpy() - g['output_flags']).max()
+    if precision == 'fp32':
+        assert d < tol and df < tol
+    else:
+        assert d < bf16_tol(g['output_mask']) and df < bf16_tol(g['output_flags']) + 5e-3
+    Gm = torch.from_numpy(synth._rng(meta['seed'], 'g12_mask').standard_normal(size=tuple(om.shape), dtype=np.float32)).cuda()
+    Gf = torch.from_numpy(synth._rng(meta['seed'], 'g12_flags').standard_normal(size=tuple(fl.shape), dtype=np.float32)).cuda()
+    ((om * Gm).sum() + (fl * Gf).sum()).backward()
+    named = dict(net.named_parameters())
+    for k, ref in g.items():
+        if k.startswith('grad::'):
+            assert np.abs(named[k[6:]].grad.cpu().numpy() - ref).max() <= gtol * np.abs(ref).max() + 1e-7, k
+    for k, n in meta['grad_norms'].items():
+        if n is not None:
+            assert abs(float(named[k].grad.norm()) - n) <= gtol * n + 1e-7, k
+    # and the masks matter: without them the same module gives a different answer
+    net.seeker.forced_drop_masks = None; net.eval()
+    with torch.no_grad():
+        plain, _ = net(rgb.cuda(), qm.cuda())
+    assert float((plain - om.detach()).abs().max()) > 1e-3
+
+
+@pytest.mark.parametrize('precision,tol', [('fp32', 3e-4), ('bf16', 5e-2)])
+def test_full_size_gradients_vs_reference_golden(cuda, precision, tol):
+    """BASELINE configs[1] at full size with the Qs = 3 queries batched (M = 27 090 rows: the 320-tile GEMMs, streaming attention
+    and 256-tile weight-gradient kernels the benchmark runs) against gradients of the REAL reference (golden g7: three sequential
+    query forwards + one backward, pipeline.py:134-158 / train.py:98): every parameter's gradient norm, ten small gradients in full
+    and strided samples of eleven large ones."""
+    from oracle.seeker_oracle import grad_sample
+    meta, g = load_golden('g7_cfg2_grads')
+    cfg = meta['cfg']
+    sd = synth.make_state_dict(cfg, meta['seed'])
+    net = build_hip_seeker(cfg, sd, precision).cuda().train()
+    clip = synth.make_clip(1, 30, 240, 320, seed=meta['seed'])
+    Qs = meta['queries']
+    rgb = torch.from_numpy(clip['rgb']).cuda().expand(Qs, -1, -1, -1, -1).contiguous()
+    qm = torch.cat([torch.from_numpy(synth.make_query_mask(clip, q, 0)) for q in range(Qs)], 0).cuda()
+    om, fl = net(rgb, qm)
+    pooled, _, _ = summarise(om.detach().cpu())
+    d = np.abs(pooled - g['pooled']).max(); df = np.abs(fl.detach().cpu().numpy() - g['output_flags']).max()
+    if precision == 'fp32':
+        assert d < FP32_TOL and df < FP32_TOL
+    else:
+        assert d < 0.08 * float(g['logit_std']) + 1e-3
+    Gm = torch.cat([torch.from_numpy(synth._rng(meta['seed'], f'g7_mask_{q}').standard_normal(size=(1,) + tuple(om.shape[1:]), dtype=np.float32)) for q in range(Qs)]).cuda()
+    Gf = torch.cat([torch.from_numpy(synth._rng(meta['seed'], f'g7_flags_{q}').standard_normal(size=(1,) + tuple(fl.shape[1:]), dtype=np.float32)) for q in range(Qs)]).cuda()
+    ((om * Gm).sum() * meta['mask_probe_scale'] + (fl * Gf).sum()).backward()
+    named = dict(net.named_parameters())
+    worst = {}
+    for k, ref in g.items():
+        if k.startswith('grad::'):
+            got = named[k[6:]].grad.cpu().numpy()
+        elif k.startswith('gsample::'):
+            got = grad_sample(named[k[9:]].grad.cpu().numpy())
+        else:
+            continue
+        worst[k] = np.abs(got - ref).max() / (np.abs(ref).max() + 1e-30)
+        assert worst[k] <= tol, (k, worst[k])
+    for k, n in meta['grad_norms'].items():
+        if n is None:
+            assert named[k].grad is None, k
+        else:
+            assert abs(float(named[k].grad.norm()) - n) <= tol * n + 1e-7, (k, float(named[k].grad.norm()), n)
+
+
+@pytest.mark.parametrize('precision', ['bf16', 'fp32'])
+def test_config3_long_clip_vs_reference_golden(cuda, precision):
+    """BASELINE configs[3]: T=60, 480x640 (1200 spatial x 60 temporal tokens, S = 1201), inference forward, against the reference's
+    output on the same synthetic clip (golden g8: pooled logits of six frames, per-frame sums / abs-max, flags)."""
+    meta, g = load_golden('g8_cfg3_long')
+    cfg, sd, rgb, qm = golden_inputs(meta)
+    net = build_hip_seeker(cfg, sd, precision).cuda().eval()
+    with torch.no_grad():
+        om, fl = net(rgb.cuda(), qm.cuda())
+    assert tuple(om.shape) == (1, 3, 60, 480, 640) and bool(torch.isfinite(om).all())
+    pooled, fsum, fmax = summarise(om.cpu())
+    pooled = pooled.reshape(60, 3, 120, 160)[g['frames']]
+    d = np.abs(pooled - g['pooled_frames']).max(); df = np.abs(fl.cpu().numpy() - g['output_flags']).max()
+    if precision == 'fp32':
+        assert d < FP32_TOL and df < FP32_TOL and np.abs(fmax - g['frame_absmax']).max() < FP32_TOL
+    else:
+        tol = 0.08 * float(g['logit_std']) + 1e-3
+        assert d < tol and df < tol + 5e-3
+    assert abs(float((om > 0).float().mean()) - float(g['positive_frac'])) < (1e-5 if precision == 'fp32' else 5e-3)
+
+
+@pytest.mark.parametrize('precision', ['bf16', 'fp32'])
+def test_config4_batched_eval_vs_reference_golden(cuda, precision):
+    """BASELINE configs[4]: num_queries = 4 x 4 temporal strides of one plugin-shaped video = 16 clips through ONE batched Seeker call
+    (the reference runs 16 sequential B = 1 forwards, eval/test.py + data_plugin.py:141-156); logits, flags and the IoU metrics of
+    eval/metrics.py:9-113 against what the reference's MyTrainPipeline.forward_plugin produced on 6 of the 16 items (golden g9)."""
+    from tcow_amd import plugin_data as pd
+    from tcow_amd.metrics import calculate_metrics_mask_track
+    from tcow_amd.pipeline import SeekerPipeline
+    meta, g = load_golden('g9_cfg4_eval')
+    cfg = meta['cfg']
+    net = build_hip_seeker(cfg, synth.make_state_dict(cfg, meta['seed']), precision).cuda().eval()
+    video = synth.make_plugin_video(meta['video_frames'], 240, 320, seed=meta['video_seed'])
+    items = pd.eval_items(video, num_frames=30, query_time_idx=0, queries=(0, 1, 2, 3), strides=(1, 2, 3, 4))
+    assert [[it['query'], it['frame_stride']] for it in items] == g['item_query_stride'].tolist()
+    pipe = SeekerPipeline(net, num_queries=1, phase='test', device='cuda')
+    with torch.no_grad():
+        mr = pipe.forward_plugin_items(items)
+    om, fl = mr['output_mask'], mr['output_flags']
+    assert tuple(om.shape) == (16, 3, 30, 240, 320)
+    logit_tol = FP32_TOL if precision == 'fp32' else 2e-2
+    for i in g['picked'].tolist():
+        pooled, fsum, _ = summarise(om[i:i + 1].cpu())
+        assert np.abs(pooled[::4] - g[f'item{i}::pooled']).max() < logit_tol, i
+        assert np.abs(fl[i:i + 1].cpu().numpy() - g[f'item{i}::output_flags']).max() < logit_tol + (0 if precision == 'fp32' else 5e-3), i
+        m = calculate_metrics_mask_track(om[i:i + 1], mr['target_mask'][i:i + 1], plugin=True)
+        for k in m:
+            ref = g[f'item{i}::metric::{k}']
+            if k.startswith('count_'):
+                assert int(m[k]) == int(ref), (i, k)                        # which frames carry annotations: exact
+            else:
+                assert abs(float(m[k]) - float(ref)) < (1e-6 if precision == 'fp32' else 3e-3), (i, k, float(m[k]), float(ref))
+    # batched == sequential, bit for bit (batch rows are independent)
+    with torch.no_grad():
+        one = pipe.forward_plugin_items(items[5:6])['output_mask']
+    assert torch.equal(one[0], om[5])
+
+
+@pytest.mark.parametrize('name', ['g11_depth18', 'g11_depth24'])
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_depth_18_and_24_vs_reference_golden(cuda, name, precision):
+    """V0 (vit.py:433-447): D = 896 / 14 heads / 18 blocks and D = 1024 / 16 heads / 24 blocks through Seeker(network_depth=...)."""
+    meta, g = load_golden(name)
+    cfg, sd, rgb, qm = golden_inputs(meta)
+    from tcow_amd.seeker import Seeker
+    net = Seeker(None, num_total_frames=cfg['num_total_frames'], frame_height=cfg['frame_height'], frame_width=cfg['frame_width'], causal_attention=1,
+                 network_depth=cfg['depth'], drop_path_rate=0.0, precision=precision)
+    assert net.seeker.embed_dim == cfg['embed_dim'] and net.seeker.num_heads == cfg['num_heads']
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    net = net.cuda().eval()
+    with torch.no_grad():
+        om, fl = net(rgb.cuda(), qm.cuda())
+    d = np.abs(om.cpu().numpy() - g['output_mask']).max(); df = np.abs(fl.cpu().numpy() - g['output_flags']).max()
+    if precision == 'fp32':
+        assert d < FP32_TOL and df < FP32_TOL
+    else:
+        assert d < bf16_tol(g['output_mask']) and df < bf16_tol(g['output_flags']) + 5e-3
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_pretrained_checkpoint_forward_vs_reference_golden(cuda, precision, tmp_path):
+    """(f)1 end to end on the GPU: image-ViT file -> tracker_pretrained=<path> (weight surgery of helpers.py:100-205) -> a reference-format
+    checkpoint.pth (train.py:269-304) -> load_tcow_checkpoint (eval/inference.py:38-54) -> HIP forward with the rgb normalisation of
+    vision_tf.py:81-89, against the reference's own forward with its own load_pretrained weights (golden g10)."""
+    import argparse
+    from oracle.make_golden_r2 import toy_vit_checkpoint
+    from tcow_amd.checkpoint import load_tcow_checkpoint
+    from tcow_amd.seeker import Seeker
+    meta, g = load_golden('g10_pretrained')
+    cfg, sd, rgb, qm = golden_inputs(meta)
+    vit_path = tmp_path / 'vit.pth'
+    torch.save({'state_dict': toy_vit_checkpoint(**meta['toy'])}, vit_path)
+    seeker_args = dict(num_total_frames=cfg['num_total_frames'], num_visible_frames=cfg['num_total_frames'], frame_height=cfg['frame_height'], frame_width=cfg['frame_width'],
+                       tracker_pretrained=str(vit_path), attention_type='divided_space_time', patch_size=16, causal_attention=1, norm_embeddings=False, drop_path_rate=0.1,
+                       network_depth=cfg['depth'], track_map_stride=4, track_map_resize='bilinear', query_channels=1, output_channels=3, flag_channels=3,
+                       embed_dim=cfg['embed_dim'], num_heads=cfg['num_heads'])
+    trained = Seeker(None, **seeker_args)
+    heads = {k[6:]: torch.from_numpy(v) for k, v in g.items() if k.startswith('head::')}
+    trained.load_state_dict({**trained.state_dict(), **heads}, strict=True)
+    ck_path = tmp_path / 'checkpoint.pth'
+    torch.save({'epoch': 0, 'train_args': argparse.Namespace(name='t'), 'dset_args': {}, 'seeker_args': seeker_args, 'net_seeker': trained.state_dict(),
+                'optim_seeker': {}, 'lr_sched_seeker': {}}, ck_path)
+    vit_path.unlink()                                                      # the eval-side load must not need the image-ViT file again
+    net = load_tcow_checkpoint(str(ck_path), device='cuda', precision=precision).eval()
+    assert net.seeker.tracker_pretrained is True
+    with torch.no_grad():
+        om, fl = net(rgb.cuda(), qm.cuda())
+    d = np.abs(om.cpu().numpy() - g['output_mask']).max(); df = np.abs(fl.cpu().numpy() - g['output_flags']).max()
+    if precision == 'fp32':
+        assert d < FP32_TOL and df < FP32_TOL
+    else:
+        assert d < bf16_tol(g['output_mask']) and df < bf16_tol(g['output_flags']) + 5e-3
+
+
 def test_full_size_properties(cuda):
     """BASELINE configs[1] geometry, bf16: determinism, batch independence (the Qs queries of pipeline.py:134 batched as
     B=3 equal three B=1 calls), inputs untouched, eval == train when DropPath is off."""
@@ -164,15 +363,23 @@ def test_fused_adamw_clip_matches_torch(cuda):
     pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
     ref = torch.optim.AdamW(pb, lr=1e-3)
     opt = FusedAdamWClip(pa, lr=1e-3, max_norm=0.3)
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt, [1, 2], gamma=0.3); sched_ref = torch.optim.lr_scheduler.MultiStepLR(ref, [1, 2], gamma=0.3)   # train.py:236-243 attaches unchanged
     for it in range(3):
         for a, b in zip(pa[:-1], pb[:-1]):                      # the last parameter never gets a gradient
             gr = torch.randn(a.shape, device=cuda, generator=g) * (10.0 if it == 0 else 0.001)   # clipped on step 0, not afterwards
             a.grad = gr.clone(); b.grad = gr.clone()
         n_ref = torch.nn.utils.clip_grad_norm_(pb, 0.3)
-        ref.step(); opt.step()
+        v0 = pa[0]._version
+        ref.step(); opt.step(); sched.step(); sched_ref.step()
+        assert pa[0]._version > v0                              # raw-pointer update made visible to version-keyed caches
         assert abs(float(opt.grad_norm()) - float(n_ref)) <= 1e-4 * float(n_ref)
         for a, b in zip(pa, pb):
             assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(b.abs().max()))
+    # state in torch.optim.AdamW's layout: it loads into AdamW and back (train.py:246-257 resumes 'optim_seeker' this way)
+    ref2 = torch.optim.AdamW(pb, lr=1e-3); ref2.load_state_dict(opt.state_dict())
+    assert all(torch.equal(ref2.state[b]['exp_avg'], opt.state[a]['exp_avg']) for a, b in zip(pa[:-1], pb[:-1]))
+    opt.load_state_dict(ref.state_dict())
+    assert opt.step_count == 3
 
 
 def test_persistent_gradient_buckets(cuda):
@@ -215,8 +422,8 @@ def test_training_is_bitwise_reproducible(cuda):
                      precision='bf16')
         net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg, 900).items()})
         net = net.cuda().train()
-        opt = FusedAdamWClip(list(net.parameters()), lr=1e-4, max_norm=0.3)
-        opt.on_step.append(net.seeker.invalidate_weight_cache); net.seeker.persistent_grads = True
+        opt = FusedAdamWClip(list(net.parameters()), lr=1e-4, max_norm=0.3, module=net)
+        net.seeker.persistent_grads = True
         data = synth.to_torch_tree(synth.make_kubric_batch(1, T, H, W, seed=900, n_objects=5), 'cuda', host_keys=synth.HOST_KEYS)
         pipe = SeekerPipeline(net, num_queries=3, train_args=default_args(), phase='train', device='cuda', rng=np.random.default_rng(0))
         losses = []

@@ -83,8 +83,70 @@ def test_reference_checkpoint_round_trip(tmp_path):
     cfg = synth.seeker_config(num_total_frames=4, frame_height=32, frame_width=48, causal_attention=1)
     sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg, 3).items()}
     path = tmp_path / 'checkpoint.pth'
-    torch.save({'epoch': 7, 'train_args': None, 'dset_args': {}, 'seeker_args': args, 'net_seeker': sd, 'optim_seeker': {}, 'lr_sched_seeker': {}}, path)
+    import argparse
+    train_args = argparse.Namespace(name='v1', num_frames=4, learn_rate=1e-4)         # train.py:269-275 pickles the argparse Namespace
+    torch.save({'epoch': 7, 'train_args': train_args, 'dset_args': {'x': 1}, 'seeker_args': args, 'net_seeker': sd, 'optim_seeker': {}, 'lr_sched_seeker': {}}, path)
     net = load_tcow_checkpoint(str(path), device='cpu')
     got = net.state_dict()
     assert list(got.keys()) == list(sd.keys()) and all(torch.equal(got[k], sd[k]) for k in sd)
-    assert net.seeker.causal_attention == 1 and net.seeker.tracker_pretrained is False
+    # a model trained from the ImageNet ViT ('1') keeps its rgb normalisation at eval time (eval/inference.py:44-52 passes seeker_args through)
+    assert net.seeker.causal_attention == 1 and net.seeker.tracker_pretrained is True
+    args['tracker_pretrained'] = 'false'
+    torch.save({'epoch': 7, 'train_args': train_args, 'dset_args': {}, 'seeker_args': args, 'net_seeker': sd, 'optim_seeker': {}, 'lr_sched_seeker': {}}, path)
+    assert load_tcow_checkpoint(str(path), device='cpu').seeker.tracker_pretrained is False
+
+
+def test_pretrained_surgery_matches_reference_load_pretrained(tmp_path):
+    """tests/golden/g10_pretrained.npz holds the state dict the reference's own helpers.load_pretrained (helpers.py:100-205) produced
+    from a toy image-ViT checkpoint file; ours must give the same tensors key for key, through the same file formats."""
+    import sys
+    from conftest import ROOT, load_golden
+    sys.path.insert(0, ROOT)
+    from oracle.make_golden_r2 import toy_vit_checkpoint
+    meta, g = load_golden('g10_pretrained')
+    toy = toy_vit_checkpoint(**meta['toy'])
+    cfg = meta['cfg']
+    for wrap in ('plain', 'state_dict', 'model'):
+        path = tmp_path / f'vit_{wrap}.pth'
+        torch.save(toy if wrap == 'plain' else {wrap: toy}, path)
+        torch.manual_seed(0)
+        net = Seeker(None, num_total_frames=cfg['num_total_frames'], frame_height=cfg['frame_height'], frame_width=cfg['frame_width'], tracker_pretrained=str(path),
+                     causal_attention=1, network_depth=cfg['depth'], embed_dim=cfg['embed_dim'], num_heads=cfg['num_heads'])
+        assert net.seeker.tracker_pretrained is True and net.seeker.pretrained_path == str(path)
+        got = net.seeker.vit.state_dict()
+        changed = 0
+        for k, ref in ((k[4:], v) for k, v in g.items() if k.startswith('sd::')):
+            if bool(g['changed::' + k]):                                   # tensors the reference's load overwrote
+                assert np.array_equal(got[k].numpy(), ref), (wrap, k)
+                changed += 1
+            else:                                                           # untouched by the load: stock init on both sides (time_embed, temporal_fc)
+                assert k.endswith('time_embed') or 'temporal_fc' in k, k
+                assert float(got[k].abs().max()) == 0.0
+        assert changed > 20
+
+
+def test_plugin_usage_modes_and_items():
+    """data_utils.py:301-342 / data_plugin.py:141-199: usage modes equal the reference's own (golden g9), item assembly by known answers."""
+    from conftest import load_golden
+    from tcow_amd import plugin_data as pd
+    _, g = load_golden('g9_cfg4_eval')
+    i = 0
+    while f'modes_{i}' in g:
+        a = g[f'modes_{i}_args'].tolist()
+        n_in, nf, qt, mtc = a[:4]
+        rest = a[5:]; cut = rest.index(-1)
+        got = pd.get_usage_modes(range(n_in), rest[:cut], rest[cut + 1:], nf, qt, min_target_frames_covered=mtc)
+        assert np.allclose(np.asarray(got, dtype=np.float64).reshape(-1, 3), g[f'modes_{i}']), i
+        i += 1
+    assert i == 5
+    rgb = np.arange(3 * 20 * 2 * 2, dtype=np.float32).reshape(3, 20, 2, 2)
+    q = {4: np.ones((2, 2), np.uint8)}
+    sn = {4: np.ones((2, 2), np.uint8), 9: np.zeros((2, 2), np.uint8), 11: np.ones((2, 2), np.uint8)}
+    oc = {11: np.ones((2, 2), np.uint8)}
+    it = pd.build_plugin_item(rgb, q, sn, oc, {}, frame_start=2, frame_stride=2, num_frames=6, query_time_idx=1)
+    assert it['frame_inds'] == [2, 4, 6, 8, 10, 12] and np.array_equal(it['pv_rgb_tf'], rgb[:, [2, 4, 6, 8, 10, 12]])
+    assert it['pv_query_tf'].sum() == 4 and it['pv_query_tf'][0, 1].all()
+    tg = it['pv_target_tf']
+    # snitch: round((t - start) / stride) -> t=4 -> 1, t=9 -> round(3.5) = 4 (banker's), t=11 -> round(4.5) = 4 (last write wins); occl: (11 - 2) // 2 = 4
+    assert (tg[0, 1] == 1).all() and (tg[0, 4] == 1).all() and (tg[0, [0, 2, 3, 5]] == -1).all()
+    assert (tg[1, 4] == 1).all() and (tg[1, [0, 1, 2, 3, 5]] == -1).all() and (tg[2] == -1).all()

@@ -78,3 +78,55 @@ def test_config2_full_size_matches_reference():
     """BASELINE configs[1] geometry (T=30, 240x320, 12 layers): ~15 s of CPU."""
     torch.set_num_threads(8)
     _check_summary('g4_cfg2_T30_240x320')
+
+
+@pytest.mark.parametrize('name', ['g11_depth18', 'g11_depth24', 'g10_pretrained'])
+def test_depth_variants_and_pretrained_forward_match_reference(name):
+    """V0: the reference's native depth-18 / depth-24 geometries (vit.py:433-447); g10: weights that went through the reference's
+    load_pretrained, forward with the pretrained rgb normalisation on (vision_tf.py:81-89)."""
+    meta, g = load_golden(name)
+    cfg, sd, rgb, qm = golden_inputs(meta)
+    if name == 'g10_pretrained':
+        sd = pretrained_state_dict(meta, g, sd)
+    with torch.no_grad():
+        om, fl = so.seeker_forward(so.to_torch_state_dict(sd), cfg, rgb, qm)
+    assert np.abs(om.numpy() - g['output_mask']).max() < 2e-5 and np.abs(fl.numpy() - g['output_flags']).max() < 2e-5
+
+
+def pretrained_state_dict(meta, g, sd):
+    """State dict of the g10 fixture: backbone = what the reference's load_pretrained produced, heads from synth."""
+    sd = dict(sd)
+    for k in g:
+        if k.startswith('sd::'):
+            sd[so.PREFIX + k[4:]] = g[k]
+    return sd
+
+
+def droppath_masks(g):
+    masks = {}
+    for k in g:
+        if k.startswith('keep::'):
+            _, i, kind = k.split('::')
+            masks[(int(i), kind)] = (torch.from_numpy(g[k]), float(g[f'rate::{i}']))
+    return masks
+
+
+@pytest.mark.parametrize('name', ['g12_droppath_ca1', 'g12_droppath_ca0'])
+def test_droppath_row_semantics_match_reference_train_mode(name):
+    """K9b: the reference in TRAIN mode (vit_utils.py:139-164, vit.py:172-174,186,216): temporal DropPath per site before
+    temporal_fc, spatial per frame (incl. the cls row that feeds the cls merge), MLP per sample -- forward and gradients."""
+    meta, g = load_golden(name)
+    cfg, sd, rgb, qm = golden_inputs(meta)
+    tsd = so.to_torch_state_dict(sd)
+    for v in tsd.values():
+        v.requires_grad_(True)
+    om, fl = so.seeker_forward(tsd, cfg, rgb, qm, drop_masks=droppath_masks(g))
+    assert np.abs(om.detach().numpy() - g['output_mask']).max() < TOL and np.abs(fl.detach().numpy() - g['output_flags']).max() < TOL
+    Gm = torch.from_numpy(synth._rng(meta['seed'], 'g12_mask').standard_normal(size=tuple(om.shape), dtype=np.float32))
+    Gf = torch.from_numpy(synth._rng(meta['seed'], 'g12_flags').standard_normal(size=tuple(fl.shape), dtype=np.float32))
+    ((om * Gm).sum() + (fl * Gf).sum()).backward()
+    for k, ref in g.items():
+        if k.startswith('grad::'):
+            assert np.abs(tsd[k[6:]].grad.numpy() - ref).max() <= 2e-4 * np.abs(ref).max() + 1e-7, k
+    no_drop, _ = so.seeker_forward(tsd, cfg, rgb, qm)
+    assert float((no_drop - om).abs().max()) > 1e-3                       # the masks really dropped something

@@ -11,7 +11,7 @@ dev = torch.device('cuda', 0)
 cfg = synth.seeker_config(causal_attention=1)
 net = Seeker(None, num_total_frames=30, frame_height=240, frame_width=320, causal_attention=1, drop_path_rate=0.1, precision='bf16')
 net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg, 900).items()}); net = net.to(dev).train()
-opt = FusedAdamWClip(list(net.parameters()), lr=1e-4, max_norm=0.3); opt.on_step.append(net.seeker.invalidate_weight_cache); net.seeker.persistent_grads = True
+opt = FusedAdamWClip(list(net.parameters()), lr=1e-4, max_norm=0.3, module=net); net.seeker.persistent_grads = True
 data = synth.to_torch_tree(synth.make_kubric_batch(1, 30, 240, 320, seed=900, n_objects=5), dev, host_keys=synth.HOST_KEYS)
 pipe = SeekerPipeline(net, num_queries=3, train_args=default_args(), phase='train', device=dev, rng=np.random.default_rng(0))
 def step(i):
