@@ -10,9 +10,11 @@ LIB := tcow_amd/libtcow_hip.so
 
 all: $(LIB)
 
+# (attention: no NaN arithmetic on the path -- lets fmaxf chains become v_max3_f32 without canonicalising v_max instructions)
+$(OBJ)/attention_bf16.hip.o: EXTRA := -fno-honor-nans
 $(OBJ)/%.hip.o: $(CSRC)/%.hip $(CSRC)/common.h include/tcow_hip.h
 	@mkdir -p $(OBJ)
-	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
+	$(HIPCC) $(HIPFLAGS) $(EXTRA) -x hip -c $< -o $@
 
 $(OBJ)/%.cpp.o: $(CSRC)/%.cpp $(CSRC)/common.h include/tcow_hip.h
 	@mkdir -p $(OBJ)

@@ -150,6 +150,11 @@ int tcow_attn_spatial_bwd(void* stream, const tcow_attn_shape* shape, const void
  *   backward != 0 applies the adjoint to a gradient buffer in place. */
 int tcow_im2col(void* stream, int dtype, int B, int T, int H, int W, int P, const float* rgb, const float* query,
                 int pretrained_norm, void* out);
+/* One channel group of the same gather: src (B,C,T,H,W) f32 -> out `dtype` [B*T*S, C*P*P] (normalise != 0: (x-0.45)/0.225).
+ * The Qs queries of a clip share its rgb frames (pipeline.py:134-158 re-feeds the same seeker_input Qs times): the patch
+ * embedding then splits into ONE rgb GEMM per clip (C = 3) plus a K = P*P mask-channel GEMM per query (C = 1). */
+int tcow_im2col_channels(void* stream, int dtype, int B, int T, int H, int W, int P, int C, const float* src,
+                         int normalise, void* out);
 int tcow_embed_fwd(void* stream, int B, int T, int S, int D, float* x, const float* cls, const float* pos,
                    const float* time_embed);
 int tcow_embed_bwd(void* stream, int B, int T, int S, int D, const float* g, float* dpos, float* dtime,

@@ -33,6 +33,14 @@ constexpr int TILE_B = 4096;                 // 32 rows x 128 B
 constexpr float kScale = 0.125f;             // head_dim^-0.5 (vit.py:70)
 constexpr float kLog2e = 1.4426950408889634f;
 
+// Combine a value with the other half-wave's (lane ^ 32) without an LDS round trip (__shfl_xor lowers to ds_bpermute): v_permlane32_swap
+// exchanges the upper half of its first operand with the lower half of its second, so two copies of v become (lower, lower) and
+// (upper, upper).  Inline asm: with identical operands hipcc 7.2 folds the builtin's two results into one (wrong values, caught by the
+// oracle tests); the two v_nop are the VALU-write -> permlane-read wait states the compiler does not insert inside an asm statement.
+__device__ __forceinline__ void half_swap(float& a, float& b) { asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ float half_max(float v) { float a = v, b = v; half_swap(a, b); return fmaxf(a, b); }
+__device__ __forceinline__ float half_sum(float v) { float a = v, b = v; half_swap(a, b); return a + b; }
+
 __device__ __forceinline__ int swz_g(int r) { return (((r >> 1) & 1) << 2) | ((r >> 2) & 3); }
 
 __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
@@ -113,7 +121,7 @@ __device__ __forceinline__ void fwd_tile(const SeqDesc& sd, const char* ktile, c
     float mx = s[0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * sc;            // (sc > 0: the maximum commutes with the scale)
+    mx = half_max(mx) * sc;                                 // (sc > 0: the maximum commutes with the scale)
     if (__any(mx > m + 8.0f)) {
         const float mn = fmaxf(m, mx);
         const float alpha = exp2f(m - mn);
@@ -142,7 +150,7 @@ __device__ __forceinline__ void fwd_tile(const SeqDesc& sd, const char* ktile, c
 // normalise and store one query tile's output (+ log-sum-exp)
 __device__ __forceinline__ void fwd_store(const SeqDesc& sd, long base, int head, int q, int hi, float m, float l, const f32x16& o0, const f32x16& o1,
                                           bf16_t* __restrict__ out, float* __restrict__ lse) {
-    l += __shfl_xor(l, 32, 64);
+    l = half_sum(l);
     if (q < sd.L) {
         const float inv = 1.0f / l;
         const long row = base + (long)q * sd.pos_stride;
@@ -512,7 +520,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_one_tile(SeqDesc sd, const bf
         const float4 x = ld4(oh + (size_t)qc * pso + 32 * hi + d), y = ld4(doh + (size_t)qc * pso + 32 * hi + d);
         part += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
     }
-    const float dl = part + __shfl_xor(part, 32, 64);
+    const float dl = half_sum(part);
     const float lsv = lse[(base + (long)qc * sd.pos_stride) * sd.heads + w.head];
     if (hi == 0) ldw[l31] = l31 < sd.L ? make_float2(lsv, dl) : make_float2(0.f, 0.f);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -623,7 +631,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_stream(SeqDesc sd, int nt,
 #pragma unroll
         for (int e = 0; e < 8; ++e) part = fmaf((float)of[e], (float)dof[ks][e], part);
     }
-    const float dl = part + __shfl_xor(part, 32, 64);
+    const float dl = half_sum(part);
     const float lsn = lse[(base + (long)qc * sd.pos_stride) * sd.heads + head];
     if (active && hi == 0) ldh[32 * qt + l31] = q < sd.L ? make_float2(lsn, dl) : make_float2(0.f, 0.f);
     const float ls = lsn * kLog2e;

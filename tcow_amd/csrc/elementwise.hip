@@ -352,6 +352,17 @@ int tcow_im2col(void* stream, int dtype, int B, int T_, int H, int W, int P, con
     return TCOW_OK;
 }
 
+int tcow_im2col_channels(void* stream, int dtype, int B, int T_, int H, int W, int P, int C, const float* src, int normalise, void* out) {
+    TCOW_CHECK_ARG(B > 0 && T_ > 0 && C > 0 && P > 0 && P % 4 == 0 && H % P == 0 && W % P == 0, "tcow_im2col_channels: bad geometry B=%d T=%d H=%d W=%d P=%d C=%d", B, T_, H, W, P, C);
+    TCOW_CHECK_ARG(src && out, "tcow_im2col_channels: null pointer");
+    const long total = (long)B * T_ * ((H / P) * (W / P) + 1) * (C * P * P / 4);
+    if (dtype == TCOW_BF16) hipLaunchKernelGGL(im2col_kernel<bf16_t>, dim3(gs_blocks(total)), dim3(256), 0, (hipStream_t)stream, B, T_, H, W, P, C, 0, src, src, normalise, (bf16_t*)out);
+    else if (dtype == TCOW_F32) hipLaunchKernelGGL(im2col_kernel<float>, dim3(gs_blocks(total)), dim3(256), 0, (hipStream_t)stream, B, T_, H, W, P, C, 0, src, src, normalise, (float*)out);
+    else { tcow_set_error("tcow_im2col_channels: unknown dtype %d", dtype); return TCOW_ERR_INVALID_ARG; }
+    TCOW_CHECK_LAUNCH();
+    return TCOW_OK;
+}
+
 int tcow_embed_fwd(void* stream, int B, int T_, int S, int D, float* x, const float* cls, const float* pos, const float* time_embed) {
     TCOW_CHECK_ARG(B > 0 && T_ > 0 && S > 1 && D % 4 == 0 && x && cls && pos && time_embed, "tcow_embed_fwd: bad arguments");
     hipLaunchKernelGGL(embed_fwd_kernel, dim3(gs_blocks((long)B * T_ * S * D / 4)), dim3(256), 0, (hipStream_t)stream, B, T_, S, D, x, cls, pos, time_embed);

@@ -175,7 +175,7 @@ def run_forward(module, rgb, qm, params, save):
     mode = module.mode
     dt = ops.tdtype(mode)
     dev = rgb.device
-    B = rgb.shape[0]
+    B = qm.shape[0]                          # query rows (== clips unless the rgb frames are shared between a clip's queries)
     g = module.geometry(B)
     T, S, D, M, P, heads = g['T'], g['S'], g['D'], g['M'], g['P'], g['heads']
     ca = module.causal_attention
@@ -192,10 +192,29 @@ def run_forward(module, rgb, qm, params, save):
 
     # ---- patch embed (vit.py:233-241) + embeddings (vision_tf.py:99-138)
     Kpe = module.input_channels * P * P
-    A_pe = E(M, Kpe)
-    ops.im2col(mode, rgb, qm, P, module.tracker_pretrained, A_pe)
     X = E(M, D, dtype=f32)
-    ops.gemm_nt(mode, A_pe, W(params[3]), X, bias=params[4].detach())
+    Bc = rgb.shape[0]                        # clips; B = Bc * Qs query rows
+    Qs = B // Bc
+    if Qs > 1:
+        # shared rgb: the Qs queries of a clip see the same frames (pipeline.py:134-158), only the mask channel differs:
+        # conv(cat[rgb, mask]) = W[:, :3] * rgb + W[:, 3] * mask -> one K = 3 P^2 GEMM per clip + one K = P^2 GEMM per query, the
+        # latter taking the clip's rgb part as its residual operand
+        Krgb = 3 * P * P
+        Wc = W(params[3])                                            # [D, 4 P^2], channel-major columns (vit.py:233)
+        A_rgb = E(Bc * T * S, Krgb); A_m = E(M, Kpe - Krgb)
+        ops.im2col_channels(mode, rgb, P, module.tracker_pretrained, A_rgb)
+        ops.im2col_channels(mode, qm, P, False, A_m)
+        Xrgb = E(Bc * T * S, D, dtype=f32)
+        ops.gemm_nt(mode, A_rgb, Wc[:, :Krgb], Xrgb, bias=params[4].detach())
+        TS = T * S
+        for bq in range(B):
+            b = bq // Qs
+            ops.gemm_nt(mode, A_m[bq * TS:(bq + 1) * TS], Wc[:, Krgb:], X[bq * TS:(bq + 1) * TS], resid=Xrgb[b * TS:(b + 1) * TS])
+        A_pe = (A_rgb, A_m)
+    else:
+        A_pe = E(M, Kpe)
+        ops.im2col(mode, rgb, qm, P, module.tracker_pretrained, A_pe)
+        ops.gemm_nt(mode, A_pe, W(params[3]), X, bias=params[4].detach())
     pos, te, pos_idx, time_idx = _effective_embeddings(module, g)
     ops.embed_fwd(X, B, T, S, params[0].detach().reshape(-1), pos, te)
     if save:
@@ -453,8 +472,17 @@ def run_backward(module, sv, params, d_mask, d_flags):
     else:
         Gpe = E(M, D)
         ops.scale_cast(mode, gX, mask0, Gpe)
-    dWpe = galloc(3)
-    ops.gemm_tn(mode, Gpe, sv['A_pe'], dWpe.reshape(D, -1))
+    dWpe = galloc(3).reshape(D, -1)
+    if isinstance(sv['A_pe'], tuple):                                   # shared rgb: dW[:, :3 P^2] = (sum over the clip's queries of G)^T A_rgb
+        A_rgb, A_m = sv['A_pe']
+        Krgb = A_rgb.shape[1]
+        Bc = A_rgb.shape[0] // (T * S)
+        Gsum = E(Bc * T * S, D)
+        ops.scale_cast(mode, gX.reshape(Bc, B // Bc, T * S, D).sum(dim=1).reshape(Bc * T * S, D), mask0[:Bc * T * S], Gsum)
+        ops.gemm_tn(mode, Gsum, A_rgb, dWpe[:, :Krgb])
+        ops.gemm_tn(mode, Gpe, A_m, dWpe[:, Krgb:])
+    else:
+        ops.gemm_tn(mode, Gpe, sv['A_pe'], dWpe)
     grads[4].copy_(dtime_eff.sum(0))       # bias gradient = sum over all patch rows
     if module.grad_hook is not None:
         module.grad_hook('embed', emb_flat)

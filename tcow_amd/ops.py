@@ -114,6 +114,13 @@ def im2col(mode, rgb, query, P, pretrained_norm, out):
     return out
 
 
+def im2col_channels(mode, src, P, normalise, out):
+    """src (B,C,T,H,W) f32 -> out [B*T*S, C*P*P] (see tcow_im2col_channels)."""
+    B, C, T, H, W = src.shape
+    L.check(L.lib().tcow_im2col_channels(_stream(), mode, B, T, H, W, P, C, src.data_ptr(), int(normalise), out.data_ptr()), 'tcow_im2col_channels')
+    return out
+
+
 def embed_fwd(x, B, T, S, cls, pos, time_embed):
     L.check(L.lib().tcow_embed_fwd(_stream(), B, T, S, x.shape[1], x.data_ptr(), cls.data_ptr(), pos.data_ptr(), time_embed.data_ptr()), 'tcow_embed_fwd')
     return x

@@ -158,8 +158,11 @@ class SeekerPipeline:
             flags_ready = torch.cuda.Event(); flags_ready.record()
         else:
             host_flags, flags_ready = nonzero, None
-        rgb_rep = rgb[:, None].expand(B, Qs, 3, T, H, W).reshape(B * Qs, 3, T, H, W)
-        out_mask, _ = self.seeker(rgb_rep, query_mask.reshape(B * Qs, 1, T, H, W))   # pipeline.py:157-158, Qs calls in one
+        if getattr(self.seeker, 'shares_rgb', False):                          # tcow_amd Seeker: the clip's frames go in once for its Qs queries
+            out_mask, _ = self.seeker(rgb, query_mask.reshape(B * Qs, 1, T, H, W))
+        else:
+            rgb_rep = rgb[:, None].expand(B, Qs, 3, T, H, W).reshape(B * Qs, 3, T, H, W)
+            out_mask, _ = self.seeker(rgb_rep, query_mask.reshape(B * Qs, 1, T, H, W))   # pipeline.py:157-158, Qs calls in one
         if flags_ready is not None:
             flags_ready.synchronize()
         for q in range(Qs):

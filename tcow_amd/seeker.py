@@ -233,9 +233,13 @@ class QueryMaskTracker(nn.Module):
 
     # ---- forward
     def forward(self, input_frames, query_mask):
-        """mask_tracker.py:92-142: (B,3,T,Hf,Wf), (B,1,T,Hf,Wf) -> (B,C,T,Hf,Wf) logits, (B,T,F) flags."""
+        """mask_tracker.py:92-142: (B,3,T,Hf,Wf), (B,1,T,Hf,Wf) -> (B,C,T,Hf,Wf) logits, (B,T,F) flags.
+        Extension (SURVEY 8f-3): query_mask may carry Qs masks per clip, (B*Qs,1,T,Hf,Wf) with clip b's queries at rows b*Qs..b*Qs+Qs-1;
+        the outputs then have B*Qs rows and equal Qs separate calls with the same frames (pipeline.py:134-158), but the rgb part of the
+        patch embedding is computed once per clip."""
         (B, _, T, Hf, Wf) = input_frames.shape
         assert query_mask.shape[1] == 1                                   # mask_tracker.py:105
+        assert query_mask.shape[0] % B == 0 and query_mask.shape[2:] == input_frames.shape[2:]
         assert T == self.num_total_frames                                 # vision_tf.py:96
         assert Hf == self.frame_height and Wf == self.frame_width         # vision_tf.py:97 (W' check)
         if not input_frames.is_cuda:
@@ -259,6 +263,8 @@ class QueryMaskTracker(nn.Module):
 
 class Seeker(nn.Module):
     """model/seeker.py:17-25."""
+
+    shares_rgb = True          # forward accepts (B, ...) frames with (B * Qs, ...) query masks (see QueryMaskTracker.forward)
 
     def __init__(self, logger, **kwargs):
         super().__init__()

@@ -295,6 +295,34 @@ def test_pretrained_checkpoint_forward_vs_reference_golden(cuda, precision, tmp_
         assert d < bf16_tol(g['output_mask']) and df < bf16_tol(g['output_flags']) + 5e-3
 
 
+@pytest.mark.parametrize('precision,tol,gtol', [('fp32', 2e-5, 2e-4), ('bf16', 1.5e-2, 4e-2)])
+def test_shared_rgb_queries_equal_expanded_batch(cuda, precision, tol, gtol):
+    """Qs query masks per clip with the frames passed ONCE ((B,3,..) + (B*Qs,1,..)) == the same frames repeated per query
+    (what pipeline.py:134-158 feeds): outputs, and the gradients of the patch-embedding weight whose rgb / mask column blocks are now
+    produced by two different GEMMs."""
+    cfg = synth.seeker_config(num_total_frames=4, frame_height=64, frame_width=96, embed_dim=256, depth=2, num_heads=4, causal_attention=1)
+    sd = synth.make_state_dict(cfg, 11)
+    B, Qs = 2, 3
+    clip = synth.make_clip(B, 4, 64, 96, seed=5)
+    rgb = torch.from_numpy(clip['rgb']).cuda()
+    qm = torch.stack([torch.from_numpy(synth.make_query_mask(clip, q, 0)) for q in range(Qs)], 1).reshape(B * Qs, 1, 4, 64, 96).cuda()   # clip-major rows
+    res = {}
+    for shared in (True, False):
+        net = build_hip_seeker(cfg, sd, precision).cuda().train()
+        frames = rgb if shared else rgb[:, None].expand(B, Qs, -1, -1, -1, -1).reshape(B * Qs, 3, 4, 64, 96).contiguous()
+        om, fl = net(frames, qm)
+        assert tuple(om.shape) == (B * Qs, 3, 4, 64, 96) and tuple(fl.shape) == (B * Qs, 4, 3)
+        g = torch.Generator(device='cuda').manual_seed(1)
+        (om * torch.randn(om.shape, device=cuda, generator=g)).sum().backward()
+        pe = net.seeker.vit.patch_embed.proj
+        res[shared] = (om.detach(), fl.detach(), pe.weight.grad.clone(), pe.bias.grad.clone(), net.seeker.vit.blocks[0].attn.qkv.weight.grad.clone())
+    a, b = res[True], res[False]
+    assert float((a[0] - b[0]).abs().max()) < tol and float((a[1] - b[1]).abs().max()) < tol
+    for x, y in zip(a[2:], b[2:]):
+        assert float((x - y).abs().max()) <= gtol * float(y.abs().max()) + 1e-7
+    assert float((a[0][0] - a[0][1]).abs().max()) > 0                      # different queries of one clip -> different masks
+
+
 def test_full_size_properties(cuda):
     """BASELINE configs[1] geometry, bf16: determinism, batch independence (the Qs queries of pipeline.py:134 batched as
     B=3 equal three B=1 calls), inputs untouched, eval == train when DropPath is off."""
