@@ -155,6 +155,11 @@ int tcow_im2col(void* stream, int dtype, int B, int T, int H, int W, int P, cons
  * embedding then splits into ONE rgb GEMM per clip (C = 3) plus a K = P*P mask-channel GEMM per query (C = 1). */
 int tcow_im2col_channels(void* stream, int dtype, int B, int T, int H, int W, int P, int C, const float* src,
                          int normalise, void* out);
+/* Input-pipeline gather (data/augs.py:150-203: frame sub-sampling, centre / random crop, horizontal flip, NEAREST resize composed into
+ * index tables by tcow_amd/augs.py): out[c,t,y,x] = src[c, frame_idx[t], src_y[y], src_x[x]]; src (C,Tv,H,W), out (C,Tc,h,w), elements of
+ * elem_bytes = 1 (uint8 segmentation / masks) or 4 (f32 frames); index tables are device int32 arrays with in-range entries. */
+int tcow_gather_frames(void* stream, int elem_bytes, int C, int Tv, int H, int W, int Tc, int h, int w, const void* src,
+                       const int* frame_idx, const int* src_y, const int* src_x, void* out);
 int tcow_embed_fwd(void* stream, int B, int T, int S, int D, float* x, const float* cls, const float* pos,
                    const float* time_embed);
 int tcow_embed_bwd(void* stream, int B, int T, int S, int D, const float* g, float* dpos, float* dtime,

@@ -278,6 +278,127 @@ def g12():
         save(f'g12_droppath_ca{ca}', cfg, B, arrays, dict(d_mask=d, d_flags=dfl, t_ref=0.0, grad_norms=norms, drop_path_rate=rate, torch_seed=seed))
 
 
+def augs_inputs(tag, H, W):
+    """Deterministic integer test videos of the g13 fixture: segm (1,14,H,W) and div_segm (4,14,H,W) uint8 (regenerated by the tests)."""
+    r = synth._rng(SEED, 'g13_' + tag)
+    return torch.from_numpy(r.integers(0, 7, size=(1, 14, H, W), dtype=np.uint8)), torch.from_numpy(r.integers(0, 2, size=(4, 14, H, W), dtype=np.uint8))
+
+
+def g13():
+    """(f)4: the reference's augmentation INDEX logic (data/augs.py:50-210).  sample_augs_params is pure numpy (global RNG): run as is for
+    many seeds / settings.  apply_augs_2d_frames is run on the integer modalities ('segm', 'div_segm') only; torchvision is not installed,
+    so its two index operators used there get functional stand-ins written from torchvision's documented semantics -- CenterCrop (top =
+    round((H - h) / 2), left = round((W - w) / 2)) and Resize(NEAREST) (torch.nn.functional.interpolate(mode='nearest')) -- everything
+    else (frame selection, crop arithmetic, flip, op order) is the reference's own code."""
+    import importlib
+    ref_shim.load()
+    cwd = os.getcwd(); os.chdir(ref_shim.REF)
+    try:
+        augs = importlib.import_module('augs')
+    finally:
+        os.chdir(cwd)
+
+    class CenterCrop:
+        def __init__(self, size): self.size = size
+        def __call__(self, x):
+            h, w = self.size; H, W = x.shape[-2:]
+            top = int(round((H - h) / 2.0)); left = int(round((W - w) / 2.0))
+            return x[..., top:top + h, left:left + w]
+
+    class Resize:
+        def __init__(self, size, interpolation=None, antialias=None): self.size, self.antialias = size, antialias
+        def __call__(self, x):
+            assert not self.antialias, 'smooth resize is out of scope'
+            return torch.nn.functional.interpolate(x.float(), size=self.size, mode='nearest').to(x.dtype)
+
+    augs.torchvision.transforms.CenterCrop = CenterCrop
+    augs.torchvision.transforms.Resize = Resize
+    arrays = {}
+    cases = []
+    for seed in range(12):
+        for (nl, nc, fs, rnd, a2d, rp, pp) in [(36, 30, 1, True, True, 0.2, 0.1), (42, 30, 2, True, False, 0.5, 0.6), (30, 30, 1, False, False, 0.0, 0.0), (24, 8, 3, True, True, 0.0, 1.0)]:
+            cases.append((seed, nl, nc, fs, rnd, a2d, rp, pp))
+    keys = ['palindrome', 'reverse', 'frame_stride_factor', 'offset', 'color_jitter', 'rgb_blur', 'rgb_grayscale', 'horz_flip']
+    for i, (seed, nl, nc, fs, rnd, a2d, rp, pp) in enumerate(cases):
+        pipe = augs.MyAugmentationPipeline(ref_shim.NullLogger(), nl, nc, 240, 320, fs, rnd, a2d, rp, pp, False)
+        np.random.seed(1000 + seed)
+        p = pipe.sample_augs_params()
+        arrays[f'params{i}::scalars'] = np.asarray([float(p[k]) for k in keys], dtype=np.float64)
+        arrays[f'params{i}::frame_inds_load'] = np.asarray(p['frame_inds_load']); arrays[f'params{i}::frame_inds_clip'] = np.asarray(p['frame_inds_clip'])
+        arrays[f'params{i}::crop_rect'] = np.asarray(p['crop_rect'], dtype=np.float64)
+    arrays['param_cases'] = np.asarray(cases, dtype=np.float64)
+    # index chain on integer modalities: several source sizes (incl. aspect ratios that trigger either centre-crop branch)
+    k = 0
+    for (H, W, oh, ow, cc, rnd, a2d) in [(120, 160, 60, 80, False, True, True), (100, 180, 48, 64, True, False, False), (150, 120, 60, 80, True, True, True),
+                                          (96, 128, 96, 128, False, True, True), (77, 131, 40, 56, True, True, True), (64, 64, 120, 160, True, True, True)]:
+        for seed in range(3):
+            pipe = augs.MyAugmentationPipeline(ref_shim.NullLogger(), 14, 10, oh, ow, 1, rnd, a2d, 0.3, 0.4, cc)
+            np.random.seed(2000 + 10 * k + seed)
+            p = pipe.sample_augs_params()
+            tag = f'aug{k}_{seed}'
+            segm, div = augs_inputs(tag, H, W)
+            out = pipe.apply_augs_2d_frames({'segm': segm, 'div_segm': div}, p)
+            arrays[tag + '::cfg'] = np.asarray([H, W, oh, ow, int(cc), int(rnd), int(a2d), 2000 + 10 * k + seed], dtype=np.int64)
+            arrays[tag + '::segm_out'] = out['segm'].numpy(); arrays[tag + '::div_out'] = out['div_segm'].numpy()
+        k += 1
+    np.savez_compressed(os.path.join(OUT, 'g13_augs.npz'), **arrays)
+    print('  wrote g13_augs.npz', os.path.getsize(os.path.join(OUT, 'g13_augs.npz')) // 1024, 'KiB')
+
+
+def g14():
+    """A0: attention_type='joint_space_time' (vit.py:159-163; CLI-selectable at args.py:154-156): forward, gradients and train-mode
+    DropPath (one draw per sample for the attention and one for the MLP) from the reference."""
+    rate, depth, B, T, H, W = 0.3, 3, 2, 3, 48, 64
+    cfg = synth.seeker_config(num_total_frames=T, frame_height=H, frame_width=W, embed_dim=256, depth=depth, num_heads=4, causal_attention=0,
+                              attention_type='joint_space_time')
+    sd = synth.make_state_dict(cfg, SEED)
+    clip = synth.make_clip(B, T, H, W, seed=SEED)
+    rgb = torch.from_numpy(clip['rgb']); qm = torch.from_numpy(synth.make_query_mask(clip, 0, 0))
+    net = ref_shim.build_reference_seeker(cfg, sd, drop_path_rate=rate)
+    assert len(net.state_dict()) == len(sd)
+    Gm = Gf = None
+    arrays = {}
+    for mode in ('eval', 'train'):
+        net.train(mode == 'train'); net.zero_grad()
+        seed = 4321
+        torch.manual_seed(seed)
+        om, fl = net(rgb.clone(), qm)
+        masks = None
+        if mode == 'train':
+            torch.manual_seed(seed)
+            rates = torch.linspace(0, rate, depth).tolist()
+            masks = {}
+            for i in range(depth):
+                if rates[i] > 0.:
+                    for kind in ('spatial', 'mlp'):
+                        masks[(i, kind)] = ((1.0 - rates[i] + torch.rand((B, 1, 1), dtype=torch.float32)).floor_().reshape(B), rates[i])
+        osd = {k: torch.from_numpy(v).requires_grad_(True) for k, v in sd.items()}
+        om2, fl2 = so.seeker_forward(osd, cfg, rgb, qm, drop_masks=masks)
+        d = (om.detach() - om2.detach()).abs().max().item(); dfl = (fl.detach() - fl2.detach()).abs().max().item()
+        assert d < 1e-5 and dfl < 1e-5, (mode, d, dfl)
+        if Gm is None:
+            Gm = torch.from_numpy(synth._rng(SEED, 'g14_mask').standard_normal(size=tuple(om.shape), dtype=np.float32))
+            Gf = torch.from_numpy(synth._rng(SEED, 'g14_flags').standard_normal(size=tuple(fl.shape), dtype=np.float32))
+        ((om * Gm).sum() + (fl * Gf).sum()).backward(); ((om2 * Gm).sum() + (fl2 * Gf).sum()).backward()
+        named = dict(net.named_parameters())
+        for k, p in named.items():
+            if p.grad is not None:
+                e = (osd[k].grad - p.grad).abs().max().item() / (p.grad.abs().max().item() + 1e-12)
+                assert e < 2e-4, (mode, k, e)
+        arrays[f'{mode}::output_mask'] = om.detach().numpy(); arrays[f'{mode}::output_flags'] = fl.detach().numpy()
+        arrays[f'{mode}::grad_norms'] = np.asarray([float(p.grad.norm()) if p.grad is not None else -1.0 for p in named.values()])
+        for k in ('seeker.tracker_backbone.timesformer.model.blocks.1.attn.qkv.weight', 'seeker.tracker_backbone.timesformer.model.blocks.2.attn.proj.bias',
+                  'seeker.tracker_backbone.timesformer.model.cls_token', 'seeker.tracker_backbone.timesformer.model.blocks.0.norm1.weight',
+                  'seeker.tracker_backbone.timesformer.model.patch_embed.proj.weight'):
+            gk = named[k].grad.numpy()
+            arrays[f'{mode}::' + ('gsample::' if gk.size > 4096 else 'grad::') + k] = so.grad_sample(gk) if gk.size > 4096 else gk.copy()
+        if masks:
+            for (i, kind), (keep, r) in masks.items():
+                arrays[f'keep::{i}::{kind}'] = keep.numpy(); arrays[f'rate::{i}'] = np.float32(r)
+    arrays['param_names'] = np.asarray(list(dict(net.named_parameters()).keys()))
+    save('g14_joint', cfg, B, arrays, dict(d_mask=d, d_flags=dfl, t_ref=0.0, drop_path_rate=rate))
+
+
 def main():
     ap = argparse.ArgumentParser(); ap.add_argument('--only', default='g10,g11,g9,g7,g8'); args = ap.parse_args()
     assert ref_shim.available(), 'reference tree not found'

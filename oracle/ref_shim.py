@@ -104,7 +104,7 @@ def build_reference_seeker(cfg, np_state_dict, drop_path_rate=0.0):
     std = {12: (768, 12), 18: (896, 14), 24: (1024, 16)}
     native = depth in std and std[depth] == (D, heads)
     kw = dict(num_total_frames=cfg['num_total_frames'], frame_height=cfg['frame_height'],
-              frame_width=cfg['frame_width'], tracker_pretrained=False, attention_type='divided_space_time',
+              frame_width=cfg['frame_width'], tracker_pretrained=False, attention_type=cfg.get('attention_type', 'divided_space_time'),
               patch_size=cfg['patch_size'], causal_attention=cfg['causal_attention'],
               norm_embeddings=cfg['norm_embeddings'], drop_path_rate=drop_path_rate,
               network_depth=depth if native else 12, track_map_stride=cfg['track_map_stride'],
@@ -121,7 +121,7 @@ def build_reference_seeker(cfg, np_state_dict, drop_path_rate=0.0):
             img_size=(cfg['frame_height'], cfg['frame_width']), patch_size=cfg['patch_size'],
             in_chans=3 + cfg['query_channels'], num_classes=0, embed_dim=D, depth=depth, num_heads=heads,
             mlp_ratio=cfg['mlp_ratio'], qkv_bias=True, norm_layer=partial(torch.nn.LayerNorm, eps=1e-6),
-            drop_path_rate=drop_path_rate, num_frames=cfg['num_total_frames'], attention_type='divided_space_time',
+            drop_path_rate=drop_path_rate, num_frames=cfg['num_total_frames'], attention_type=cfg.get('attention_type', 'divided_space_time'),
             causal_attention=cfg['causal_attention'])
         bb = qt.tracker_backbone
         bb.timesformer.model = vt

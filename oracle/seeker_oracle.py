@@ -149,40 +149,54 @@ def seeker_forward(sd, cfg, input_frames, query_mask, drop_masks=None, taps=None
         keep, rate = drop_masks[(i, kind)]
         return drop_path_scale(keep.to(dt), rate)
 
+    joint = cfg.get('attention_type', 'divided_space_time') == 'joint_space_time'
     for i in range(cfg['depth']):
         b = PREFIX + f'blocks.{i}.'
-        # ---- temporal half (vit.py:169-176)
-        U = layer_norm(X, sd[b + 'temporal_norm1.weight'], sd[b + 'temporal_norm1.bias'])
-        Ut = U.permute(0, 2, 1, 3).reshape(B * N, T, D)                   # '(b h w) t m'
-        R = attention(Ut, sd[b + 'temporal_attn.qkv.weight'], sd[b + 'temporal_attn.qkv.bias'],
-                      sd[b + 'temporal_attn.proj.weight'], sd[b + 'temporal_attn.proj.bias'], heads, ca)
-        s = dp(i, 'temporal', None)
-        if s is not None:
-            R = R * s.reshape(B * N, 1, 1)                                # DropPath before temporal_fc
-        R = R @ sd[b + 'temporal_fc.weight'].t() + sd[b + 'temporal_fc.bias']
-        Xt = X + R.reshape(B, N, T, D).permute(0, 2, 1, 3)
-        # ---- spatial half (vit.py:179-210)
-        use_cls = ca in (0, 1)
-        if use_cls:
-            Vin = torch.cat([CLS[:, None, None, :].expand(B, T, 1, D), Xt], dim=2)       # (B,T,S,D)
-        else:                                                              # ca>=2 or ca==-1 (vit.py:202-208)
-            Vin = Xt
-        S = Vin.shape[2]
-        Y = attention(layer_norm(Vin, sd[b + 'norm1.weight'], sd[b + 'norm1.bias']).reshape(B * T, S, D),
-                      sd[b + 'attn.qkv.weight'], sd[b + 'attn.qkv.bias'],
-                      sd[b + 'attn.proj.weight'], sd[b + 'attn.proj.bias'], heads, 0).reshape(B, T, S, D)
-        s = dp(i, 'spatial', None)
-        if s is not None:
-            Y = Y * s.reshape(B, T, 1, 1)
-        if use_cls:
-            cls_rows = Y[:, :, 0]                                          # (B, T, D)
-            cls_out = cls_rows.mean(dim=1) if ca == 0 else cls_rows[:, 0]  # vit.py:193-198
-            res = Y[:, :, 1:]
+        if joint:
+            # ---- joint space-time attention (vit.py:159-162): one sequence (cls, all N*T patch tokens) per clip, no mask, DropPath per sample
+            assert ca == 0                                                   # vit.py:160
+            allt = torch.cat([CLS[:, None, :], X.reshape(B, T * N, D)], dim=1)
+            Y = attention(layer_norm(allt, sd[b + 'norm1.weight'], sd[b + 'norm1.bias']), sd[b + 'attn.qkv.weight'], sd[b + 'attn.qkv.bias'],
+                          sd[b + 'attn.proj.weight'], sd[b + 'attn.proj.bias'], heads, 0)
+            s = dp(i, 'spatial', None)
+            if s is not None:
+                Y = Y * s.reshape(B, 1, 1)
+            allt = allt + Y
+            CLS = allt[:, 0]
+            X = allt[:, 1:].reshape(B, T, N, D)
         else:
-            cls_out = torch.zeros_like(CLS)                                # vit.py:205
-            res = Y
-        X = Xt + res                                                       # vit.py:215
-        CLS = CLS + cls_out
+            # ---- temporal half (vit.py:169-176)
+            U = layer_norm(X, sd[b + 'temporal_norm1.weight'], sd[b + 'temporal_norm1.bias'])
+            Ut = U.permute(0, 2, 1, 3).reshape(B * N, T, D)                   # '(b h w) t m'
+            R = attention(Ut, sd[b + 'temporal_attn.qkv.weight'], sd[b + 'temporal_attn.qkv.bias'],
+                          sd[b + 'temporal_attn.proj.weight'], sd[b + 'temporal_attn.proj.bias'], heads, ca)
+            s = dp(i, 'temporal', None)
+            if s is not None:
+                R = R * s.reshape(B * N, 1, 1)                                # DropPath before temporal_fc
+            R = R @ sd[b + 'temporal_fc.weight'].t() + sd[b + 'temporal_fc.bias']
+            Xt = X + R.reshape(B, N, T, D).permute(0, 2, 1, 3)
+            # ---- spatial half (vit.py:179-210)
+            use_cls = ca in (0, 1)
+            if use_cls:
+                Vin = torch.cat([CLS[:, None, None, :].expand(B, T, 1, D), Xt], dim=2)       # (B,T,S,D)
+            else:                                                              # ca>=2 or ca==-1 (vit.py:202-208)
+                Vin = Xt
+            S = Vin.shape[2]
+            Y = attention(layer_norm(Vin, sd[b + 'norm1.weight'], sd[b + 'norm1.bias']).reshape(B * T, S, D),
+                          sd[b + 'attn.qkv.weight'], sd[b + 'attn.qkv.bias'],
+                          sd[b + 'attn.proj.weight'], sd[b + 'attn.proj.bias'], heads, 0).reshape(B, T, S, D)
+            s = dp(i, 'spatial', None)
+            if s is not None:
+                Y = Y * s.reshape(B, T, 1, 1)
+            if use_cls:
+                cls_rows = Y[:, :, 0]                                          # (B, T, D)
+                cls_out = cls_rows.mean(dim=1) if ca == 0 else cls_rows[:, 0]  # vit.py:193-198
+                res = Y[:, :, 1:]
+            else:
+                cls_out = torch.zeros_like(CLS)                                # vit.py:205
+                res = Y
+            X = Xt + res                                                       # vit.py:215
+            CLS = CLS + cls_out
         # ---- MLP (vit.py:216, 55-61) over cls + all patch tokens
         allt = torch.cat([CLS[:, None, :], X.reshape(B, T * N, D)], dim=1)
         h = layer_norm(allt, sd[b + 'norm2.weight'], sd[b + 'norm2.bias'])

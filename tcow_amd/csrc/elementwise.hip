@@ -34,6 +34,19 @@ __global__ void im2col_kernel(int B, int T_, int H, int W, int P, int Crgb, int 
     }
 }
 
+// ------------------------------------------------------------------------------------------ clip gather (input pipeline)
+// out[c, t, y, x] = src[c, frame_idx[t], src_y[y], src_x[x]]: temporal sub-sampling, centre / random crop, flip and nearest resize of
+// data/augs.py:150-203 composed into three index tables (tcow_amd/augs.py); byte or 4-byte elements.
+template <typename T>
+__global__ void gather_frames_kernel(int C, int Tv, int H, int W, int Tc, int h, int w, const T* __restrict__ src, const int* __restrict__ frame_idx,
+                                     const int* __restrict__ src_y, const int* __restrict__ src_x, T* __restrict__ out) {
+    const long total = (long)C * Tc * h * w;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % w); long r = i / w; const int y = (int)(r % h); r /= h; const int t = (int)(r % Tc); const int c = (int)(r / Tc);
+        out[i] = src[(((size_t)c * Tv + frame_idx[t]) * H + src_y[y]) * W + src_x[x]];
+    }
+}
+
 // ------------------------------------------------------------------------------------------ embeddings
 // x[b,t,s,:] = (s == 0) ? cls + pos[0] : x + pos[s] + time[t]      (vision_tf.py:99-138; f32 residual stream)
 __global__ void embed_fwd_kernel(int B, int T_, int S, int D, float* __restrict__ x, const float* __restrict__ cls, const float* __restrict__ pos,
@@ -348,6 +361,17 @@ int tcow_im2col(void* stream, int dtype, int B, int T_, int H, int W, int P, con
     if (dtype == TCOW_BF16) hipLaunchKernelGGL(im2col_kernel<bf16_t>, dim3(gs_blocks(total)), dim3(256), 0, (hipStream_t)stream, B, T_, H, W, P, 3, 1, rgb, query, pretrained_norm, (bf16_t*)out);
     else if (dtype == TCOW_F32) hipLaunchKernelGGL(im2col_kernel<float>, dim3(gs_blocks(total)), dim3(256), 0, (hipStream_t)stream, B, T_, H, W, P, 3, 1, rgb, query, pretrained_norm, (float*)out);
     else { tcow_set_error("tcow_im2col: unknown dtype %d", dtype); return TCOW_ERR_INVALID_ARG; }
+    TCOW_CHECK_LAUNCH();
+    return TCOW_OK;
+}
+
+int tcow_gather_frames(void* stream, int elem_bytes, int C, int Tv, int H, int W, int Tc, int h, int w, const void* src, const int* frame_idx,
+                       const int* src_y, const int* src_x, void* out) {
+    TCOW_CHECK_ARG(C > 0 && Tv > 0 && H > 0 && W > 0 && Tc > 0 && h > 0 && w > 0 && src && frame_idx && src_y && src_x && out, "tcow_gather_frames: bad arguments");
+    TCOW_CHECK_ARG(elem_bytes == 1 || elem_bytes == 4, "tcow_gather_frames: elem_bytes must be 1 or 4 (got %d)", elem_bytes);
+    const long total = (long)C * Tc * h * w;
+    if (elem_bytes == 1) hipLaunchKernelGGL(gather_frames_kernel<uint8_t>, dim3(gs_blocks(total)), dim3(256), 0, (hipStream_t)stream, C, Tv, H, W, Tc, h, w, (const uint8_t*)src, frame_idx, src_y, src_x, (uint8_t*)out);
+    else hipLaunchKernelGGL(gather_frames_kernel<uint32_t>, dim3(gs_blocks(total)), dim3(256), 0, (hipStream_t)stream, C, Tv, H, W, Tc, h, w, (const uint32_t*)src, frame_idx, src_y, src_x, (uint32_t*)out);
     TCOW_CHECK_LAUNCH();
     return TCOW_OK;
 }

@@ -19,7 +19,27 @@ import torch
 from . import ops
 from .ops import ACT_GELU, ACT_GELU_DSAVE, ACT_MUL_AUX
 
-_BLOCK_PARAMS = 20   # parameters per block in QueryMaskTracker.param_list()
+def _layout(module):
+    """(parameters per block, offset of each sub-module's weight inside a block's slice of QueryMaskTracker.param_list(); bias = +1)."""
+    if module.attention_type == 'divided_space_time':
+        return 20, dict(tn=0, tqkv=2, tproj=4, tfc=6, n1=8, qkv=10, proj=12, n2=14, fc1=16, fc2=18)
+    return 12, dict(n1=0, qkv=2, proj=4, n2=6, fc1=8, fc2=10)          # joint_space_time block: norm1, attn, norm2, mlp (vit.py:135-153)
+
+
+def _joint_rows(module, g, dev):
+    """Row indices [B * (1 + T*N)] of the joint-attention sequences inside the [B*T*S] token matrix: per clip its cls row (frame 0's
+    slot 0) followed by every patch row.  The reference's sequence is (cls, patches in n-major order) (vision_tf.py:137); attention
+    without a mask is invariant to the order of its keys / queries, so the frame-major order of our layout is used as is."""
+    key = ('jrows', g['B'], str(dev))
+    idx = module._wcache.get(key)
+    if idx is None:
+        B, T, S = g['B'], g['T'], g['S']
+        r = torch.arange(B * T * S, device=dev).reshape(B, T * S)
+        keep = torch.ones(T * S, dtype=torch.bool, device=dev)
+        keep[torch.arange(1, T, device=dev) * S] = False                      # cls replicas of frames 1..T-1 take no part
+        idx = r[:, keep].reshape(-1).contiguous()
+        module._wcache[key] = idx
+    return idx
 
 
 def _w2d(p):
@@ -104,6 +124,21 @@ def _row_vectors(module, g, train):
     rates = torch.linspace(0, module.drop_path_rate, depth).tolist() if depth > 1 else [0.0]   # vit.py:272
     scales = []
     forced = module.forced_drop_masks
+    joint = module.attention_type != 'divided_space_time'
+    if joint:
+        # joint_space_time block (vit.py:161-162): both DropPath calls see x of shape (B, 1+N*T, D) -> one draw per sample each
+        for i in range(depth):
+            ent = {'t': None, 's': None, 'm': None}
+            for kind, name in (('s', 'spatial'), ('m', 'mlp')):
+                if forced is not None:
+                    if (i, name) in forced:
+                        keep, rate = forced[(i, name)]
+                        ent[kind] = (keep.to(dev, torch.float32).reshape(B) / (1.0 - rate))[:, None].expand(B, T * S).reshape(-1).contiguous()
+                elif train and rates[i] > 0.:
+                    keep = (torch.rand(B, device=dev) + (1.0 - rates[i])).floor_()
+                    ent[kind] = (keep / (1.0 - rates[i]))[:, None].expand(B, T * S).reshape(-1).contiguous()
+            scales.append(ent)
+        return mask0, scales
     if forced is None and train and max(rates) > 0.:
         # all DropPath draws of the step in one batch (vit_utils.py:150-152 per call: keep = floor(rand + 1 - r), x / (1 - r) * keep):
         # one rand and three broadcasts instead of ~15 tiny launches per block
@@ -220,43 +255,67 @@ def run_forward(module, rgb, qm, params, save):
     if save:
         sv.update(A_pe=A_pe, pos_idx=pos_idx, time_idx=time_idx)
 
+    BP, ix = _layout(module)
+    joint = module.attention_type != 'divided_space_time'
     shape_attn = ops.attn_shape(mode, B, T, S, D, heads, ca)
+    if joint:
+        jrows = _joint_rows(module, g, dev)
+        Lj = 1 + T * (S - 1)
+        shape_joint = ops.attn_shape(mode, B, 1, Lj, D, heads, 0)          # one sequence of 1 + N*T tokens per clip, cls included, no mask (vit.py:159-161)
     for i in range(module.network_depth):
-        q = params[5 + i * _BLOCK_PARAMS: 5 + (i + 1) * _BLOCK_PARAMS]
-        (tn_w, tn_b, tqkv_w, tqkv_b, tproj_w, tproj_b, tfc_w, tfc_b, n1_w, n1_b, qkv_w, qkv_b, proj_w, proj_b,
-         n2_w, n2_b, fc1_w, fc1_b, fc2_w, fc2_b) = [t.detach() for t in q]
+        q = params[5 + i * BP: 5 + (i + 1) * BP]
+        P_ = lambda name, k=0: q[ix[name] + k].detach()                     # weight (k = 0) / bias (k = 1) of a sub-module of this block
+        n1_w, n1_b, qkv_b, proj_b, n2_w, n2_b, fc1_w, fc1_b, fc2_b = P_('n1'), P_('n1', 1), P_('qkv', 1), P_('proj', 1), P_('n2'), P_('n2', 1), P_('fc1'), P_('fc1', 1), P_('fc2', 1)
         dp = dps[i]
         st = {}
         R0 = X
-        # temporal
-        U = E(M, D); mu0 = E(M, dtype=f32) if save else None; rs0 = E(M, dtype=f32) if save else None
-        ops.layernorm_fwd(mode, R0, tn_w, tn_b, U, mu0, rs0)
-        QKV = E(M, 3 * D)
-        ops.gemm_nt(mode, U, W(q[2]), QKV, bias=tqkv_b)
-        O = E(M, D); lse_t = E(M, heads, dtype=f32) if save else None
-        ops.attn_fwd(shape_attn, False, QKV, O, lse_t)
-        Pj = E(M, D)
-        ops.gemm_nt(mode, O, W(q[4]), Pj, bias=tproj_b, row_scale=dp['t'])
-        R1 = E(M, D, dtype=f32) if save else R0
-        ops.gemm_nt(mode, Pj, W(q[6]), R1, bias=tfc_b, row_scale=mask0, resid=R0)
-        if save:
-            st.update(R0=R0, mu0=mu0, rs0=rs0, U=U, QKV_t=QKV, O_t=O, lse_t=lse_t, Pj=Pj)
-        # spatial
-        V = E(M, D); mu1 = E(M, dtype=f32) if save else None; rs1 = E(M, dtype=f32) if save else None
-        ops.layernorm_fwd(mode, R1, n1_w, n1_b, V, mu1, rs1)
-        QKV2 = E(M, 3 * D)
-        ops.gemm_nt(mode, V, W(q[10]), QKV2, bias=qkv_b)
-        O2 = E(M, D); lse_s = E(M, heads, dtype=f32) if save else None
-        ops.attn_fwd(shape_attn, True, QKV2, O2, lse_s)
-        rs_s = dp['s']
-        if not use_cls:
-            rs_s = mask0 if rs_s is None else rs_s * mask0
-        R2 = E(M, D, dtype=f32) if save else R1
-        ops.gemm_nt(mode, O2, W(q[12]), R2, bias=proj_b, row_scale=rs_s, resid=R1)
-        if use_cls:
-            ops.cls_merge(R2, B, T, S, 1 if ca == 1 else 0)
-        if save:
-            st.update(R1=R1, mu1=mu1, rs1=rs1, V=V, QKV_s=QKV2, O_s=O2, lse_s=lse_s, rs_s=rs_s)
+        if joint:
+            # ---- joint space-time attention (vit.py:159-162): x = x + drop_path(attn(norm1(x))) over all 1 + N*T tokens of a clip
+            V = E(M, D); mu1 = E(M, dtype=f32) if save else None; rs1 = E(M, dtype=f32) if save else None
+            ops.layernorm_fwd(mode, R0, n1_w, n1_b, V, mu1, rs1)
+            QKV2 = E(M, 3 * D)
+            ops.gemm_nt(mode, V, W(q[ix['qkv']]), QKV2, bias=qkv_b)
+            QJ = QKV2.index_select(0, jrows)                                # compact (cls, patches) sequences: the kernels take contiguous ones
+            OJ = E(B * Lj, D); lse_s = E(B * Lj, heads, dtype=f32) if save else None
+            ops.attn_fwd(shape_joint, True, QJ, OJ, lse_s)
+            O2 = torch.zeros(M, D, dtype=dt, device=dev)
+            O2.index_copy_(0, jrows, OJ)                                    # (the unused cls replicas of frames 1.. get a zero attention output)
+            rs_s = dp['s']
+            R2 = E(M, D, dtype=f32) if save else R0
+            ops.gemm_nt(mode, O2, W(q[ix['proj']]), R2, bias=proj_b, row_scale=rs_s, resid=R0)
+            if save:
+                st.update(R1=R0, mu1=mu1, rs1=rs1, V=V, QKV_s=QJ, O_s=O2, OJ=OJ, lse_s=lse_s, rs_s=rs_s)
+        else:
+            tn_w, tn_b, tqkv_b, tproj_b, tfc_b = P_('tn'), P_('tn', 1), P_('tqkv', 1), P_('tproj', 1), P_('tfc', 1)
+            # temporal
+            U = E(M, D); mu0 = E(M, dtype=f32) if save else None; rs0 = E(M, dtype=f32) if save else None
+            ops.layernorm_fwd(mode, R0, tn_w, tn_b, U, mu0, rs0)
+            QKV = E(M, 3 * D)
+            ops.gemm_nt(mode, U, W(q[ix['tqkv']]), QKV, bias=tqkv_b)
+            O = E(M, D); lse_t = E(M, heads, dtype=f32) if save else None
+            ops.attn_fwd(shape_attn, False, QKV, O, lse_t)
+            Pj = E(M, D)
+            ops.gemm_nt(mode, O, W(q[ix['tproj']]), Pj, bias=tproj_b, row_scale=dp['t'])
+            R1 = E(M, D, dtype=f32) if save else R0
+            ops.gemm_nt(mode, Pj, W(q[ix['tfc']]), R1, bias=tfc_b, row_scale=mask0, resid=R0)
+            if save:
+                st.update(R0=R0, mu0=mu0, rs0=rs0, U=U, QKV_t=QKV, O_t=O, lse_t=lse_t, Pj=Pj)
+            # spatial
+            V = E(M, D); mu1 = E(M, dtype=f32) if save else None; rs1 = E(M, dtype=f32) if save else None
+            ops.layernorm_fwd(mode, R1, n1_w, n1_b, V, mu1, rs1)
+            QKV2 = E(M, 3 * D)
+            ops.gemm_nt(mode, V, W(q[ix['qkv']]), QKV2, bias=qkv_b)
+            O2 = E(M, D); lse_s = E(M, heads, dtype=f32) if save else None
+            ops.attn_fwd(shape_attn, True, QKV2, O2, lse_s)
+            rs_s = dp['s']
+            if not use_cls:
+                rs_s = mask0 if rs_s is None else rs_s * mask0
+            R2 = E(M, D, dtype=f32) if save else R1
+            ops.gemm_nt(mode, O2, W(q[ix['proj']]), R2, bias=proj_b, row_scale=rs_s, resid=R1)
+            if use_cls:
+                ops.cls_merge(R2, B, T, S, 1 if ca == 1 else 0)
+            if save:
+                st.update(R1=R1, mu1=mu1, rs1=rs1, V=V, QKV_s=QKV2, O_s=O2, lse_s=lse_s, rs_s=rs_s)
         # mlp
         Wn = E(M, D); mu2 = E(M, dtype=f32) if save else None; rs2 = E(M, dtype=f32) if save else None
         ops.layernorm_fwd(mode, R2, n2_w, n2_b, Wn, mu2, rs2)
@@ -264,16 +323,16 @@ def run_forward(module, rgb, qm, params, save):
         pre = E(M, Hd) if save else None
         H = E(M, Hd)
         # training saves GELU'(pre-activation) instead of the pre-activation: the backward is then one multiply per element
-        ops.gemm_nt(mode, Wn, W(q[16]), H, bias=fc1_b, act=ACT_GELU_DSAVE if save else ACT_GELU, aux=pre)
+        ops.gemm_nt(mode, Wn, W(q[ix['fc1']]), H, bias=fc1_b, act=ACT_GELU_DSAVE if save else ACT_GELU, aux=pre)
         R3 = E(M, D, dtype=f32) if save else R2
-        ops.gemm_nt(mode, H, W(q[18]), R3, bias=fc2_b, row_scale=dp['m'], resid=R2)
+        ops.gemm_nt(mode, H, W(q[ix['fc2']]), R3, bias=fc2_b, row_scale=dp['m'], resid=R2)
         if save:
             st.update(R2=R2, mu2=mu2, rs2=rs2, Wn=Wn, pre=pre, H=H)
             sv['blocks'].append(st)
         X = R3
 
     # ---- output heads
-    nb = 5 + module.network_depth * _BLOCK_PARAMS
+    nb = 5 + module.network_depth * BP
     norm_w, norm_b, head_w, head_b = params[nb], params[nb + 1], params[nb + 2], params[nb + 3]
     feat32 = X
     if module.norm_embeddings:                                            # vision_tf.py:152-153
@@ -356,7 +415,9 @@ def run_backward(module, sv, params, d_mask, d_flags):
         dW = galloc(idx_w); db = galloc(idx_w + 1)
         ops.gemm_tn(mode, dY, Xin, dW.reshape(dW.shape[0], -1), bias_grad=db)
 
-    nb = 5 + module.network_depth * _BLOCK_PARAMS
+    BP, ix = _layout(module)
+    joint = module.attention_type != 'divided_space_time'
+    nb = 5 + module.network_depth * BP
     Co = module.output_channels
     have_flags = module.flag_channels > 0 and d_flags is not None and d_flags.numel() > 0
     head_idx = ([nb, nb + 1] if module.norm_embeddings else []) + [nb + 2, nb + 3] + ([nb + 4, nb + 5] if have_flags else [])
@@ -391,15 +452,20 @@ def run_backward(module, sv, params, d_mask, d_flags):
         module.grad_hook('head', head_flat)
 
     shape_attn = ops.attn_shape(mode, B, T, S, D, heads, ca)
+    if joint:
+        jrows = _joint_rows(module, g, dev)
+        Lj = 1 + T * (S - 1)
+        shape_joint = ops.attn_shape(mode, B, 1, Lj, D, heads, 0)
     dR3 = dX
     G3_next = None
     for i in reversed(range(module.network_depth)):
-        o = 5 + i * _BLOCK_PARAMS
-        q = params[o: o + _BLOCK_PARAMS]
+        o = 5 + i * BP
+        q = params[o: o + BP]
         st = sv['blocks'][i]
         dp = sv['dps'][i]
-        Hd = q[16].shape[0]
-        blk_flat = bucket(range(o, o + _BLOCK_PARAMS))
+        Hd = q[ix['fc1']].shape[0]
+        blk_flat = bucket(range(o, o + BP))
+        next_scale = (sv['dps'][i - 1]['m'] if i > 0 else mask0)      # row scale of the operand the block below (or the patch embedding) consumes
         # ---- mlp
         if G3_next is not None:
             G3 = G3_next                       # produced by the LayerNorm backward of the block above (fused cast)
@@ -407,48 +473,59 @@ def run_backward(module, sv, params, d_mask, d_flags):
             G3 = E(M, D)
             ops.scale_cast(mode, dR3, dp['m'], G3)
         dpre = E(M, Hd)
-        ops.gemm_nt(mode, G3, Wt(q[18]), dpre, act=ACT_MUL_AUX, aux=st['pre'])
-        linear_bwd(o + 18, G3, st['H'])
+        ops.gemm_nt(mode, G3, Wt(q[ix['fc2']]), dpre, act=ACT_MUL_AUX, aux=st['pre'])
+        linear_bwd(o + ix['fc2'], G3, st['H'])
         dWn = E(M, D)
-        ops.gemm_nt(mode, dpre, Wt(q[16]), dWn)
-        linear_bwd(o + 16, dpre, st['Wn'])
+        ops.gemm_nt(mode, dpre, Wt(q[ix['fc1']]), dWn)
+        linear_bwd(o + ix['fc1'], dpre, st['Wn'])
         dR2 = E(M, D, dtype=f32)
-        ops.layernorm_bwd(mode, dWn, st['R2'], st['mu2'], st['rs2'], q[14].detach(), dR3, dR2, galloc(o + 14), galloc(o + 15))
+        ops.layernorm_bwd(mode, dWn, st['R2'], st['mu2'], st['rs2'], q[ix['n2']].detach(), dR3, dR2, galloc(o + ix['n2']), galloc(o + ix['n2'] + 1))
         del G3, dpre, dWn
-        # ---- spatial
-        if use_cls:
+        # ---- spatial / joint attention
+        if use_cls and not joint:
             ops.cls_merge(dR2, B, T, S, 1 if ca == 1 else 0, backward=True)
         G2 = E(M, D)
         ops.scale_cast(mode, dR2, st['rs_s'], G2)
         dO2 = E(M, D)
-        ops.gemm_nt(mode, G2, Wt(q[12]), dO2)
-        linear_bwd(o + 12, G2, st['O_s'])
-        dQKV2 = E(M, 3 * D)
-        ops.attn_bwd(shape_attn, True, st['QKV_s'], st['O_s'], dO2, st['lse_s'], dQKV2)
+        ops.gemm_nt(mode, G2, Wt(q[ix['proj']]), dO2)
+        linear_bwd(o + ix['proj'], G2, st['O_s'])
+        if joint:
+            dQJ = E(B * Lj, 3 * D)
+            ops.attn_bwd(shape_joint, True, st['QKV_s'], st['OJ'], dO2.index_select(0, jrows), st['lse_s'], dQJ)
+            dQKV2 = torch.zeros(M, 3 * D, dtype=dt, device=dev)       # the unused cls replicas receive no gradient
+            dQKV2.index_copy_(0, jrows, dQJ)
+        else:
+            dQKV2 = E(M, 3 * D)
+            ops.attn_bwd(shape_attn, True, st['QKV_s'], st['O_s'], dO2, st['lse_s'], dQKV2)
         dV = E(M, D)
-        ops.gemm_nt(mode, dQKV2, Wt(q[10]), dV)
-        linear_bwd(o + 10, dQKV2, st['V'])
+        ops.gemm_nt(mode, dQKV2, Wt(q[ix['qkv']]), dV)
+        linear_bwd(o + ix['qkv'], dQKV2, st['V'])
         dR1 = E(M, D, dtype=f32)
-        G1 = E(M, D)                           # bf16(dR1 * mask0), written by the same LayerNorm backward pass
-        ops.layernorm_bwd(mode, dV, st['R1'], st['mu1'], st['rs1'], q[8].detach(), dR2, dR1, galloc(o + 8), galloc(o + 9), dx_cast=G1, cast_scale=mask0)
+        G1 = E(M, D)                           # bf16(dR1 * row scale), written by the same LayerNorm backward pass
+        ops.layernorm_bwd(mode, dV, st['R1'], st['mu1'], st['rs1'], q[ix['n1']].detach(), dR2, dR1, galloc(o + ix['n1']), galloc(o + ix['n1'] + 1), dx_cast=G1,
+                          cast_scale=(next_scale if joint else mask0))
         del G2, dO2, dQKV2, dV
-        # ---- temporal
-        dPj = E(M, D)
-        ops.gemm_nt(mode, G1, Wt(q[6]), dPj, row_scale=dp['t'])
-        linear_bwd(o + 6, G1, st['Pj'])
-        dO = E(M, D)
-        ops.gemm_nt(mode, dPj, Wt(q[4]), dO)
-        linear_bwd(o + 4, dPj, st['O_t'])
-        dQKV = E(M, 3 * D)
-        ops.attn_bwd(shape_attn, False, st['QKV_t'], st['O_t'], dO, st['lse_t'], dQKV)
-        dU = E(M, D)
-        ops.gemm_nt(mode, dQKV, Wt(q[2]), dU)
-        linear_bwd(o + 2, dQKV, st['U'])
-        dR0 = E(M, D, dtype=f32)
-        G3_next = E(M, D)                      # operand of the next (lower) block's MLP backward, or of the patch-embed weight gradient
-        ops.layernorm_bwd(mode, dU, st['R0'], st['mu0'], st['rs0'], q[0].detach(), dR1, dR0, galloc(o), galloc(o + 1),
-                          dx_cast=G3_next, cast_scale=(sv['dps'][i - 1]['m'] if i > 0 else mask0))
-        dR3 = dR0
+        if joint:
+            G3_next = G1                       # a joint block has no temporal half: its input gradient is complete here
+            dR3 = dR1
+        else:
+            # ---- temporal
+            dPj = E(M, D)
+            ops.gemm_nt(mode, G1, Wt(q[ix['tfc']]), dPj, row_scale=dp['t'])
+            linear_bwd(o + ix['tfc'], G1, st['Pj'])
+            dO = E(M, D)
+            ops.gemm_nt(mode, dPj, Wt(q[ix['tproj']]), dO)
+            linear_bwd(o + ix['tproj'], dPj, st['O_t'])
+            dQKV = E(M, 3 * D)
+            ops.attn_bwd(shape_attn, False, st['QKV_t'], st['O_t'], dO, st['lse_t'], dQKV)
+            dU = E(M, D)
+            ops.gemm_nt(mode, dQKV, Wt(q[ix['tqkv']]), dU)
+            linear_bwd(o + ix['tqkv'], dQKV, st['U'])
+            dR0 = E(M, D, dtype=f32)
+            G3_next = E(M, D)                  # operand of the next (lower) block's MLP backward, or of the patch-embed weight gradient
+            ops.layernorm_bwd(mode, dU, st['R0'], st['mu0'], st['rs0'], q[ix['tn']].detach(), dR1, dR0, galloc(o + ix['tn']), galloc(o + ix['tn'] + 1),
+                              dx_cast=G3_next, cast_scale=next_scale)
+            dR3 = dR0
         sv['blocks'][i] = None   # free this block's activations
         if module.grad_hook is not None:
             module.grad_hook(i, blk_flat)

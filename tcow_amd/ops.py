@@ -114,6 +114,21 @@ def im2col(mode, rgb, query, P, pretrained_norm, out):
     return out
 
 
+def gather_frames(frames, frame_idx, src_y, src_x):
+    """frames (C,Tv,H,W) uint8 / 4-byte CUDA tensor, int32 CUDA index tables -> (C,Tc,h,w) (see tcow_gather_frames)."""
+    _need_cuda(frames, frame_idx, src_y, src_x)
+    if frames.element_size() not in (1, 4) or not frames.is_contiguous():
+        raise L.TcowError('gather_frames: contiguous tensor of 1- or 4-byte elements expected')
+    for t in (frame_idx, src_y, src_x):
+        if t.dtype != torch.int32 or not t.is_contiguous():
+            raise L.TcowError('gather_frames: index tables must be contiguous int32 tensors')
+    C, Tv, H, W = frames.shape
+    out = torch.empty(C, frame_idx.numel(), src_y.numel(), src_x.numel(), dtype=frames.dtype, device=frames.device)
+    L.check(L.lib().tcow_gather_frames(_stream(), frames.element_size(), C, Tv, H, W, frame_idx.numel(), src_y.numel(), src_x.numel(), frames.data_ptr(),
+                                       frame_idx.data_ptr(), src_y.data_ptr(), src_x.data_ptr(), out.data_ptr()), 'tcow_gather_frames')
+    return out
+
+
 def im2col_channels(mode, src, P, normalise, out):
     """src (B,C,T,H,W) f32 -> out [B*T*S, C*P*P] (see tcow_im2col_channels)."""
     B, C, T, H, W = src.shape

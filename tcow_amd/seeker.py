@@ -47,14 +47,15 @@ class _Mlp(nn.Module):                           # vit.py:45-53
         self.fc2 = nn.Linear(hidden, dim)
 
 
-class _Block(nn.Module):                         # vit.py:126-153 (divided_space_time)
-    def __init__(self, dim, mlp_ratio):
+class _Block(nn.Module):                         # vit.py:126-153
+    def __init__(self, dim, mlp_ratio, divided=True):
         super().__init__()
         self.norm1 = nn.LayerNorm(dim, eps=1e-6)
         self.attn = _Attention(dim)
-        self.temporal_norm1 = nn.LayerNorm(dim, eps=1e-6)
-        self.temporal_attn = _Attention(dim)
-        self.temporal_fc = nn.Linear(dim, dim)
+        if divided:                              # temporal parameters exist only for divided_space_time (vit.py:140-146)
+            self.temporal_norm1 = nn.LayerNorm(dim, eps=1e-6)
+            self.temporal_attn = _Attention(dim)
+            self.temporal_fc = nn.Linear(dim, dim)
         self.norm2 = nn.LayerNorm(dim, eps=1e-6)
         self.mlp = _Mlp(dim, int(dim * mlp_ratio))
 
@@ -66,7 +67,7 @@ class _PatchEmbed(nn.Module):                    # vit.py:220-233
 
 
 class _VisionTransformer(nn.Module):             # vit.py:244-306
-    def __init__(self, img_size, patch, in_chans, dim, depth, mlp_ratio, num_frames):
+    def __init__(self, img_size, patch, in_chans, dim, depth, mlp_ratio, num_frames, divided=True):
         super().__init__()
         self.embed_dim = dim
         self.patch_embed = _PatchEmbed(patch, in_chans, dim)
@@ -74,7 +75,7 @@ class _VisionTransformer(nn.Module):             # vit.py:244-306
         self.cls_token = nn.Parameter(torch.zeros(1, 1, dim))
         self.pos_embed = nn.Parameter(torch.zeros(1, n_patches + 1, dim))
         self.time_embed = nn.Parameter(torch.zeros(1, num_frames, dim))      # stays zero at init (vit.py:268)
-        self.blocks = nn.ModuleList([_Block(dim, mlp_ratio) for _ in range(depth)])
+        self.blocks = nn.ModuleList([_Block(dim, mlp_ratio, divided) for _ in range(depth)])
         self.norm = nn.LayerNorm(dim, eps=1e-6)
         _trunc_normal_(self.pos_embed)
         _trunc_normal_(self.cls_token)
@@ -86,7 +87,7 @@ class _VisionTransformer(nn.Module):             # vit.py:244-306
                 nn.init.constant_(m.bias, 0)
                 nn.init.constant_(m.weight, 1.0)
         # vit.py:289-297: the loop counts the ModuleList itself as "Block 0", so every real block is zeroed.
-        for blk in self.blocks:
+        for blk in self.blocks if divided else []:
             nn.init.constant_(blk.temporal_fc.weight, 0)
             nn.init.constant_(blk.temporal_fc.bias, 0)
 
@@ -144,9 +145,11 @@ class QueryMaskTracker(nn.Module):
             logger.info(f'(QueryMaskTracker) tracker_pretrained: {self.tracker_pretrained} '
                         f'pretrained_path: {self.pretrained_path}')
 
-        if attention_type != 'divided_space_time':
-            raise TcowError(f"attention_type='{attention_type}' is not on the MI355X hot path "
-                            "(only divided_space_time; vit.py:159-163 is out of scope)")
+        assert attention_type in ['divided_space_time', 'space_only', 'joint_space_time']      # vit.py:133
+        if attention_type == 'space_only':
+            # the reference cannot run this setting either: DenseTimeSformer.forward reads model.time_embed (vision_tf.py:127-132), which a
+            # space_only VisionTransformer does not create (vit.py:263-265) -> AttributeError on the first forward
+            raise TcowError("attention_type='space_only' is not runnable through Seeker (vision_tf.py:127 needs time_embed, vit.py:263-265)")
         if query_channels != 1:
             raise TcowError('query_channels must be 1 (mask_tracker.py:105)')
         if embed_dim is None or num_heads is None:
@@ -165,7 +168,7 @@ class QueryMaskTracker(nn.Module):
 
         self.tracker_backbone = _Backbone(img_size=(frame_height, frame_width), patch=patch_size,
                                           in_chans=self.input_channels, dim=embed_dim, depth=network_depth,
-                                          mlp_ratio=4, num_frames=num_total_frames)
+                                          mlp_ratio=4, num_frames=num_total_frames, divided=(attention_type == 'divided_space_time'))
         self.use_feature_dim = embed_dim
         self.tracker_post_linear = nn.Linear(embed_dim, output_channels * patch_size * patch_size)
         if flag_channels > 0:
@@ -221,10 +224,11 @@ class QueryMaskTracker(nn.Module):
         """Fixed order of the parameters the autograd.Function sees."""
         v = self.vit
         ps = [v.cls_token, v.pos_embed, v.time_embed, v.patch_embed.proj.weight, v.patch_embed.proj.bias]
-        for b in v.blocks:
-            ps += [b.temporal_norm1.weight, b.temporal_norm1.bias, b.temporal_attn.qkv.weight, b.temporal_attn.qkv.bias,
-                   b.temporal_attn.proj.weight, b.temporal_attn.proj.bias, b.temporal_fc.weight, b.temporal_fc.bias,
-                   b.norm1.weight, b.norm1.bias, b.attn.qkv.weight, b.attn.qkv.bias, b.attn.proj.weight, b.attn.proj.bias,
+        for b in v.blocks:                   # (order = engine._layout)
+            if self.attention_type == 'divided_space_time':
+                ps += [b.temporal_norm1.weight, b.temporal_norm1.bias, b.temporal_attn.qkv.weight, b.temporal_attn.qkv.bias,
+                       b.temporal_attn.proj.weight, b.temporal_attn.proj.bias, b.temporal_fc.weight, b.temporal_fc.bias]
+            ps += [b.norm1.weight, b.norm1.bias, b.attn.qkv.weight, b.attn.qkv.bias, b.attn.proj.weight, b.attn.proj.bias,
                    b.norm2.weight, b.norm2.bias, b.mlp.fc1.weight, b.mlp.fc1.bias, b.mlp.fc2.weight, b.mlp.fc2.bias]
         ps += [v.norm.weight, v.norm.bias, self.tracker_post_linear.weight, self.tracker_post_linear.bias]
         if self.flag_channels > 0:
@@ -242,6 +246,7 @@ class QueryMaskTracker(nn.Module):
         assert query_mask.shape[0] % B == 0 and query_mask.shape[2:] == input_frames.shape[2:]
         assert T == self.num_total_frames                                 # vision_tf.py:96
         assert Hf == self.frame_height and Wf == self.frame_width         # vision_tf.py:97 (W' check)
+        assert self.attention_type == 'divided_space_time' or self.causal_attention == 0   # vit.py:160
         if not input_frames.is_cuda:
             raise TcowError('Seeker (tcow_amd) runs on the GPU only: move inputs and module to cuda')
         if query_mask.device != input_frames.device or self.vit.pos_embed.device != input_frames.device:

@@ -29,14 +29,14 @@ def _trunc_normal(rng, shape, std):
 def seeker_config(num_total_frames=30, frame_height=240, frame_width=320, patch_size=16, embed_dim=768,
                   depth=12, num_heads=12, causal_attention=1, norm_embeddings=False, query_channels=1,
                   output_channels=3, flag_channels=3, track_map_stride=4, track_map_resize='bilinear',
-                  pretrained_norm=False, mlp_ratio=4):
+                  pretrained_norm=False, mlp_ratio=4, attention_type='divided_space_time'):
     """Plain dict describing one Seeker geometry (defaults = BASELINE.json configs[1])."""
     return dict(num_total_frames=num_total_frames, frame_height=frame_height, frame_width=frame_width,
                 patch_size=patch_size, embed_dim=embed_dim, depth=depth, num_heads=num_heads,
                 causal_attention=int(causal_attention), norm_embeddings=bool(norm_embeddings),
                 query_channels=query_channels, output_channels=output_channels, flag_channels=flag_channels,
                 track_map_stride=track_map_stride, track_map_resize=track_map_resize,
-                pretrained_norm=bool(pretrained_norm), mlp_ratio=mlp_ratio)
+                pretrained_norm=bool(pretrained_norm), mlp_ratio=mlp_ratio, attention_type=attention_type)
 
 
 def state_dict_shapes(cfg):
@@ -55,10 +55,11 @@ def state_dict_shapes(cfg):
         s[b + 'norm1.weight'] = (D,); s[b + 'norm1.bias'] = (D,)
         s[b + 'attn.qkv.weight'] = (3 * D, D); s[b + 'attn.qkv.bias'] = (3 * D,)
         s[b + 'attn.proj.weight'] = (D, D); s[b + 'attn.proj.bias'] = (D,)
-        s[b + 'temporal_norm1.weight'] = (D,); s[b + 'temporal_norm1.bias'] = (D,)
-        s[b + 'temporal_attn.qkv.weight'] = (3 * D, D); s[b + 'temporal_attn.qkv.bias'] = (3 * D,)
-        s[b + 'temporal_attn.proj.weight'] = (D, D); s[b + 'temporal_attn.proj.bias'] = (D,)
-        s[b + 'temporal_fc.weight'] = (D, D); s[b + 'temporal_fc.bias'] = (D,)
+        if cfg.get('attention_type', 'divided_space_time') == 'divided_space_time':      # vit.py:140-146
+            s[b + 'temporal_norm1.weight'] = (D,); s[b + 'temporal_norm1.bias'] = (D,)
+            s[b + 'temporal_attn.qkv.weight'] = (3 * D, D); s[b + 'temporal_attn.qkv.bias'] = (3 * D,)
+            s[b + 'temporal_attn.proj.weight'] = (D, D); s[b + 'temporal_attn.proj.bias'] = (D,)
+            s[b + 'temporal_fc.weight'] = (D, D); s[b + 'temporal_fc.bias'] = (D,)
         s[b + 'norm2.weight'] = (D,); s[b + 'norm2.bias'] = (D,)
         s[b + 'mlp.fc1.weight'] = (Hd, D); s[b + 'mlp.fc1.bias'] = (Hd,)
         s[b + 'mlp.fc2.weight'] = (D, Hd); s[b + 'mlp.fc2.bias'] = (D,)

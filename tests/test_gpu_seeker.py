@@ -323,6 +323,48 @@ def test_shared_rgb_queries_equal_expanded_batch(cuda, precision, tol, gtol):
     assert float((a[0][0] - a[0][1]).abs().max()) > 0                      # different queries of one clip -> different masks
 
 
+@pytest.mark.parametrize('precision,tol,gtol', [('fp32', FP32_TOL, 3e-4), ('bf16', None, 4e-2)])
+def test_joint_space_time_vs_reference_golden(cuda, precision, tol, gtol):
+    """A0 (vit.py:159-163, args.py:154-156): attention_type='joint_space_time' -- one attention over (cls, all N*T patch tokens) per clip
+    through the streaming MFMA kernels -- forward, gradients, and train-mode DropPath (one draw per sample) against the reference."""
+    from oracle.seeker_oracle import grad_sample
+    from tcow_amd.seeker import Seeker
+    meta, g = load_golden('g14_joint')
+    cfg, sd, rgb, qm = golden_inputs(meta)
+    names = [str(n) for n in g['param_names']]
+    for mode in ('eval', 'train'):
+        net = Seeker(None, num_total_frames=cfg['num_total_frames'], frame_height=cfg['frame_height'], frame_width=cfg['frame_width'], causal_attention=0,
+                     attention_type='joint_space_time', drop_path_rate=meta['drop_path_rate'], network_depth=cfg['depth'], embed_dim=cfg['embed_dim'],
+                     num_heads=cfg['num_heads'], precision=precision)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+        net = net.cuda().train()
+        net.seeker.forced_drop_masks = _droppath_masks(g) if mode == 'train' else {}     # {} = train graph with every DropPath forced open
+        om, fl = net(rgb.cuda(), qm.cuda())
+        d = np.abs(om.detach().cpu().numpy() - g[f'{mode}::output_mask']).max(); df = np.abs(fl.detach().cpu().numpy() - g[f'{mode}::output_flags']).max()
+        if precision == 'fp32':
+            assert d < tol and df < tol, (mode, d, df)
+        else:
+            assert d < bf16_tol(g[f'{mode}::output_mask']) and df < bf16_tol(g[f'{mode}::output_flags']) + 5e-3
+        Gm = torch.from_numpy(synth._rng(meta['seed'], 'g14_mask').standard_normal(size=tuple(om.shape), dtype=np.float32)).cuda()
+        Gf = torch.from_numpy(synth._rng(meta['seed'], 'g14_flags').standard_normal(size=tuple(fl.shape), dtype=np.float32)).cuda()
+        ((om * Gm).sum() + (fl * Gf).sum()).backward()
+        named = dict(net.named_parameters())
+        for k, ref in g.items():
+            if k.startswith(f'{mode}::grad::'):
+                got = named[k.split('::', 2)[2]].grad.cpu().numpy()
+            elif k.startswith(f'{mode}::gsample::'):
+                got = grad_sample(named[k.split('::', 2)[2]].grad.cpu().numpy())
+            else:
+                continue
+            assert np.abs(got - ref).max() <= gtol * np.abs(ref).max() + 1e-7, (mode, k)
+        for name, n in zip(names, g[f'{mode}::grad_norms']):
+            if n >= 0:
+                assert abs(float(named[name].grad.norm()) - n) <= gtol * n + 1e-7, (mode, name)
+    from tcow_amd._lib import TcowError
+    with pytest.raises(TcowError):
+        Seeker(None, attention_type='space_only')                          # not runnable in the reference either (vision_tf.py:127 vs vit.py:263-265)
+
+
 def test_full_size_properties(cuda):
     """BASELINE configs[1] geometry, bf16: determinism, batch independence (the Qs queries of pipeline.py:134 batched as
     B=3 equal three B=1 calls), inputs untouched, eval == train when DropPath is off."""

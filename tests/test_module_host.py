@@ -35,7 +35,11 @@ def test_constructor_contract():
     with pytest.raises(AssertionError):
         Seeker(None, frame_height=100, frame_width=64)                                                   # mask_tracker.py:89
     with pytest.raises(TcowError):
-        Seeker(None, attention_type='joint_space_time')
+        Seeker(None, attention_type='space_only')                                                        # vision_tf.py:127 needs time_embed, vit.py:263-265 does not create it
+    with pytest.raises(AssertionError):
+        Seeker(None, attention_type='nope')                                                              # vit.py:133
+    joint = Seeker(None, num_total_frames=4, frame_height=32, frame_width=32, attention_type='joint_space_time', causal_attention=0)
+    assert not any('temporal' in k for k in joint.state_dict()) and len(joint.state_dict()) == 155           # vit.py:140-146: no temporal parameters
     with pytest.raises(TcowError):
         Seeker(None, tracker_pretrained='1')          # ImageNet weights need the network (vit.py:35)
 

@@ -130,3 +130,24 @@ def test_droppath_row_semantics_match_reference_train_mode(name):
             assert np.abs(tsd[k[6:]].grad.numpy() - ref).max() <= 2e-4 * np.abs(ref).max() + 1e-7, k
     no_drop, _ = so.seeker_forward(tsd, cfg, rgb, qm)
     assert float((no_drop - om).abs().max()) > 1e-3                       # the masks really dropped something
+
+
+def test_joint_space_time_matches_reference():
+    """A0 (vit.py:159-163): joint attention over (cls, all N*T patches), eval forward + train-mode DropPath (per sample) + gradients."""
+    meta, g = load_golden('g14_joint')
+    cfg, sd, rgb, qm = golden_inputs(meta)
+    assert len(sd) == 5 + 12 * cfg['depth'] + 6                           # no temporal_* keys in this mode
+    for mode in ('eval', 'train'):
+        tsd = so.to_torch_state_dict(sd)
+        for v in tsd.values():
+            v.requires_grad_(True)
+        om, fl = so.seeker_forward(tsd, cfg, rgb, qm, drop_masks=droppath_masks(g) if mode == 'train' else None)
+        assert np.abs(om.detach().numpy() - g[f'{mode}::output_mask']).max() < TOL and np.abs(fl.detach().numpy() - g[f'{mode}::output_flags']).max() < TOL
+        Gm = torch.from_numpy(synth._rng(meta['seed'], 'g14_mask').standard_normal(size=tuple(om.shape), dtype=np.float32))
+        Gf = torch.from_numpy(synth._rng(meta['seed'], 'g14_flags').standard_normal(size=tuple(fl.shape), dtype=np.float32))
+        ((om * Gm).sum() + (fl * Gf).sum()).backward()
+        for k, ref in g.items():
+            if k.startswith(f'{mode}::grad::'):
+                assert np.abs(tsd[k.split('::', 2)[2]].grad.numpy() - ref).max() <= 2e-4 * np.abs(ref).max() + 1e-7, k
+            elif k.startswith(f'{mode}::gsample::'):
+                assert np.abs(so.grad_sample(tsd[k.split('::', 2)[2]].grad.numpy()) - ref).max() <= 2e-4 * np.abs(ref).max() + 1e-7, k
