@@ -1,8 +1,10 @@
 """GPU: the drop-in Seeker on libtcow_hip against the golden vectors of the real reference, and against the properties
 the domain offers at full size.  Stated tolerances (north_star: mask-logit max|d| < 1e-3 vs the fp32 reference):
-  fp32 mode : max|d| < 1e-4 asserted (measured ~1e-6) -- the parity mode.
-  bf16 mode : max|d| < 0.08 * logit_std + 1e-3 asserted (bf16 operands cannot reach 1e-3: the reference itself under
-              bf16 autocast deviates by 8e-3 at logit std 0.137)."""
+  fp32 mode : max|d| < 1e-5 asserted (measured 7e-8 ... 3e-6 over all goldens) -- the parity mode, 100x inside the north-star bound.
+  bf16 mode : max|d| < 0.05 x the golden's logit std asserted = 1.5 x the worst measured ratio (0.013 ... 0.034 x std over 13 goldens,
+              tools/dev_bf16_ratios.py; 3.4e-3 absolute at BASELINE configs[1], logit std 0.154); flags < 0.012 x their std (measured
+              <= 0.0077).  bf16 operands cannot reach 1e-3 at these logit scales: profiles/r02_bf16_error_budget.txt (weight copies alone
+              2.7e-3; every activation class 0.2 ... 2.0e-3); the reference itself under bf16 autocast deviates by 8e-3."""
 import numpy as np
 import pytest
 import torch
@@ -13,11 +15,15 @@ from tcow_amd import synth
 
 pytestmark = pytest.mark.gpu
 
-FP32_TOL = 1e-4
+FP32_TOL = 1e-5
 
 
 def bf16_tol(ref):
-    return 0.08 * float(np.std(ref)) + 1e-3
+    return 0.05 * float(np.std(ref))
+
+
+def bf16_flags_tol(ref):
+    return 0.012 * float(np.std(ref))
 
 
 def _run(name, precision, grad=False):
@@ -43,7 +49,7 @@ def test_forward_vs_reference_golden(cuda, name, precision):
     if precision == 'fp32':
         assert d < FP32_TOL and df < FP32_TOL
     else:
-        assert d < bf16_tol(g['output_mask']) and df < bf16_tol(g['output_flags']) + 5e-3
+        assert d < bf16_tol(g['output_mask']) and df < bf16_flags_tol(g['output_flags'])
 
 
 @pytest.mark.parametrize('precision,tol', [('fp32', 2e-4), ('bf16', 4e-2)])
@@ -75,8 +81,7 @@ def test_large_geometries_vs_reference_golden(cuda, name, precision):
         assert d < FP32_TOL and df < FP32_TOL and np.abs(fmax - g['frame_absmax']).max() < FP32_TOL
         assert np.abs(fsum - g['frame_sum']).max() < 0.5
     else:
-        tol = 0.08 * float(g['logit_std']) + 1e-3
-        assert d < tol and df < tol + 5e-3
+        assert d < 0.05 * float(g['logit_std']) and df < bf16_flags_tol(g['output_flags'])
 
 
 @pytest.mark.parametrize('precision', ['fp32', 'bf16'])
@@ -120,7 +125,7 @@ def test_droppath_forced_masks_vs_reference_train_mode(cuda, name, precision, to
     if precision == 'fp32':
         assert d < tol and df < tol
     else:
-        assert d < bf16_tol(g['output_mask']) and df < bf16_tol(g['output_flags']) + 5e-3
+        assert d < bf16_tol(g['output_mask']) and df < bf16_flags_tol(g['output_flags'])
     Gm = torch.from_numpy(synth._rng(meta['seed'], 'g12_mask').standard_normal(size=tuple(om.shape), dtype=np.float32)).cuda()
     Gf = torch.from_numpy(synth._rng(meta['seed'], 'g12_flags').standard_normal(size=tuple(fl.shape), dtype=np.float32)).cuda()
     ((om * Gm).sum() + (fl * Gf).sum()).backward()
@@ -159,7 +164,7 @@ def test_full_size_gradients_vs_reference_golden(cuda, precision, tol):
     if precision == 'fp32':
         assert d < FP32_TOL and df < FP32_TOL
     else:
-        assert d < 0.08 * float(g['logit_std']) + 1e-3
+        assert d < 0.05 * float(g['logit_std'])
     Gm = torch.cat([torch.from_numpy(synth._rng(meta['seed'], f'g7_mask_{q}').standard_normal(size=(1,) + tuple(om.shape[1:]), dtype=np.float32)) for q in range(Qs)]).cuda()
     Gf = torch.cat([torch.from_numpy(synth._rng(meta['seed'], f'g7_flags_{q}').standard_normal(size=(1,) + tuple(fl.shape[1:]), dtype=np.float32)) for q in range(Qs)]).cuda()
     ((om * Gm).sum() * meta['mask_probe_scale'] + (fl * Gf).sum()).backward()
@@ -197,8 +202,7 @@ def test_config3_long_clip_vs_reference_golden(cuda, precision):
     if precision == 'fp32':
         assert d < FP32_TOL and df < FP32_TOL and np.abs(fmax - g['frame_absmax']).max() < FP32_TOL
     else:
-        tol = 0.08 * float(g['logit_std']) + 1e-3
-        assert d < tol and df < tol + 5e-3
+        assert d < 0.05 * float(g['logit_std']) and df < bf16_flags_tol(g['output_flags'])
     assert abs(float((om > 0).float().mean()) - float(g['positive_frac'])) < (1e-5 if precision == 'fp32' else 5e-3)
 
 
@@ -221,11 +225,12 @@ def test_config4_batched_eval_vs_reference_golden(cuda, precision):
         mr = pipe.forward_plugin_items(items)
     om, fl = mr['output_mask'], mr['output_flags']
     assert tuple(om.shape) == (16, 3, 30, 240, 320)
-    logit_tol = FP32_TOL if precision == 'fp32' else 2e-2
     for i in g['picked'].tolist():
         pooled, fsum, _ = summarise(om[i:i + 1].cpu())
+        logit_tol = FP32_TOL if precision == 'fp32' else bf16_tol(g[f'item{i}::pooled'])
+        flag_tol = FP32_TOL if precision == 'fp32' else bf16_flags_tol(g[f'item{i}::output_flags'])
         assert np.abs(pooled[::4] - g[f'item{i}::pooled']).max() < logit_tol, i
-        assert np.abs(fl[i:i + 1].cpu().numpy() - g[f'item{i}::output_flags']).max() < logit_tol + (0 if precision == 'fp32' else 5e-3), i
+        assert np.abs(fl[i:i + 1].cpu().numpy() - g[f'item{i}::output_flags']).max() < flag_tol, i
         m = calculate_metrics_mask_track(om[i:i + 1], mr['target_mask'][i:i + 1], plugin=True)
         for k in m:
             ref = g[f'item{i}::metric::{k}']
@@ -257,7 +262,7 @@ def test_depth_18_and_24_vs_reference_golden(cuda, name, precision):
     if precision == 'fp32':
         assert d < FP32_TOL and df < FP32_TOL
     else:
-        assert d < bf16_tol(g['output_mask']) and df < bf16_tol(g['output_flags']) + 5e-3
+        assert d < bf16_tol(g['output_mask']) and df < bf16_flags_tol(g['output_flags'])
 
 
 @pytest.mark.parametrize('precision', ['fp32', 'bf16'])
@@ -292,7 +297,7 @@ def test_pretrained_checkpoint_forward_vs_reference_golden(cuda, precision, tmp_
     if precision == 'fp32':
         assert d < FP32_TOL and df < FP32_TOL
     else:
-        assert d < bf16_tol(g['output_mask']) and df < bf16_tol(g['output_flags']) + 5e-3
+        assert d < bf16_tol(g['output_mask']) and df < bf16_flags_tol(g['output_flags'])
 
 
 @pytest.mark.parametrize('precision,tol,gtol', [('fp32', 2e-5, 2e-4), ('bf16', 1.5e-2, 4e-2)])
@@ -344,7 +349,7 @@ def test_joint_space_time_vs_reference_golden(cuda, precision, tol, gtol):
         if precision == 'fp32':
             assert d < tol and df < tol, (mode, d, df)
         else:
-            assert d < bf16_tol(g[f'{mode}::output_mask']) and df < bf16_tol(g[f'{mode}::output_flags']) + 5e-3
+            assert d < bf16_tol(g[f'{mode}::output_mask']) and df < bf16_flags_tol(g[f'{mode}::output_flags'])
         Gm = torch.from_numpy(synth._rng(meta['seed'], 'g14_mask').standard_normal(size=tuple(om.shape), dtype=np.float32)).cuda()
         Gf = torch.from_numpy(synth._rng(meta['seed'], 'g14_flags').standard_normal(size=tuple(fl.shape), dtype=np.float32)).cuda()
         ((om * Gm).sum() + (fl * Gf).sum()).backward()
