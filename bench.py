@@ -37,6 +37,8 @@ def parse():
     ap.add_argument('--grad-dtype', default='f32', choices=['f32', 'bf16'], help='dtype of the all-reduced gradient buckets (N > 1)')
     ap.add_argument('--launch-selftest', action='store_true', help='only start the ranks, all-reduce one number and print the rank count (CPU-runnable check of the N > 1 launch path)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-parity', action='store_true', help='skip the fp32 parity-mode timing and the live max|d| check against the oracle')
+    ap.add_argument('--parity-steps', type=int, default=2)
     ap.add_argument('--cpu-budget-s', type=float, default=25.0)
     return ap.parse_args()
 
@@ -67,7 +69,8 @@ class KernelTimer:
 
 def cpu_baseline(cfg, budget_s):
     """Times the oracle (our CPU port of the reference path, oracle/seeker_oracle.py) on this host's cores:
-    one query forward at the benchmark geometry; if it fits the budget also one forward+backward."""
+    one query forward at the benchmark geometry; if it fits the budget also one forward+backward.  Returns (the oracle's mask logits of that
+    forward -- the parity leg compares the HIP outputs with them --, the cpu_baseline record)."""
     from oracle import seeker_oracle as so
     from tcow_amd import synth
     cores = os.cpu_count() or 1
@@ -78,7 +81,7 @@ def cpu_baseline(cfg, budget_s):
     clip = synth.make_clip(1, T, H, W, seed=900)
     rgb = torch.from_numpy(clip['rgb']); qm = torch.from_numpy(synth.make_query_mask(clip, 0, 0))
     with torch.no_grad():
-        t0 = time.time(); so.seeker_forward(sd, cfg, rgb, qm); t_fwd = time.time() - t0
+        t0 = time.time(); ref_mask, _ = so.seeker_forward(sd, cfg, rgb, qm); t_fwd = time.time() - t0
     sample = f'1 query forward (B=1) = {t_fwd:.2f} s'
     t_fb = None
     if t_fwd * 4 < budget_s:
@@ -91,9 +94,57 @@ def cpu_baseline(cfg, budget_s):
         sample += f', 1 query forward+backward = {t_fb:.2f} s'
     per_query = t_fb if t_fb is not None else 3.0 * t_fwd     # bwd ~ 2x fwd when not measured
     nq = 3
-    return dict(value=1.0 / (nq * per_query), unit='clips/s', cores=threads, kind='port',
+    return ref_mask, dict(value=1.0 / (nq * per_query), unit='clips/s', cores=threads, kind='port',
                 sample=sample + f'; clips/s = 1 / ({nq} queries x {"measured" if t_fb else "3 x forward"} per-query time); '
                 f'optimizer step not included')
+
+
+def pmc_traffic():
+    """roofline.traffic: HBM bytes per launch of the dominant kernel family from the rocprofv3 --pmc passes of this command (FETCH_SIZE
+    with the gfx950 x2 correction + WRITE_SIZE, tools/pmc_gemm_traffic.sh -> profiles/r02_pmc_gemm_nt.json).  Counters cannot be read
+    inside the timed run, so the committed measurement is used ONLY while it still describes the kernel source that is running: the JSON
+    records the sha256 of gemm_bf16.hip it was taken with; any difference reports null rather than a stale number."""
+    import hashlib
+    root = os.path.dirname(os.path.abspath(__file__))
+    path = os.path.join(root, 'profiles', 'r02_pmc_gemm_nt.json')
+    if not os.path.exists(path):
+        return None
+    rec = json.load(open(path))
+    src = os.path.join(root, 'tcow_amd', 'csrc', 'gemm_bf16.hip')
+    sha = hashlib.sha256(open(src, 'rb').read()).hexdigest() if os.path.exists(src) else None
+    return rec.get('traffic_bytes_per_launch') if sha is not None and rec.get('gemm_bf16_sha256') == sha else None
+
+
+def parity_leg(make_trainer, bf16_net, ref_mask, args):
+    """The precision story in the bench line (north_star: mask-logit max|d| < 1e-3 vs the reference):
+      * fp32_parity_mode: the same training step with precision='fp32' (exact-f32 MFMA / FMA kernels) timed over --parity-steps steps
+        -- the only mode inside the 1e-3 bound;
+      * max_abs_d: eval forward of both modes on the cpu_baseline clip against the oracle's logits computed in this run."""
+    from tcow_amd import synth
+    out = {}
+    net32, step32 = make_trainer('fp32')
+    step32(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.parity_steps):
+        step32()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / args.parity_steps * 1e3
+    out['fp32_parity_mode'] = dict(ms_per_step=ms, clips_s=1e3 / ms, steps=args.parity_steps, dtype='f32')
+    if ref_mask is not None:
+        clip = synth.make_clip(1, args.frames, args.height, args.width, seed=900)
+        rgb = torch.from_numpy(clip['rgb']).cuda(); qm = torch.from_numpy(synth.make_query_mask(clip, 0, 0)).cuda()
+        cfg = synth.seeker_config(num_total_frames=args.frames, frame_height=args.height, frame_width=args.width, depth=args.depth, causal_attention=1)
+        sd = {k: torch.from_numpy(v).cuda() for k, v in synth.make_state_dict(cfg, 900).items()}     # the weights the oracle ran with (the trainers have stepped)
+        for name, net in (('bf16', bf16_net), ('fp32', net32)):
+            trained = {k: v.detach().clone() for k, v in net.state_dict().items()}
+            net.load_state_dict(sd, strict=True); net.seeker.invalidate_weight_cache(); net.eval()
+            with torch.no_grad():
+                om, _ = net(rgb, qm)
+            out.setdefault('max_abs_d', {})[name] = float((om.cpu() - ref_mask).abs().max())
+            net.load_state_dict(trained, strict=True); net.seeker.invalidate_weight_cache(); net.train()
+        out['max_abs_d']['logit_std'] = float(ref_mask.std())
+        out['max_abs_d']['against'] = 'oracle (CPU restatement pinned to the reference) on the cpu_baseline clip, weights of synth seed 900'
+    return out
 
 
 def self_launch(args):
@@ -134,39 +185,40 @@ def main():
 
     cfg = synth.seeker_config(num_total_frames=args.frames, frame_height=args.height, frame_width=args.width,
                               depth=args.depth, causal_attention=1)
-    net = Seeker(None, num_total_frames=args.frames, frame_height=args.height, frame_width=args.width,
-                 tracker_pretrained=False, causal_attention=1, drop_path_rate=0.1, network_depth=args.depth,
-                 precision=args.precision)
-    net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg, 900).items()}, strict=True)
-    net = net.to(dev).train()
-    ddp.broadcast_parameters(net)
-    params = [p for p in net.parameters()]
     from tcow_amd.optim import FusedAdamWClip
-    opt = FusedAdamWClip(params, lr=1e-4, max_norm=0.3, module=net)        # train.py:99-102,239-241: clip_grad_norm_(0.3) + AdamW(lr 1e-4), fused
-    net.seeker.persistent_grads = True                                     # one backward per step: gradients live in persistent flat buckets
-    sync = ddp.GradSync(world, bucket_dtype=args.grad_dtype)
-    net.seeker.grad_hook = sync
-
-    # synthetic Kubric-shaped batch for this rank: 1 clip, Qs queries chosen by desirability, query_time 0 (README.md:42)
     from tcow_amd.pipeline import SeekerPipeline
     from tcow_amd.tcow_loss import default_args
     Qs = args.queries
+    # synthetic Kubric-shaped batch for this rank: 1 clip, Qs queries chosen by desirability, query_time 0 (README.md:42)
     data = synth.to_torch_tree(synth.make_kubric_batch(1, args.frames, args.height, args.width, seed=ddp.shard_seed(900, rank), n_objects=5), dev,
                                host_keys=synth.HOST_KEYS)   # control-flow metadata stays on the host, as in the reference's DataLoader batch
-    pipe = SeekerPipeline(net, num_queries=Qs, train_args=default_args(), phase='train', device=dev,
-                          rng=__import__('numpy').random.default_rng(ddp.shard_seed(900, rank)))
 
+    def make_trainer(precision):
+        net = Seeker(None, num_total_frames=args.frames, frame_height=args.height, frame_width=args.width,
+                     tracker_pretrained=False, causal_attention=1, drop_path_rate=0.1, network_depth=args.depth,
+                     precision=precision)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg, 900).items()}, strict=True)
+        net = net.to(dev).train()
+        ddp.broadcast_parameters(net)
+        opt = FusedAdamWClip(list(net.parameters()), lr=1e-4, max_norm=0.3, module=net)   # train.py:99-102,239-241: clip_grad_norm_(0.3) + AdamW(lr 1e-4), fused
+        net.seeker.persistent_grads = True                                 # one backward per step: gradients live in persistent flat buckets
+        net.seeker.grad_hook = ddp.GradSync(world, bucket_dtype=args.grad_dtype)
+        pipe = SeekerPipeline(net, num_queries=Qs, train_args=default_args(), phase='train', device=dev,
+                              rng=__import__('numpy').random.default_rng(ddp.shard_seed(900, rank)))
+        state = {'step': 0}
+
+        def step():
+            model_retval = pipe.forward_kubric(data)                        # query sampling, query/target masks, ONE batched Seeker call (pipeline.py:85-200); persistent gradient buckets are overwritten, no zero_grad
+            progress = state['step'] / 1000.0
+            loss = pipe.step_losses(data, model_retval, progress)['total_seeker']   # loss.py:238-421: weighted BCE + bootstrapped BCE + soft Jaccard
+            loss.backward()                                                # train.py:98 (bucketed RCCL all-reduce runs inside, overlapped)
+            opt.step()                                                     # grad-clip 0.3 + AdamW in three launches
+            state['step'] += 1
+            return loss
+        return net, step
+
+    net, step = make_trainer(args.precision)
     timer = KernelTimer()
-    state = {'step': 0}
-
-    def step():
-        model_retval = pipe.forward_kubric(data)                            # (no zero_grad: persistent gradient buckets are overwritten)                           # query sampling, query/target masks, ONE batched Seeker call (pipeline.py:85-200)
-        progress = state['step'] / 1000.0
-        loss = pipe.step_losses(data, model_retval, progress)['total_seeker']   # loss.py:238-421: weighted BCE + bootstrapped BCE + soft Jaccard
-        loss.backward()                                                    # train.py:98 (bucketed RCCL all-reduce runs inside, overlapped)
-        opt.step()                                                         # grad-clip 0.3 + AdamW in three launches
-        state['step'] += 1
-        return loss
 
     for _ in range(args.warmup):
         step()
@@ -194,10 +246,7 @@ def main():
         fl = flops.seeker_forward_flops(1, g['T'], g['Hp'], g['Wp'], g['D'], g['heads'], args.depth)
         ks = timer.summary()
         peak = PEAK_BF16_TFLOPS if args.precision == 'bf16' else PEAK_F32_TFLOPS
-        traffic = None
-        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_gemm_nt.json')
-        if args.precision == 'bf16' and os.path.exists(pmc_path):      # from the separate rocprofv3 --pmc passes of this command (see the file)
-            traffic = json.load(open(pmc_path)).get('traffic_bytes_per_launch')
+        traffic = pmc_traffic() if args.precision == 'bf16' else None
         roof = dict(bound='mfma', kernel='gemm_nt_bf16_320_kernel (+ gemm_nt_bf16_256_kernel, gemm_nt_bf16_kernel)' if args.precision == 'bf16' else 'gemm_f32_kernel',
                     achieved=ks['tflops'], peak=peak, unit='TFLOP/s', frac=ks['tflops'] / peak, traffic=traffic,
                     launches_per_step=ks['launches'] / args.steps, avg_launch_us=ks['avg_us'], flops_per_launch=ks['flops_per_launch'])
@@ -211,11 +260,14 @@ def main():
                                loss='TCOW mask losses (loss.py:238-421): class-balanced BCE + bootstrapped BCE + soft Jaccard on 3 channels'),
                    query_forwards_per_s=clips_per_s * Qs, step_model_tflops=step_tflops, step_mfma_frac=step_tflops / peak,
                    final_loss=float(loss.detach()), roofline=roof)
+        ref_mask = None
         if not args.no_cpu_baseline and world == 1:
             try:
-                res['cpu_baseline'] = cpu_baseline(cfg, args.cpu_budget_s)
+                ref_mask, res['cpu_baseline'] = cpu_baseline(cfg, args.cpu_budget_s)
             except Exception as e:  # the baseline is a reported aside; never fail the bench line over it
                 res['cpu_baseline'] = dict(value=None, unit='clips/s', cores=os.cpu_count(), kind='port', sample=f'failed: {e}')
+        if world == 1 and args.precision == 'bf16' and not args.no_parity:
+            res.update(parity_leg(make_trainer, net, ref_mask, args))
         print(json.dumps(res), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libtcow_hip.so')
+LIB_PATH = os.environ.get('TCOW_LIB') or os.path.join(_HERE, 'libtcow_hip.so')     # TCOW_LIB: A/B builds of the library (dev aid)
 
 TCOW_F32, TCOW_BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_DGELU, ACT_GELU_DSAVE, ACT_MUL_AUX = 0, 1, 2, 3, 4
