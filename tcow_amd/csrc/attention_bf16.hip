@@ -41,6 +41,11 @@ __device__ __forceinline__ void half_swap(float& a, float& b) { asm volatile("v_
 __device__ __forceinline__ float half_max(float v) { float a = v, b = v; half_swap(a, b); return fmaxf(a, b); }
 __device__ __forceinline__ float half_sum(float v) { float a = v, b = v; half_swap(a, b); return a + b; }
 
+// hipcc if-converts a cheap `if (wave_uniform_flag) { selects }` block into unconditional compare / select code -- for the mask evaluation
+// of the tile functions below that was ~64 extra VALU instructions per step, half the VALU work of an interior tile on VALU-bound kernels
+// (profiles/r02_pmc_attn.txt).  An empty volatile asm statement cannot be speculated, so the block keeps its (scalar) branch.
+#define TCOW_NO_IFCVT() asm volatile("" ::: "memory")
+
 __device__ __forceinline__ int swz_g(int r) { return (((r >> 1) & 1) << 2) | ((r >> 2) & 3); }
 
 __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
@@ -112,6 +117,7 @@ __device__ __forceinline__ void fwd_tile(const SeqDesc& sd, const char* ktile, c
     for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(ktile, l31, ks, hi), qf[ks], s, 0, 0, 0);
     const bool need_mask = (32 * j + 31 >= sd.L) || ((long)32 * j + 31 > (long)32 * qt + sd.diag);
     if (need_mask) {
+        TCOW_NO_IFCVT();
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int key = 32 * j + crow32(r, hi);
@@ -135,6 +141,7 @@ __device__ __forceinline__ void fwd_tile(const SeqDesc& sd, const char* ktile, c
 #pragma unroll
     for (int r = 0; r < 16; ++r) { p[r] = __builtin_amdgcn_exp2f(fmaf(s[r], sc, -m)); ps += p[r]; }
     if (need_mask) {                                        // a fully masked row (m still at its start value) must contribute nothing
+        TCOW_NO_IFCVT();
         ps = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { if (s[r] <= -1e29f) p[r] = 0.f; ps += p[r]; }
@@ -284,7 +291,7 @@ __global__ void attn_bwd_prep_kernel(SeqDesc sd, int Lp, const bf16_t* __restric
             float s = 0.f;
 #pragma unroll
             for (int d = 0; d < ATT_HD; d += 4) { const float4 x = ld4(a + d), y = ld4(b + d); s += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w; }
-            v = make_float2(lse[row * sd.heads + h], s);
+            v = make_float2(lse[row * sd.heads + h] * kLog2e, s);      // (lse in log2 units: the consumers feed it to exp2)
         }
         ld[i] = v;
     }
@@ -305,21 +312,25 @@ __device__ __forceinline__ void dkv_tile(const SeqDesc& sd, const char* qtile, c
     // (VALU diet: masks only on boundary tiles -- masked scores are pushed to -1e30 so that exp2 underflows to 0; the 1/sqrt(d)
     // factor of dS is applied once to the finished dK / dQ tiles in dkv_store / dq_store instead of per element here.)
     const bool need_mask = (32 * i + 31 >= sd.L) || (key - l31 + 31 >= sd.L) || ((long)(key - l31) + 31 > (long)32 * i + sd.diag);
+    if (need_mask) {
+        TCOW_NO_IFCVT();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int q = 32 * i + crow32(r, hi);
+            if (!(q < sd.L && key < sd.L && (long)key <= (long)q + sd.diag)) s[r] = -1e30f;
+        }
+    }
     float pv[16], dsv[16];
+    const float4* tab = reinterpret_cast<const float4*>(ldh + 32 * i + 4 * hi);     // (lse2, delta) of queries 8 gq + 4 hi + e: two float4 per group
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
-        const float4* p4 = reinterpret_cast<const float4*>(ldh + 32 * i + 8 * gq + 4 * hi);
-        const float4 a = p4[0], b = p4[1];   // (lse0, d0, lse1, d1), (lse2, d2, lse3, d3)
+        const float4 a = tab[4 * gq], b = tab[4 * gq + 1];   // (lse0, d0, lse1, d1), (lse2, d2, lse3, d3)
         const float ls[4] = {a.x, a.z, b.x, b.z}, dl[4] = {a.y, a.w, b.y, b.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int r = 4 * gq + e;
-            float sv = s[r];
-            if (need_mask) {
-                const int q = 32 * i + 8 * gq + 4 * hi + e;
-                if (!(q < sd.L && key < sd.L && (long)key <= (long)q + sd.diag)) sv = -1e30f;
-            }
-            const float p = __builtin_amdgcn_exp2f(fmaf(sv, kScale * kLog2e, -ls[e] * kLog2e));
+            const float sv = s[r];
+            const float p = __builtin_amdgcn_exp2f(fmaf(sv, kScale * kLog2e, -ls[e]));
             pv[r] = p;
             dsv[r] = p * (dp[r] - dl[e]);
         }
@@ -367,14 +378,18 @@ __device__ __forceinline__ void dq_tile(const SeqDesc& sd, const char* ktile, co
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(vtile, l31, ks, hi), dof[ks], dp, 0, 0, 0);
     }
     const bool need_mask = (32 * j + 31 >= sd.L) || (q - l31 + 31 >= sd.L) || ((long)32 * j + 31 > (long)(q - l31) + sd.diag);
+    if (need_mask) {
+        TCOW_NO_IFCVT();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = 32 * j + crow32(r, hi);
+            if (!(q < sd.L && key < sd.L && (long)key <= (long)q + sd.diag)) s[r] = -1e30f;
+        }
+    }
     float dsv[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        float sv = s[r];
-        if (need_mask) {
-            const int key = 32 * j + crow32(r, hi);
-            if (!(q < sd.L && key < sd.L && (long)key <= (long)q + sd.diag)) sv = -1e30f;
-        }
+        const float sv = s[r];
         const float p = __builtin_amdgcn_exp2f(fmaf(sv, kScale * kLog2e, -ls));
         dsv[r] = p * (dp[r] - dl);
     }
@@ -477,7 +492,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma(SeqDesc sd, int nt, c
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) { qf[ks] = frag_row_global(qh, pse, qc, ks, hi); dof[ks] = frag_row_global(doh, pso, qc, ks, hi); }
         const float2 lq = ldh[32 * qt + l31];
-        const float ls = lq.x * kLog2e, dl = lq.y;
+        const float ls = lq.x, dl = lq.y;
         f32x16 dq0, dq1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dq0[r] = 0.f; dq1[r] = 0.f; }
@@ -522,7 +537,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_one_tile(SeqDesc sd, const bf
     }
     const float dl = half_sum(part);
     const float lsv = lse[(base + (long)qc * sd.pos_stride) * sd.heads + w.head];
-    if (hi == 0) ldw[l31] = l31 < sd.L ? make_float2(lsv, dl) : make_float2(0.f, 0.f);
+    if (hi == 0) ldw[l31] = l31 < sd.L ? make_float2(lsv * kLog2e, dl) : make_float2(0.f, 0.f);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     // ---- dK, dV (this wave's keys against its queries)
     {
@@ -633,7 +648,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_stream(SeqDesc sd, int nt,
     }
     const float dl = half_sum(part);
     const float lsn = lse[(base + (long)qc * sd.pos_stride) * sd.heads + head];
-    if (active && hi == 0) ldh[32 * qt + l31] = q < sd.L ? make_float2(lsn, dl) : make_float2(0.f, 0.f);
+    if (active && hi == 0) ldh[32 * qt + l31] = q < sd.L ? make_float2(lsn * kLog2e, dl) : make_float2(0.f, 0.f);
     const float ls = lsn * kLog2e;
     f32x16 dq0, dq1;
 #pragma unroll
