@@ -12,7 +12,7 @@ all: $(LIB)
 
 # (attention: no NaN arithmetic on the path -- lets fmaxf chains become v_max3_f32 without canonicalising v_max instructions)
 $(OBJ)/attention_bf16.hip.o: EXTRA := -fno-honor-nans
-$(OBJ)/%.hip.o: $(CSRC)/%.hip $(CSRC)/common.h include/tcow_hip.h
+$(OBJ)/%.hip.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/gemm_f32.h include/tcow_hip.h
 	@mkdir -p $(OBJ)
 	$(HIPCC) $(HIPFLAGS) $(EXTRA) -x hip -c $< -o $@
 

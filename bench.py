@@ -28,7 +28,7 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=8)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32', 'bf16x3'])
     ap.add_argument('--queries', type=int, default=3)
     ap.add_argument('--frames', type=int, default=30)
     ap.add_argument('--height', type=int, default=240)
@@ -117,31 +117,43 @@ def pmc_traffic():
 
 def parity_leg(make_trainer, bf16_net, ref_mask, args):
     """The precision story in the bench line (north_star: mask-logit max|d| < 1e-3 vs the reference):
-      * fp32_parity_mode: the same training step with precision='fp32' (exact-f32 MFMA / FMA kernels) timed over --parity-steps steps
-        -- the only mode inside the 1e-3 bound;
-      * max_abs_d: eval forward of both modes on the cpu_baseline clip against the oracle's logits computed in this run."""
+      * fp32_parity_mode: the same training step with precision='fp32' (exact-f32 MFMA / FMA kernels) timed over --parity-steps steps;
+      * bf16x3_mode: the same with precision='bf16x3' (f32 storage, GEMM products as three bf16 MFMAs on hi / lo operand splits) -- the
+        fastest mode inside the 1e-3 bound;
+      * max_abs_d: eval forward of all three modes on the cpu_baseline clip against the oracle's logits computed in this run."""
     from tcow_amd import synth
     out = {}
-    net32, step32 = make_trainer('fp32')
-    step32(); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.parity_steps):
-        step32()
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / args.parity_steps * 1e3
-    out['fp32_parity_mode'] = dict(ms_per_step=ms, clips_s=1e3 / ms, steps=args.parity_steps, dtype='f32')
+    clip = rgb = qm = sd = None
     if ref_mask is not None:
         clip = synth.make_clip(1, args.frames, args.height, args.width, seed=900)
         rgb = torch.from_numpy(clip['rgb']).cuda(); qm = torch.from_numpy(synth.make_query_mask(clip, 0, 0)).cuda()
         cfg = synth.seeker_config(num_total_frames=args.frames, frame_height=args.height, frame_width=args.width, depth=args.depth, causal_attention=1)
         sd = {k: torch.from_numpy(v).cuda() for k, v in synth.make_state_dict(cfg, 900).items()}     # the weights the oracle ran with (the trainers have stepped)
-        for name, net in (('bf16', bf16_net), ('fp32', net32)):
-            trained = {k: v.detach().clone() for k, v in net.state_dict().items()}
-            net.load_state_dict(sd, strict=True); net.seeker.invalidate_weight_cache(); net.eval()
-            with torch.no_grad():
-                om, _ = net(rgb, qm)
-            out.setdefault('max_abs_d', {})[name] = float((om.cpu() - ref_mask).abs().max())
-            net.load_state_dict(trained, strict=True); net.seeker.invalidate_weight_cache(); net.train()
+
+    def max_abs_d(name, net):
+        if ref_mask is None:
+            return
+        trained = {k: v.detach().clone() for k, v in net.state_dict().items()}
+        net.load_state_dict(sd, strict=True); net.seeker.invalidate_weight_cache(); net.eval()
+        with torch.no_grad():
+            om, _ = net(rgb, qm)
+        out.setdefault('max_abs_d', {})[name] = float((om.cpu() - ref_mask).abs().max())
+        net.load_state_dict(trained, strict=True); net.seeker.invalidate_weight_cache(); net.train()
+
+    max_abs_d('bf16', bf16_net)
+    for key, precision, dtype in (('fp32_parity_mode', 'fp32', 'f32'), ('bf16x3_mode', 'bf16x3', 'f32 storage, bf16 x 3 GEMM products')):
+        net, step = make_trainer(precision)
+        step(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.parity_steps):
+            step()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / args.parity_steps * 1e3
+        out[key] = dict(ms_per_step=ms, clips_s=1e3 / ms, steps=args.parity_steps, dtype=dtype)
+        max_abs_d(precision, net)
+        del net, step
+        torch.cuda.empty_cache()
+    if ref_mask is not None:
         out['max_abs_d']['logit_std'] = float(ref_mask.std())
         out['max_abs_d']['against'] = 'oracle (CPU restatement pinned to the reference) on the cpu_baseline clip, weights of synth seed 900'
     return out
@@ -245,15 +257,15 @@ def main():
         g = net.seeker.geometry(Qs)
         fl = flops.seeker_forward_flops(1, g['T'], g['Hp'], g['Wp'], g['D'], g['heads'], args.depth)
         ks = timer.summary()
-        peak = PEAK_BF16_TFLOPS if args.precision == 'bf16' else PEAK_F32_TFLOPS
+        peak = {'bf16': PEAK_BF16_TFLOPS, 'fp32': PEAK_F32_TFLOPS, 'bf16x3': PEAK_BF16_TFLOPS / 3.0}[args.precision]   # bf16x3: three MFMAs per product
         traffic = pmc_traffic() if args.precision == 'bf16' else None
-        roof = dict(bound='mfma', kernel='gemm_nt_bf16_320_kernel (+ gemm_nt_bf16_256_kernel, gemm_nt_bf16_kernel)' if args.precision == 'bf16' else 'gemm_f32_kernel',
+        roof = dict(bound='mfma', kernel={'bf16': 'gemm_nt_bf16_320_kernel (+ gemm_nt_bf16_256_kernel, gemm_nt_bf16_kernel)', 'fp32': 'gemm_f32_kernel', 'bf16x3': 'gemm_x3_kernel'}[args.precision],
                     achieved=ks['tflops'], peak=peak, unit='TFLOP/s', frac=ks['tflops'] / peak, traffic=traffic,
                     launches_per_step=ks['launches'] / args.steps, avg_launch_us=ks['avg_us'], flops_per_launch=ks['flops_per_launch'])
         step_tflops = 3.0 * Qs * fl['total'] / (ms_per_step * 1e-3) / 1e12
         res = dict(metric='train clips/sec (T=30, 240x320)', value=clips_per_s, unit='clips/s', n_gpus=world, ranks_seen=(torch.distributed.get_world_size() if world > 1 else 1), steps=args.steps,
                    warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True, scaling='weak', vs_baseline=None,
-                   dtype='bf16' if args.precision == 'bf16' else 'f32', data='synthetic',
+                   dtype={'bf16': 'bf16', 'fp32': 'f32', 'bf16x3': 'f32 (bf16x3 products)'}[args.precision], data='synthetic',
                    config=dict(workload=f'TCOW Seeker train step: T={args.frames} {args.height}x{args.width} patch16, {args.depth}-layer divided '
                                f'space-time ViT (D={g["D"]}), num_queries={Qs}, causal_attention=1, 1 clip/GPU',
                                clips_per_gpu=1, num_queries=Qs, parallelism=f'dp{world}', optimizer='AdamW lr 1e-4, clip 0.3',

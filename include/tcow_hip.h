@@ -25,7 +25,10 @@
  *    Reference token index of (b, t, n): 1 + n*T + t (vision_tf.py:137).
  *  - dtype: TCOW_F32 = everything in float (parity mode, exact-f32 MFMA / FMA), TCOW_BF16 = activations and
  *    GEMM operands in bfloat16 with f32 accumulation; the residual stream, LayerNorm statistics, softmax
- *    statistics, biases and all gradients of parameters stay f32 in both modes.
+ *    statistics, biases and all gradients of parameters stay f32 in both modes.  TCOW_F32X3 is accepted by the two GEMM
+ *    entry points only (tcow_gemm_nt, tcow_gemm_tn): storage, arguments and epilogues of TCOW_F32, products computed as
+ *    three bf16 MFMAs on hi / lo splits of the f32 operands (~1e-5 relative per product; gemm_x3.hip) -- every other
+ *    entry point of the module's precision='bf16x3' mode is called with TCOW_F32.
  */
 #ifndef TCOW_HIP_H
 #define TCOW_HIP_H
@@ -41,6 +44,7 @@ extern "C" {
 
 #define TCOW_F32 0
 #define TCOW_BF16 1
+#define TCOW_F32X3 2   /* GEMM entry points only: f32 storage, bf16 x 3 split products */
 
 #define TCOW_ACT_NONE 0
 #define TCOW_ACT_GELU 1      /* C = GELU_erf(v); optionally also stores v (pre-activation) to aux         */

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('TCOW_LIB') or os.path.join(_HERE, 'libtcow_hip.so')     # TCOW_LIB: A/B builds of the library (dev aid)
 
-TCOW_F32, TCOW_BF16 = 0, 1
+TCOW_F32, TCOW_BF16, TCOW_F32X3 = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_DGELU, ACT_GELU_DSAVE, ACT_MUL_AUX = 0, 1, 2, 3, 4
 
 

@@ -36,7 +36,11 @@ int tcow_gemm_tn_bf16(hipStream_t stream, int M, int N, int K, const bf16_t* dY,
                       float* bias_part, int* bias_parts_out);
 int tcow_gemm_tn_f32(hipStream_t stream, int M, int N, int K, const float* dY, long ldy, const float* X, long ldx, float* dW, long lddw, int accumulate,
                      float* slab, int splits);
+int tcow_gemm_nt_x3(hipStream_t stream, const tcow_gemm_args* a);
+int tcow_gemm_tn_x3(hipStream_t stream, int M, int N, int K, const float* dY, long ldy, const float* X, long ldx, float* dW, long lddw, int accumulate,
+                    float* slab, int splits);
 int tcow_tn_splits(int M, int N, int K, int tile_outputs);
+int tcow_tn_splits_x3(int M, int N, int K);
 int tcow_tn_splits_256(int M, int N, int K);
 bool tcow_tn_use_256(int M, int N, int K);
 int tcow_launch_slab_reduce(hipStream_t stream, const float* slab, int nz, long slab_stride, long rows, long cols, float* out, long ldo, int accumulate,
@@ -46,7 +50,7 @@ int tcow_launch_colsum(hipStream_t stream, int dtype, const void* Y, long ldy, i
 
 extern "C" {
 
-int tcow_version(void) { return 2; }
+int tcow_version(void) { return 3; }
 const char* tcow_last_error(void) { return g_err; }
 
 // ---- optional low-overhead HIP-event timing of the dominant kernel (the NT GEMM), on the launch stream
@@ -107,10 +111,8 @@ static int gemm_nt_dispatch(void* stream, const tcow_gemm_args* a) {
     TCOW_CHECK_ARG((a->act != TCOW_ACT_DGELU && a->act != TCOW_ACT_GELU_DSAVE && a->act != TCOW_ACT_MUL_AUX) || a->aux, "tcow_gemm_nt: this activation needs aux");
     TCOW_CHECK_ARG(a->act >= TCOW_ACT_NONE && a->act <= TCOW_ACT_MUL_AUX, "tcow_gemm_nt: unknown activation %d", a->act);
     if (a->dtype == TCOW_BF16) return tcow_gemm_nt_bf16((hipStream_t)stream, a);
-    if (a->dtype == TCOW_F32) {
-        TCOW_CHECK_ARG(a->out_f32 || true, "unreachable");
-        return tcow_gemm_nt_f32((hipStream_t)stream, a);
-    }
+    if (a->dtype == TCOW_F32) return tcow_gemm_nt_f32((hipStream_t)stream, a);
+    if (a->dtype == TCOW_F32X3) return tcow_gemm_nt_x3((hipStream_t)stream, a);
     tcow_set_error("tcow_gemm_nt: unknown dtype %d", a->dtype);
     return TCOW_ERR_INVALID_ARG;
 }
@@ -121,6 +123,7 @@ long tcow_gemm_tn_workspace_bytes(int M, int N, int K) {
     const int s_bf = tcow_tn_splits(M, N, K, 128), s_f = tcow_tn_splits(M, N, K, 64), s_big = tcow_tn_splits_256(M, N, K);
     int s = s_bf > s_f ? s_bf : s_f;
     if (s_big > s) s = s_big;
+    if (tcow_tn_splits_x3(M, N, K) > s) s = tcow_tn_splits_x3(M, N, K);
     return ((long)(s + 1) * N * K + (long)kColsumParts * N) * 4 + 256;
 }
 
@@ -145,12 +148,16 @@ int tcow_gemm_tn(void* stream, int dtype, int M, int N, int K, const void* dY, l
         const int splits = tcow_tn_splits(M, N, K, 64);
         rc = tcow_gemm_tn_f32((hipStream_t)stream, M, N, K, (const float*)dY, ldy, (const float*)X, ldx, dW, lddw, accumulate, slab, splits);
         if (rc) return rc;
+    } else if (dtype == TCOW_F32X3) {
+        const int splits = tcow_tn_splits_x3(M, N, K);
+        rc = tcow_gemm_tn_x3((hipStream_t)stream, M, N, K, (const float*)dY, ldy, (const float*)X, ldx, dW, lddw, accumulate, slab, splits);
+        if (rc) return rc;
     } else {
         tcow_set_error("tcow_gemm_tn: unknown dtype %d", dtype);
         return TCOW_ERR_INVALID_ARG;
     }
     if (bias_grad) {
-        rc = tcow_launch_colsum((hipStream_t)stream, dtype, dY, ldy, M, N, bias_grad, accumulate, part, 64);
+        rc = tcow_launch_colsum((hipStream_t)stream, dtype == TCOW_BF16 ? TCOW_BF16 : TCOW_F32, dY, ldy, M, N, bias_grad, accumulate, part, 64);
         if (rc) return rc;
     }
     return TCOW_OK;

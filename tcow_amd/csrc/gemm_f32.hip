@@ -4,24 +4,13 @@
 // 64x64 tile per 256-thread workgroup (4 waves, one 32x32 MFMA tile each), k walked 16 at a time through LDS
 // stored k-major so that fragment reads are conflict-free ds_read_b32.  Speed is secondary here: this path
 // exists so that the HIP pipeline can be compared with the fp32 reference below 1e-3.
-#include "common.h"
+#include "gemm_f32.h"
 
 namespace {
 
 constexpr int FT = 64;   // tile edge
 constexpr int FK = 16;   // k-slice
 constexpr int FLD = FT + 4;
-
-struct F32Params {
-    int M, N, K;
-    const float* A; long sai, sak;
-    const float* B; long sbj, sbk;
-    void* C; long ldc;
-    const float* bias; const float* row_scale; const float* resid; long ldr;
-    int act; float* aux; long ldaux;
-    int kps;          // contraction elements per z-slice (multiple of FK)
-    float* slab;      // if non-NULL: raw partial sums to slab[z][M][N], no epilogue
-};
 
 __device__ __forceinline__ void load_tile(const float* __restrict__ P, long s_row, long s_k, int row0, int nrows, int k0, int kend,
                                           float (*dst)[FLD], int tid) {
@@ -92,22 +81,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(F32Params p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int gm = m0 + wm * 32 + crow32(r, hi);
-        if (gm >= p.M) continue;
-        float x = acc[r] + bv;
-        if (p.row_scale) x *= p.row_scale[gm];
-        if (p.act == TCOW_ACT_GELU) {
-            if (p.aux) p.aux[(size_t)gm * p.ldaux + gn] = x;
-            x = gelu_erf(x);
-        } else if (p.act == TCOW_ACT_DGELU) {
-            x *= gelu_erf_grad(p.aux[(size_t)gm * p.ldaux + gn]);
-        } else if (p.act == TCOW_ACT_GELU_DSAVE) {
-            p.aux[(size_t)gm * p.ldaux + gn] = gelu_erf_grad(x);
-            x = gelu_erf(x);
-        } else if (p.act == TCOW_ACT_MUL_AUX) {
-            x *= p.aux[(size_t)gm * p.ldaux + gn];
-        }
-        if (p.resid) x += p.resid[(size_t)gm * p.ldr + gn];
-        reinterpret_cast<float*>(p.C)[(size_t)gm * p.ldc + gn] = x;
+        if (gm < p.M) f32_epilogue_store(p, gm, gn, acc[r], bv);
     }
 }
 

@@ -208,6 +208,7 @@ def _effective_embeddings(module, g):
 
 def run_forward(module, rgb, qm, params, save):
     mode = module.mode
+    gmode = module.gemm_mode           # the GEMM entry points' arithmetic: `mode`, or TCOW_F32X3 (f32 tensors, bf16 x 3 split products) for precision='bf16x3'
     dt = ops.tdtype(mode)
     dev = rgb.device
     B = qm.shape[0]                          # query rows (== clips unless the rgb frames are shared between a clip's queries)
@@ -240,16 +241,16 @@ def run_forward(module, rgb, qm, params, save):
         ops.im2col_channels(mode, rgb, P, module.tracker_pretrained, A_rgb)
         ops.im2col_channels(mode, qm, P, False, A_m)
         Xrgb = E(Bc * T * S, D, dtype=f32)
-        ops.gemm_nt(mode, A_rgb, Wc[:, :Krgb], Xrgb, bias=params[4].detach())
+        ops.gemm_nt(gmode, A_rgb, Wc[:, :Krgb], Xrgb, bias=params[4].detach())
         TS = T * S
         for bq in range(B):
             b = bq // Qs
-            ops.gemm_nt(mode, A_m[bq * TS:(bq + 1) * TS], Wc[:, Krgb:], X[bq * TS:(bq + 1) * TS], resid=Xrgb[b * TS:(b + 1) * TS])
+            ops.gemm_nt(gmode, A_m[bq * TS:(bq + 1) * TS], Wc[:, Krgb:], X[bq * TS:(bq + 1) * TS], resid=Xrgb[b * TS:(b + 1) * TS])
         A_pe = (A_rgb, A_m)
     else:
         A_pe = E(M, Kpe)
         ops.im2col(mode, rgb, qm, P, module.tracker_pretrained, A_pe)
-        ops.gemm_nt(mode, A_pe, W(params[3]), X, bias=params[4].detach())
+        ops.gemm_nt(gmode, A_pe, W(params[3]), X, bias=params[4].detach())
     pos, te, pos_idx, time_idx = _effective_embeddings(module, g)
     ops.embed_fwd(X, B, T, S, params[0].detach().reshape(-1), pos, te)
     if save:
@@ -274,7 +275,7 @@ def run_forward(module, rgb, qm, params, save):
             V = E(M, D); mu1 = E(M, dtype=f32) if save else None; rs1 = E(M, dtype=f32) if save else None
             ops.layernorm_fwd(mode, R0, n1_w, n1_b, V, mu1, rs1)
             QKV2 = E(M, 3 * D)
-            ops.gemm_nt(mode, V, W(q[ix['qkv']]), QKV2, bias=qkv_b)
+            ops.gemm_nt(gmode, V, W(q[ix['qkv']]), QKV2, bias=qkv_b)
             QJ = QKV2.index_select(0, jrows)                                # compact (cls, patches) sequences: the kernels take contiguous ones
             OJ = E(B * Lj, D); lse_s = E(B * Lj, heads, dtype=f32) if save else None
             ops.attn_fwd(shape_joint, True, QJ, OJ, lse_s)
@@ -282,7 +283,7 @@ def run_forward(module, rgb, qm, params, save):
             O2.index_copy_(0, jrows, OJ)                                    # (the unused cls replicas of frames 1.. get a zero attention output)
             rs_s = dp['s']
             R2 = E(M, D, dtype=f32) if save else R0
-            ops.gemm_nt(mode, O2, W(q[ix['proj']]), R2, bias=proj_b, row_scale=rs_s, resid=R0)
+            ops.gemm_nt(gmode, O2, W(q[ix['proj']]), R2, bias=proj_b, row_scale=rs_s, resid=R0)
             if save:
                 st.update(R1=R0, mu1=mu1, rs1=rs1, V=V, QKV_s=QJ, O_s=O2, OJ=OJ, lse_s=lse_s, rs_s=rs_s)
         else:
@@ -291,27 +292,27 @@ def run_forward(module, rgb, qm, params, save):
             U = E(M, D); mu0 = E(M, dtype=f32) if save else None; rs0 = E(M, dtype=f32) if save else None
             ops.layernorm_fwd(mode, R0, tn_w, tn_b, U, mu0, rs0)
             QKV = E(M, 3 * D)
-            ops.gemm_nt(mode, U, W(q[ix['tqkv']]), QKV, bias=tqkv_b)
+            ops.gemm_nt(gmode, U, W(q[ix['tqkv']]), QKV, bias=tqkv_b)
             O = E(M, D); lse_t = E(M, heads, dtype=f32) if save else None
             ops.attn_fwd(shape_attn, False, QKV, O, lse_t)
             Pj = E(M, D)
-            ops.gemm_nt(mode, O, W(q[ix['tproj']]), Pj, bias=tproj_b, row_scale=dp['t'])
+            ops.gemm_nt(gmode, O, W(q[ix['tproj']]), Pj, bias=tproj_b, row_scale=dp['t'])
             R1 = E(M, D, dtype=f32) if save else R0
-            ops.gemm_nt(mode, Pj, W(q[ix['tfc']]), R1, bias=tfc_b, row_scale=mask0, resid=R0)
+            ops.gemm_nt(gmode, Pj, W(q[ix['tfc']]), R1, bias=tfc_b, row_scale=mask0, resid=R0)
             if save:
                 st.update(R0=R0, mu0=mu0, rs0=rs0, U=U, QKV_t=QKV, O_t=O, lse_t=lse_t, Pj=Pj)
             # spatial
             V = E(M, D); mu1 = E(M, dtype=f32) if save else None; rs1 = E(M, dtype=f32) if save else None
             ops.layernorm_fwd(mode, R1, n1_w, n1_b, V, mu1, rs1)
             QKV2 = E(M, 3 * D)
-            ops.gemm_nt(mode, V, W(q[ix['qkv']]), QKV2, bias=qkv_b)
+            ops.gemm_nt(gmode, V, W(q[ix['qkv']]), QKV2, bias=qkv_b)
             O2 = E(M, D); lse_s = E(M, heads, dtype=f32) if save else None
             ops.attn_fwd(shape_attn, True, QKV2, O2, lse_s)
             rs_s = dp['s']
             if not use_cls:
                 rs_s = mask0 if rs_s is None else rs_s * mask0
             R2 = E(M, D, dtype=f32) if save else R1
-            ops.gemm_nt(mode, O2, W(q[ix['proj']]), R2, bias=proj_b, row_scale=rs_s, resid=R1)
+            ops.gemm_nt(gmode, O2, W(q[ix['proj']]), R2, bias=proj_b, row_scale=rs_s, resid=R1)
             if use_cls:
                 ops.cls_merge(R2, B, T, S, 1 if ca == 1 else 0)
             if save:
@@ -323,9 +324,9 @@ def run_forward(module, rgb, qm, params, save):
         pre = E(M, Hd) if save else None
         H = E(M, Hd)
         # training saves GELU'(pre-activation) instead of the pre-activation: the backward is then one multiply per element
-        ops.gemm_nt(mode, Wn, W(q[ix['fc1']]), H, bias=fc1_b, act=ACT_GELU_DSAVE if save else ACT_GELU, aux=pre)
+        ops.gemm_nt(gmode, Wn, W(q[ix['fc1']]), H, bias=fc1_b, act=ACT_GELU_DSAVE if save else ACT_GELU, aux=pre)
         R3 = E(M, D, dtype=f32) if save else R2
-        ops.gemm_nt(mode, H, W(q[ix['fc2']]), R3, bias=fc2_b, row_scale=dp['m'], resid=R2)
+        ops.gemm_nt(gmode, H, W(q[ix['fc2']]), R3, bias=fc2_b, row_scale=dp['m'], resid=R2)
         if save:
             st.update(R2=R2, mu2=mu2, rs2=rs2, Wn=Wn, pre=pre, H=H)
             sv['blocks'].append(st)
@@ -352,7 +353,7 @@ def run_forward(module, rgb, qm, params, save):
         ops.scale_cast(mode, X, None, Fm)
     Co = module.output_channels
     Pm = E(M, Co * P * P)
-    ops.gemm_nt(mode, Fm, W(head_w), Pm, bias=head_b.detach())           # mask_tracker.py:113
+    ops.gemm_nt(gmode, Fm, W(head_w), Pm, bias=head_b.detach())           # mask_tracker.py:113
     stp = module.track_map_stride if module.track_map_stride > 1 else 1
     h, w = module.frame_height // stp, module.frame_width // stp
     pooled = E(B * T, Co, h, w, dtype=f32)
@@ -372,6 +373,7 @@ def run_forward(module, rgb, qm, params, save):
 
 def run_backward(module, sv, params, d_mask, d_flags):
     mode = module.mode
+    gmode = module.gemm_mode           # the GEMM entry points' arithmetic: `mode`, or TCOW_F32X3 (f32 tensors, bf16 x 3 split products) for precision='bf16x3'
     dt = ops.tdtype(mode)
     g = sv['g']
     B, T, S, D, M, P, heads = g['B'], g['T'], g['S'], g['D'], g['M'], g['P'], g['heads']
@@ -413,7 +415,7 @@ def run_backward(module, sv, params, d_mask, d_flags):
     def linear_bwd(idx_w, dY, Xin):
         """dW, db of a Linear whose output-gradient operand is dY [M,N] and input operand Xin [M,K]."""
         dW = galloc(idx_w); db = galloc(idx_w + 1)
-        ops.gemm_tn(mode, dY, Xin, dW.reshape(dW.shape[0], -1), bias_grad=db)
+        ops.gemm_tn(gmode, dY, Xin, dW.reshape(dW.shape[0], -1), bias_grad=db)
 
     BP, ix = _layout(module)
     joint = module.attention_type != 'divided_space_time'
@@ -433,7 +435,7 @@ def run_backward(module, sv, params, d_mask, d_flags):
     linear_bwd(nb + 2, dPm, sv['Fm'])
     # gradient w.r.t. the features that feed both heads, always f32: dFeat = dPm . Whead (+ flags adjoint)
     dFeat = E(M, D, dtype=f32)
-    ops.gemm_nt(mode, dPm, Wt(params[nb + 2]), dFeat)
+    ops.gemm_nt(gmode, dPm, Wt(params[nb + 2]), dFeat)
     if module.flag_channels > 0 and have_flags:
         # flags head adjoint (F x D, once per step; only the plugin path ever asks for it, pipeline.py:238)
         df = d_flags.to(f32).reshape(B * T, -1)
@@ -473,10 +475,10 @@ def run_backward(module, sv, params, d_mask, d_flags):
             G3 = E(M, D)
             ops.scale_cast(mode, dR3, dp['m'], G3)
         dpre = E(M, Hd)
-        ops.gemm_nt(mode, G3, Wt(q[ix['fc2']]), dpre, act=ACT_MUL_AUX, aux=st['pre'])
+        ops.gemm_nt(gmode, G3, Wt(q[ix['fc2']]), dpre, act=ACT_MUL_AUX, aux=st['pre'])
         linear_bwd(o + ix['fc2'], G3, st['H'])
         dWn = E(M, D)
-        ops.gemm_nt(mode, dpre, Wt(q[ix['fc1']]), dWn)
+        ops.gemm_nt(gmode, dpre, Wt(q[ix['fc1']]), dWn)
         linear_bwd(o + ix['fc1'], dpre, st['Wn'])
         dR2 = E(M, D, dtype=f32)
         ops.layernorm_bwd(mode, dWn, st['R2'], st['mu2'], st['rs2'], q[ix['n2']].detach(), dR3, dR2, galloc(o + ix['n2']), galloc(o + ix['n2'] + 1))
@@ -487,7 +489,7 @@ def run_backward(module, sv, params, d_mask, d_flags):
         G2 = E(M, D)
         ops.scale_cast(mode, dR2, st['rs_s'], G2)
         dO2 = E(M, D)
-        ops.gemm_nt(mode, G2, Wt(q[ix['proj']]), dO2)
+        ops.gemm_nt(gmode, G2, Wt(q[ix['proj']]), dO2)
         linear_bwd(o + ix['proj'], G2, st['O_s'])
         if joint:
             dQJ = E(B * Lj, 3 * D)
@@ -498,7 +500,7 @@ def run_backward(module, sv, params, d_mask, d_flags):
             dQKV2 = E(M, 3 * D)
             ops.attn_bwd(shape_attn, True, st['QKV_s'], st['O_s'], dO2, st['lse_s'], dQKV2)
         dV = E(M, D)
-        ops.gemm_nt(mode, dQKV2, Wt(q[ix['qkv']]), dV)
+        ops.gemm_nt(gmode, dQKV2, Wt(q[ix['qkv']]), dV)
         linear_bwd(o + ix['qkv'], dQKV2, st['V'])
         dR1 = E(M, D, dtype=f32)
         G1 = E(M, D)                           # bf16(dR1 * row scale), written by the same LayerNorm backward pass
@@ -511,15 +513,15 @@ def run_backward(module, sv, params, d_mask, d_flags):
         else:
             # ---- temporal
             dPj = E(M, D)
-            ops.gemm_nt(mode, G1, Wt(q[ix['tfc']]), dPj, row_scale=dp['t'])
+            ops.gemm_nt(gmode, G1, Wt(q[ix['tfc']]), dPj, row_scale=dp['t'])
             linear_bwd(o + ix['tfc'], G1, st['Pj'])
             dO = E(M, D)
-            ops.gemm_nt(mode, dPj, Wt(q[ix['tproj']]), dO)
+            ops.gemm_nt(gmode, dPj, Wt(q[ix['tproj']]), dO)
             linear_bwd(o + ix['tproj'], dPj, st['O_t'])
             dQKV = E(M, 3 * D)
             ops.attn_bwd(shape_attn, False, st['QKV_t'], st['O_t'], dO, st['lse_t'], dQKV)
             dU = E(M, D)
-            ops.gemm_nt(mode, dQKV, Wt(q[ix['tqkv']]), dU)
+            ops.gemm_nt(gmode, dQKV, Wt(q[ix['tqkv']]), dU)
             linear_bwd(o + ix['tqkv'], dQKV, st['U'])
             dR0 = E(M, D, dtype=f32)
             G3_next = E(M, D)                  # operand of the next (lower) block's MLP backward, or of the patch-embed weight gradient
@@ -556,10 +558,10 @@ def run_backward(module, sv, params, d_mask, d_flags):
         Bc = A_rgb.shape[0] // (T * S)
         Gsum = E(Bc * T * S, D)
         ops.scale_cast(mode, gX.reshape(Bc, B // Bc, T * S, D).sum(dim=1).reshape(Bc * T * S, D), mask0[:Bc * T * S], Gsum)
-        ops.gemm_tn(mode, Gsum, A_rgb, dWpe[:, :Krgb])
-        ops.gemm_tn(mode, Gpe, A_m, dWpe[:, Krgb:])
+        ops.gemm_tn(gmode, Gsum, A_rgb, dWpe[:, :Krgb])
+        ops.gemm_tn(gmode, Gpe, A_m, dWpe[:, Krgb:])
     else:
-        ops.gemm_tn(mode, Gpe, sv['A_pe'], dWpe)
+        ops.gemm_tn(gmode, Gpe, sv['A_pe'], dWpe)
     grads[4].copy_(dtime_eff.sum(0))       # bias gradient = sum over all patch rows
     if module.grad_hook is not None:
         module.grad_hook('embed', emb_flat)

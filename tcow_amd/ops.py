@@ -11,6 +11,7 @@ import torch
 from . import _lib as L
 
 F32, BF16 = L.TCOW_F32, L.TCOW_BF16
+F32X3 = L.TCOW_F32X3      # GEMM wrappers only: f32 tensors, bf16 x 3 split products (csrc/gemm_x3.hip)
 ACT_NONE, ACT_GELU, ACT_DGELU, ACT_GELU_DSAVE, ACT_MUL_AUX = L.ACT_NONE, L.ACT_GELU, L.ACT_DGELU, L.ACT_GELU_DSAVE, L.ACT_MUL_AUX
 
 

@@ -11,7 +11,10 @@ backward is hand-written (no autograd graph inside the model).
 precision:
   'bf16' (default)  bf16 GEMM/attention operands, f32 accumulation, f32 residual stream / LayerNorm / softmax.
   'fp32'            everything f32 on the exact-f32 MFMA/FMA kernels: the parity mode (mask logits within 1e-3
-                    of the fp32 reference; measured ~1e-5).
+                    of the fp32 reference; measured ~1e-6).
+  'bf16x3'          the fp32 mode with its GEMMs on the bf16 matrix cores: every f32 operand is split into two bf16
+                    terms in registers and a product is three MFMAs (hi*hi + hi*lo + lo*hi, csrc/gemm_x3.hip) --
+                    ~1e-5 relative per product; mask logits within ~1e-5 of the reference at twice the fp32 mode's rate.
 """
 import math
 from functools import partial
@@ -187,10 +190,11 @@ class QueryMaskTracker(nn.Module):
 
     # ---- configuration helpers
     def set_precision(self, precision):
-        if precision not in ('bf16', 'fp32'):
-            raise ValueError("precision must be 'bf16' or 'fp32'")
+        if precision not in ('bf16', 'fp32', 'bf16x3'):
+            raise ValueError("precision must be 'bf16', 'fp32' or 'bf16x3'")
         self.precision = precision
         self.mode = ops.BF16 if precision == 'bf16' else ops.F32
+        self.gemm_mode = ops.F32X3 if precision == 'bf16x3' else self.mode     # GEMM arithmetic; storage / every other kernel follow `mode`
         self._wcache = {}
         self.__dict__.pop('_wreg', None); self.__dict__.pop('_wtab', None)
         return self

@@ -23,13 +23,14 @@ def ops(cuda):
 
 
 MODES = [('f32', 2e-5), ('bf16', 2e-2)]
+GEMM_MODES = MODES + [('f32x3', 4e-5)]      # f32 tensors, bf16 x 3 split products (csrc/gemm_x3.hip): ~2^-17 per product
 
 
 def _mode(ops, name):
-    return (ops.F32, torch.float32) if name == 'f32' else (ops.BF16, torch.bfloat16)
+    return {'f32': (ops.F32, torch.float32), 'f32x3': (ops.F32X3, torch.float32), 'bf16': (ops.BF16, torch.bfloat16)}[name]
 
 
-@pytest.mark.parametrize('mname,tol', MODES)
+@pytest.mark.parametrize('mname,tol', GEMM_MODES)
 @pytest.mark.parametrize('M,K,N', [(1, 64, 64), (300, 64, 192), (130, 128, 48), (1000, 1024, 256), (4097, 768, 768)])
 def test_gemm_nt_epilogues(ops, cuda, mname, tol, M, K, N):
     mode, dt = _mode(ops, mname)
@@ -96,7 +97,7 @@ def test_gemm_nt_every_tile_kernel_at_bench_size(ops, cuda, N, K):
         assert rel(ops.gemm_nt(ops.BF16, A, W, bf(), act=ops.ACT_MUL_AUX, aux=pre, **t), ref0 * pre.double()) < BF           # <MUL_AUX, 0>: fc2 input gradient x GELU'
 
 
-@pytest.mark.parametrize('mname,tol', MODES)
+@pytest.mark.parametrize('mname,tol', GEMM_MODES)
 @pytest.mark.parametrize('M,N,K', [(5, 64, 64), (300, 192, 256), (2057, 48, 1024), (9030, 768, 768),
                                    (9030, 2304, 768), (4200, 1032, 1288), (4099, 3072, 768)])     # the last three take the 256-tile kernel (incl. ragged tiles / last slice)
 def test_gemm_tn_weight_and_bias_grad(ops, cuda, mname, tol, M, N, K):
@@ -109,6 +110,29 @@ def test_gemm_tn_weight_and_bias_grad(ops, cuda, mname, tol, M, N, K):
     assert rel(dW, ref) < max(tol / 4, 1e-5) and rel(db, dY.double().sum(0)) < 1e-4
     ops.gemm_tn(mode, dY, X, dW, bias_grad=db, accumulate=True)
     assert rel(dW, 2 * ref) < max(tol / 4, 1e-5) and rel(db, 2 * dY.double().sum(0)) < 1e-4
+
+
+@pytest.mark.parametrize('M,K,N', [(27090, 768, 768), (27090, 3072, 768), (333, 100, 70), (257, 50, 129)])
+def test_gemm_x3_split_products(ops, cuda, M, K, N):
+    """TCOW_F32X3 at the benchmark's row count and on ragged / unaligned shapes (K not a multiple of the 32-wide k-slice, K % 4 != 0:
+    scalar loader; row views with an odd pitch) against the f64 product, next to the exact-f32 kernel on the same operands:
+    the split products are within 4e-5 of the result's maximum (f32 kernel: 2e-5), both forms, every epilogue operand in play."""
+    g = torch.Generator(device='cuda').manual_seed(M + K)
+    Ab = torch.randn(M, K + 3, device=cuda, generator=g); A = Ab[:, 1:K + 1] if K % 4 else Ab[:, :K]       # odd pitch / unaligned start
+    W = torch.randn(N, K, device=cuda, generator=g) * 0.05
+    bias = torch.randn(N, device=cuda, generator=g); rs = torch.rand(M, device=cuda, generator=g) + 0.5; resid = torch.randn(M, N, device=cuda, generator=g)
+    ref = (A.double() @ W.double().t() + bias.double()) * rs.double()[:, None] + resid.double()
+    c3 = ops.gemm_nt(ops.F32X3, A, W, torch.empty(M, N, device=cuda), bias=bias, row_scale=rs, resid=resid)
+    c1 = ops.gemm_nt(ops.F32, A, W, torch.empty(M, N, device=cuda), bias=bias, row_scale=rs, resid=resid)
+    assert rel(c3, ref) < 4e-5 and rel(c1, ref) < 2e-5
+    dY = torch.randn(M, N, device=cuda, generator=g)
+    dW = ops.gemm_tn(ops.F32X3, dY, A, torch.empty(N, K, device=cuda))
+    assert rel(dW, dY.double().t() @ A.double()) < 2e-5
+    # structure of the error: a plain bf16 product of the same operands is two orders of magnitude further away
+    cb = ops.gemm_nt(ops.BF16, A.contiguous().bfloat16(), W.bfloat16(), torch.empty(M, N, device=cuda)) if K % 64 == 0 else None
+    if cb is not None:
+        r0 = A.double() @ W.double().t()
+        assert rel(cb, r0) > 30 * rel(ops.gemm_nt(ops.F32X3, A, W, torch.empty(M, N, device=cuda)), r0)
 
 
 def test_gemm_rejects_bad_arguments(ops, cuda):

@@ -1,6 +1,7 @@
 """GPU: the drop-in Seeker on libtcow_hip against the golden vectors of the real reference, and against the properties
 the domain offers at full size.  Stated tolerances (north_star: mask-logit max|d| < 1e-3 vs the fp32 reference):
   fp32 mode : max|d| < 1e-5 asserted (measured 7e-8 ... 3e-6 over all goldens) -- the parity mode, 100x inside the north-star bound.
+  bf16x3    : max|d| < 1e-4 asserted (measured 5e-7 ... 1.1e-5): the fp32 mode with split-bf16 GEMM products, 10x inside the bound.
   bf16 mode : max|d| < 0.05 x the golden's logit std asserted = 1.5 x the worst measured ratio (0.013 ... 0.034 x std over 13 goldens,
               tools/dev_bf16_ratios.py; 3.4e-3 absolute at BASELINE configs[1], logit std 0.154); flags < 0.012 x their std (measured
               <= 0.0077).  bf16 operands cannot reach 1e-3 at these logit scales: profiles/r02_bf16_error_budget.txt (weight copies alone
@@ -16,6 +17,8 @@ from tcow_amd import synth
 pytestmark = pytest.mark.gpu
 
 FP32_TOL = 1e-5
+X3_TOL = 1e-4        # precision='bf16x3' (f32 storage, GEMM products as three bf16 MFMAs): measured 5e-7 ... 1.1e-5 over the goldens
+EXACT = {'fp32': FP32_TOL, 'bf16x3': X3_TOL}
 
 
 def bf16_tol(ref):
@@ -40,19 +43,19 @@ def _run(name, precision, grad=False):
 
 
 @pytest.mark.parametrize('name', ['g1_cfg1_d256', 'g2_ca0', 'g2_ca2', 'g2_ca3', 'g2_cam1', 'g2_normemb_nearest', 'g2_stride1_prenorm', 'g2_stride2'])
-@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+@pytest.mark.parametrize('precision', ['fp32', 'bf16', 'bf16x3'])
 def test_forward_vs_reference_golden(cuda, name, precision):
     meta, g, net, om, fl = _run(name, precision)
     assert om.dtype == torch.float32 and tuple(om.shape) == g['output_mask'].shape and tuple(fl.shape) == g['output_flags'].shape
     d = np.abs(om.cpu().numpy() - g['output_mask']).max()
     df = np.abs(fl.cpu().numpy() - g['output_flags']).max()
-    if precision == 'fp32':
-        assert d < FP32_TOL and df < FP32_TOL
+    if precision in EXACT:
+        assert d < EXACT[precision] and df < EXACT[precision]
     else:
         assert d < bf16_tol(g['output_mask']) and df < bf16_flags_tol(g['output_flags'])
 
 
-@pytest.mark.parametrize('precision,tol', [('fp32', 2e-4), ('bf16', 4e-2)])
+@pytest.mark.parametrize('precision,tol', [('fp32', 2e-4), ('bf16', 4e-2), ('bf16x3', 2e-4)])
 def test_gradients_vs_reference_golden(cuda, precision, tol):
     meta, g, net, om, fl = _run('g1_cfg1_d256', precision, grad=True)
     Gm = torch.from_numpy(synth._rng(meta['seed'], 'gradprobe_mask').standard_normal(size=tuple(om.shape), dtype=np.float32)).cuda()
@@ -71,20 +74,20 @@ def test_gradients_vs_reference_golden(cuda, precision, tol):
 
 
 @pytest.mark.parametrize('name', ['g3_mid_T8_96x128', 'g4_cfg2_T30_240x320'])
-@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+@pytest.mark.parametrize('precision', ['fp32', 'bf16', 'bf16x3'])
 def test_large_geometries_vs_reference_golden(cuda, name, precision):
     """Native 12-layer ViT-B Seeker at T=8 96x128 and at the full BASELINE configs[1] size (T=30, 240x320)."""
     meta, g, net, om, fl = _run(name, precision)
     pooled, fsum, fmax = summarise(om.cpu())
     d = np.abs(pooled - g['pooled']).max(); df = np.abs(fl.cpu().numpy() - g['output_flags']).max()
-    if precision == 'fp32':
-        assert d < FP32_TOL and df < FP32_TOL and np.abs(fmax - g['frame_absmax']).max() < FP32_TOL
+    if precision in EXACT:
+        assert d < EXACT[precision] and df < EXACT[precision] and np.abs(fmax - g['frame_absmax']).max() < EXACT[precision]
         assert np.abs(fsum - g['frame_sum']).max() < 0.5
     else:
         assert d < 0.05 * float(g['logit_std']) and df < bf16_flags_tol(g['output_flags'])
 
 
-@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+@pytest.mark.parametrize('precision', ['fp32', 'bf16', 'bf16x3'])
 @pytest.mark.parametrize('ca,leak', [(1, 0), (2, 0), (3, 2)])
 def test_causality_is_bit_exact_on_gpu(cuda, precision, ca, leak):
     """Perturbing frame t0 leaves every earlier output frame bit-identical (masked keys contribute exactly zero)."""
@@ -111,7 +114,7 @@ def _droppath_masks(g):
 
 
 @pytest.mark.parametrize('name', ['g12_droppath_ca1', 'g12_droppath_ca0'])
-@pytest.mark.parametrize('precision,tol,gtol', [('fp32', FP32_TOL, 2e-4), ('bf16', None, 4e-2)])
+@pytest.mark.parametrize('precision,tol,gtol', [('fp32', FP32_TOL, 2e-4), ('bf16', None, 4e-2), ('bf16x3', X3_TOL, 2e-4)])
 def test_droppath_forced_masks_vs_reference_train_mode(cuda, name, precision, tol, gtol):
     """K9b (vit_utils.py:139-164; vit.py:172-174,186,216,272-273): the keep masks the REFERENCE drew in train mode (golden g12) are
     forced into the HIP engine; outputs and gradients must equal the reference's -- temporal DropPath per site before temporal_fc (a
@@ -122,7 +125,7 @@ def test_droppath_forced_masks_vs_reference_train_mode(cuda, name, precision, to
     net.seeker.forced_drop_masks = _droppath_masks(g)
     om, fl = net(rgb.cuda(), qm.cuda())
     d = np.abs(om.detach().cpu().numpy() - g['output_mask']).max(); df = np.abs(fl.detach().cpu().numpy() - g['output_flags']).max()
-    if precision == 'fp32':
+    if precision in EXACT:
         assert d < tol and df < tol
     else:
         assert d < bf16_tol(g['output_mask']) and df < bf16_flags_tol(g['output_flags'])
@@ -143,7 +146,7 @@ def test_droppath_forced_masks_vs_reference_train_mode(cuda, name, precision, to
     assert float((plain - om.detach()).abs().max()) > 1e-3
 
 
-@pytest.mark.parametrize('precision,tol', [('fp32', 3e-4), ('bf16', 5e-2)])
+@pytest.mark.parametrize('precision,tol', [('fp32', 3e-4), ('bf16', 5e-2), ('bf16x3', 6e-4)])
 def test_full_size_gradients_vs_reference_golden(cuda, precision, tol):
     """BASELINE configs[1] at full size with the Qs = 3 queries batched (M = 27 090 rows: the 320-tile GEMMs, streaming attention
     and 256-tile weight-gradient kernels the benchmark runs) against gradients of the REAL reference (golden g7: three sequential
@@ -161,8 +164,8 @@ def test_full_size_gradients_vs_reference_golden(cuda, precision, tol):
     om, fl = net(rgb, qm)
     pooled, _, _ = summarise(om.detach().cpu())
     d = np.abs(pooled - g['pooled']).max(); df = np.abs(fl.detach().cpu().numpy() - g['output_flags']).max()
-    if precision == 'fp32':
-        assert d < FP32_TOL and df < FP32_TOL
+    if precision in EXACT:
+        assert d < EXACT[precision] and df < EXACT[precision]
     else:
         assert d < 0.05 * float(g['logit_std'])
     Gm = torch.cat([torch.from_numpy(synth._rng(meta['seed'], f'g7_mask_{q}').standard_normal(size=(1,) + tuple(om.shape[1:]), dtype=np.float32)) for q in range(Qs)]).cuda()
@@ -186,7 +189,7 @@ def test_full_size_gradients_vs_reference_golden(cuda, precision, tol):
             assert abs(float(named[k].grad.norm()) - n) <= tol * n + 1e-7, (k, float(named[k].grad.norm()), n)
 
 
-@pytest.mark.parametrize('precision', ['bf16', 'fp32'])
+@pytest.mark.parametrize('precision', ['bf16', 'fp32', 'bf16x3'])
 def test_config3_long_clip_vs_reference_golden(cuda, precision):
     """BASELINE configs[3]: T=60, 480x640 (1200 spatial x 60 temporal tokens, S = 1201), inference forward, against the reference's
     output on the same synthetic clip (golden g8: pooled logits of six frames, per-frame sums / abs-max, flags)."""
@@ -199,11 +202,11 @@ def test_config3_long_clip_vs_reference_golden(cuda, precision):
     pooled, fsum, fmax = summarise(om.cpu())
     pooled = pooled.reshape(60, 3, 120, 160)[g['frames']]
     d = np.abs(pooled - g['pooled_frames']).max(); df = np.abs(fl.cpu().numpy() - g['output_flags']).max()
-    if precision == 'fp32':
-        assert d < FP32_TOL and df < FP32_TOL and np.abs(fmax - g['frame_absmax']).max() < FP32_TOL
+    if precision in EXACT:
+        assert d < EXACT[precision] and df < EXACT[precision] and np.abs(fmax - g['frame_absmax']).max() < EXACT[precision]
     else:
         assert d < 0.05 * float(g['logit_std']) and df < bf16_flags_tol(g['output_flags'])
-    assert abs(float((om > 0).float().mean()) - float(g['positive_frac'])) < (1e-5 if precision == 'fp32' else 5e-3)
+    assert abs(float((om > 0).float().mean()) - float(g['positive_frac'])) < ({'fp32': 1e-5, 'bf16x3': 1e-4}.get(precision, 5e-3))
 
 
 @pytest.mark.parametrize('precision', ['bf16', 'fp32'])
@@ -245,7 +248,7 @@ def test_config4_batched_eval_vs_reference_golden(cuda, precision):
 
 
 @pytest.mark.parametrize('name', ['g11_depth18', 'g11_depth24'])
-@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+@pytest.mark.parametrize('precision', ['fp32', 'bf16', 'bf16x3'])
 def test_depth_18_and_24_vs_reference_golden(cuda, name, precision):
     """V0 (vit.py:433-447): D = 896 / 14 heads / 18 blocks and D = 1024 / 16 heads / 24 blocks through Seeker(network_depth=...)."""
     meta, g = load_golden(name)
@@ -259,8 +262,8 @@ def test_depth_18_and_24_vs_reference_golden(cuda, name, precision):
     with torch.no_grad():
         om, fl = net(rgb.cuda(), qm.cuda())
     d = np.abs(om.cpu().numpy() - g['output_mask']).max(); df = np.abs(fl.cpu().numpy() - g['output_flags']).max()
-    if precision == 'fp32':
-        assert d < FP32_TOL and df < FP32_TOL
+    if precision in EXACT:
+        assert d < EXACT[precision] and df < EXACT[precision]
     else:
         assert d < bf16_tol(g['output_mask']) and df < bf16_flags_tol(g['output_flags'])
 
