@@ -313,10 +313,16 @@ long tcow_attn_mfma_bwd_workspace_bytes(const SeqDesc& d);
 int tcow_attn_mfma_bwd(hipStream_t st, const SeqDesc& d, bool shared, const void* qkv, const void* out, const void* dout, const float* lse, void* ws,
                        void* dqkv);
 
-// TCOW_ATTN_SIMPLE=1 forces the f32-arithmetic kernels for bf16 storage as well (A/B checks of the MFMA kernels)
+int tcow_attn_f32_fwd(hipStream_t st, const SeqDesc& d, const void* qkv, void* out, float* lse);
+int tcow_attn_f32_bwd(hipStream_t st, const SeqDesc& d, const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv);
+
+// TCOW_ATTN_SIMPLE=1 forces the one-thread-per-query VALU kernels for both storage types (A/B checks of the MFMA kernels)
+static bool force_simple() {
+    static const bool f = getenv("TCOW_ATTN_SIMPLE") != nullptr && getenv("TCOW_ATTN_SIMPLE")[0] == '1';
+    return f;
+}
 static bool use_mfma(const tcow_attn_shape* s, const SeqDesc& d, int spatial) {
-    static const bool force_simple = getenv("TCOW_ATTN_SIMPLE") != nullptr && getenv("TCOW_ATTN_SIMPLE")[0] == '1';
-    return s->dtype == TCOW_BF16 && !force_simple && tcow_attn_mfma_supported(d, spatial != 0);
+    return s->dtype == TCOW_BF16 && !force_simple() && tcow_attn_mfma_supported(d, spatial != 0);
 }
 
 int tcow_attn_fwd_dispatch(hipStream_t st, const tcow_attn_shape* s, int spatial, const void* qkv, void* out, float* lse) {
@@ -327,6 +333,7 @@ int tcow_attn_fwd_dispatch(hipStream_t st, const tcow_attn_shape* s, int spatial
         if (rc) return rc;
     }
     if (use_mfma(s, d, spatial)) return tcow_attn_mfma_fwd(st, d, spatial != 0, qkv, out, lse);
+    if (s->dtype == TCOW_F32 && !force_simple()) return tcow_attn_f32_fwd(st, d, qkv, out, lse);      // exact-f32 MFMA kernels (attention_f32.hip)
     return (s->dtype == TCOW_BF16) ? launch_fwd<bf16_t>(st, d, qkv, out, lse) : launch_fwd<float>(st, d, qkv, out, lse);
 }
 
@@ -352,6 +359,7 @@ int tcow_attn_bwd_dispatch(hipStream_t st, const tcow_attn_shape* s, int spatial
         if (rc) return rc;
     }
     if (use_mfma(s, d, spatial)) return tcow_attn_mfma_bwd(st, d, spatial != 0, qkv, out, dout, lse, ws, dqkv);
+    if (s->dtype == TCOW_F32 && !force_simple()) return tcow_attn_f32_bwd(st, d, qkv, out, dout, lse, (float*)ws, dqkv);
     return (s->dtype == TCOW_BF16) ? launch_bwd<bf16_t>(st, d, rows, qkv, out, dout, lse, (float*)ws, dqkv)
                                    : launch_bwd<float>(st, d, rows, qkv, out, dout, lse, (float*)ws, dqkv);
 }
