@@ -100,6 +100,21 @@ int tcow_gemm_tn(void* stream, int dtype, int M, int N, int K, const void* dY, l
                  long ldx, float* dW, long lddw, float* bias_grad, int accumulate, void* workspace,
                  long workspace_bytes);
 
+/* The same for several Linear layers at once (the weight gradients of one transformer block, train.py:98's backward through
+ * vit.py:50-61,74-76,146): in bf16 mode, problems that share M run as ONE grid with a common, much smaller number of token slices
+ * (see gemm_bf16.hip: gemm_tn_bf16_256_group_kernel); otherwise the call is a loop over tcow_gemm_tn.  Results are identical in
+ * meaning to n calls of tcow_gemm_tn (f32 summation order over the token slices differs). */
+typedef struct {
+    int M, N, K;
+    const void* dY; long ldy;
+    const void* X; long ldx;
+    float* dW; long lddw;
+    float* bias_grad;      /* may be NULL */
+    int accumulate;
+} tcow_tn_problem;
+long tcow_gemm_tn_grouped_workspace_bytes(int dtype, int n, const tcow_tn_problem* problems);
+int tcow_gemm_tn_grouped(void* stream, int dtype, int n, const tcow_tn_problem* problems, void* workspace, long workspace_bytes);
+
 /* ------------------------------------------------------------------------------------------- LayerNorm
  * y = (x - mean) / sqrt(var + eps) * gamma + beta over the last dimension of the f32 residual stream
  * (nn.LayerNorm(D, eps=1e-6): vit.py:135 norm1, :142 temporal_norm1, :150 norm2, :283 norm; eps vit.py:428).

@@ -30,6 +30,12 @@ class GemmArgs(ctypes.Structure):
                 ('ldr', ctypes.c_long), ('act', ctypes.c_int), ('aux', ctypes.c_void_p), ('ldaux', ctypes.c_long), ('tile', ctypes.c_int)]
 
 
+class TnProblem(ctypes.Structure):
+    _fields_ = [('M', ctypes.c_int), ('N', ctypes.c_int), ('K', ctypes.c_int),
+                ('dY', ctypes.c_void_p), ('ldy', ctypes.c_long), ('X', ctypes.c_void_p), ('ldx', ctypes.c_long),
+                ('dW', ctypes.c_void_p), ('lddw', ctypes.c_long), ('bias_grad', ctypes.c_void_p), ('accumulate', ctypes.c_int)]
+
+
 class MaskLossArgs(ctypes.Structure):
     _fields_ = [('n_frames', ctypes.c_long), ('frame_len', ctypes.c_long), ('frames_per_seq', ctypes.c_long),
                 ('logits', ctypes.c_void_p), ('logits_seq_stride', ctypes.c_long),
@@ -55,6 +61,8 @@ SIGNATURES = {
     'tcow_prof_gemm_end': (_i, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long)]),
     'tcow_gemm_tn_workspace_bytes': (_l, [_i, _i, _i]),
     'tcow_gemm_tn': (_i, [_vp, _i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _vp, _i, _vp, _l]),
+    'tcow_gemm_tn_grouped_workspace_bytes': (_l, [_i, _i, _vp]),
+    'tcow_gemm_tn_grouped': (_i, [_vp, _i, _i, _vp, _vp, _l]),
     'tcow_layernorm_fwd': (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _vp, _f, _vp, _l, _vp, _vp]),
     'tcow_layernorm_bwd_workspace_bytes': (_l, [_i]),
     'tcow_layernorm_bwd': (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _l, _vp, _vp, _vp, _vp, _l, _vp, _l, _vp, _vp, _i, _vp, _l, _vp, _l, _vp]),

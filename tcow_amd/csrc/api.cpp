@@ -39,6 +39,11 @@ int tcow_gemm_tn_f32(hipStream_t stream, int M, int N, int K, const float* dY, l
 int tcow_gemm_nt_x3(hipStream_t stream, const tcow_gemm_args* a);
 int tcow_gemm_tn_x3(hipStream_t stream, int M, int N, int K, const float* dY, long ldy, const float* X, long ldx, float* dW, long lddw, int accumulate,
                     float* slab, int splits);
+int tcow_tn_group_max(void);
+bool tcow_tn_group_ok(int n, const tcow_tn_problem* pr);
+int tcow_tn_group_slices(int n, const tcow_tn_problem* pr);
+int tcow_gemm_tn_bf16_group(hipStream_t stream, int n, const tcow_tn_problem* pr, int nz_req, float* const* slabs, float* const* bias_parts, int* nz_out,
+                            int* bias_nparts);
 int tcow_tn_splits(int M, int N, int K, int tile_outputs);
 int tcow_tn_splits_x3(int M, int N, int K);
 int tcow_tn_splits_256(int M, int N, int K);
@@ -50,7 +55,7 @@ int tcow_launch_colsum(hipStream_t stream, int dtype, const void* Y, long ldy, i
 
 extern "C" {
 
-int tcow_version(void) { return 3; }
+int tcow_version(void) { return 4; }
 const char* tcow_last_error(void) { return g_err; }
 
 // ---- optional low-overhead HIP-event timing of the dominant kernel (the NT GEMM), on the launch stream
@@ -158,6 +163,53 @@ int tcow_gemm_tn(void* stream, int dtype, int M, int N, int K, const void* dY, l
     }
     if (bias_grad) {
         rc = tcow_launch_colsum((hipStream_t)stream, dtype == TCOW_BF16 ? TCOW_BF16 : TCOW_F32, dY, ldy, M, N, bias_grad, accumulate, part, 64);
+        if (rc) return rc;
+    }
+    return TCOW_OK;
+}
+
+// ---- grouped weight gradients
+static long tn_group_bytes(int n, const tcow_tn_problem* pr, int nz) {
+    long b = 256;
+    for (int i = 0; i < n; ++i) b += ((long)nz * pr[i].N * pr[i].K + (long)nz * ((pr[i].K + 255) / 256) * 2 * pr[i].N) * 4 + 64;
+    return b;
+}
+
+long tcow_gemm_tn_grouped_workspace_bytes(int dtype, int n, const tcow_tn_problem* pr) {
+    if (n <= 0 || pr == nullptr) return 0;
+    long single = 0;
+    for (int i = 0; i < n; ++i) { const long b = tcow_gemm_tn_workspace_bytes(pr[i].M, pr[i].N, pr[i].K); if (b > single) single = b; }
+    if (dtype == TCOW_BF16 && tcow_tn_group_ok(n, pr)) { const long g = tn_group_bytes(n, pr, tcow_tn_group_slices(n, pr) + 1); if (g > single) single = g; }
+    return single;
+}
+
+int tcow_gemm_tn_grouped(void* stream, int dtype, int n, const tcow_tn_problem* pr, void* workspace, long workspace_bytes) {
+    TCOW_CHECK_ARG(n > 0 && pr && workspace, "tcow_gemm_tn_grouped: bad arguments");
+    TCOW_CHECK_ARG(workspace_bytes >= tcow_gemm_tn_grouped_workspace_bytes(dtype, n, pr), "tcow_gemm_tn_grouped: workspace too small (%ld < %ld)", workspace_bytes,
+                   tcow_gemm_tn_grouped_workspace_bytes(dtype, n, pr));
+    for (int i = 0; i < n; ++i)
+        TCOW_CHECK_ARG(pr[i].M > 0 && pr[i].N > 0 && pr[i].K > 0 && pr[i].dY && pr[i].X && pr[i].dW, "tcow_gemm_tn_grouped: bad problem %d", i);
+    if (!(dtype == TCOW_BF16 && tcow_tn_group_ok(n, pr))) {
+        for (int i = 0; i < n; ++i) {
+            const int rc = tcow_gemm_tn(stream, dtype, pr[i].M, pr[i].N, pr[i].K, pr[i].dY, pr[i].ldy, pr[i].X, pr[i].ldx, pr[i].dW, pr[i].lddw, pr[i].bias_grad,
+                                        pr[i].accumulate, workspace, workspace_bytes);
+            if (rc) return rc;
+        }
+        return TCOW_OK;
+    }
+    const int nz_req = tcow_tn_group_slices(n, pr);
+    float* slabs[8]; float* parts[8]; int nparts[8];
+    char* w = (char*)workspace;
+    for (int i = 0; i < n; ++i) {
+        slabs[i] = (float*)w; w += (long)(nz_req + 1) * pr[i].N * pr[i].K * 4;
+        parts[i] = pr[i].bias_grad ? (float*)w : nullptr; w += (long)(nz_req + 1) * ((pr[i].K + 255) / 256) * 2 * pr[i].N * 4 + 64;
+    }
+    int nz = 0;
+    int rc = tcow_gemm_tn_bf16_group((hipStream_t)stream, n, pr, nz_req, slabs, parts, &nz, nparts);
+    if (rc) return rc;
+    for (int i = 0; i < n; ++i) {
+        rc = tcow_launch_slab_reduce((hipStream_t)stream, slabs[i], nz, (long)pr[i].N * pr[i].K, pr[i].N, pr[i].K, pr[i].dW, pr[i].lddw, pr[i].accumulate,
+                                     parts[i], parts[i] ? nparts[i] : 0, pr[i].N, pr[i].bias_grad);
         if (rc) return rc;
     }
     return TCOW_OK;

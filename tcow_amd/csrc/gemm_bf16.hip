@@ -1019,13 +1019,12 @@ __device__ __forceinline__ bf16x8 tr_frag512(const char* tile, int off0) {
 }
 
 namespace {
-__global__ __launch_bounds__(512, 2) void gemm_tn_bf16_256_kernel(TnParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+// one workgroup of the 256-tile weight-gradient GEMM `p`: pid = slice * tiles + tile
+__device__ __forceinline__ void tn256_body(const TnParams& p, const int pid, char* smem) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     const int ntile = p.tiles_n * p.tiles_k;
-    const int pid = xcd_remap(blockIdx.x, gridDim.x);
     const int z = pid / ntile, tile = pid - z * ntile;
     const int pn = tile / p.tiles_k, pk = tile - pn * p.tiles_k;
     const int n0 = pn * T2, k0 = pk * T2;
@@ -1180,6 +1179,26 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_bf16_256_kernel(TnParams p) {
         }
 }
 
+__global__ __launch_bounds__(512, 2) void gemm_tn_bf16_256_kernel(TnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    tn256_body(p, xcd_remap(blockIdx.x, gridDim.x), smem);
+}
+
+// Grouped launch: the weight gradients of ONE transformer block (7 Linear layers, 153 tiles of 256 x 256 at ViT-B) as one grid.  Launched
+// one by one, a 768 x 768 weight has 9 tiles and needs 28 token slices to fill the chip -- 66 MB of f32 partials written and read back per
+// GEMM (11.5 GB per training step), a fold launch each, and a ramp / tail per launch.  Together the tiles fill three rounds with FIVE slices:
+// every workgroup walks 5 418 token rows, the partials shrink 5x and one launch replaces seven.
+constexpr int TN_GROUP_MAX = 8;
+struct TnGroup { int n; int first[TN_GROUP_MAX + 1]; TnParams p[TN_GROUP_MAX]; };
+__global__ __launch_bounds__(512, 2) void gemm_tn_bf16_256_group_kernel(TnGroup g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int pid = xcd_remap(blockIdx.x, gridDim.x);
+    int k = 0;
+    while (k + 1 < g.n && pid >= g.first[k + 1]) ++k;           // workgroup-uniform
+    const TnParams p = g.p[k];
+    tn256_body(p, pid - g.first[k], smem);
+}
+
 }  // namespace
 
 // slices for the 256-tile kernel: as many as fit one round of workgroups (<= 256), at least 256 token rows each
@@ -1227,6 +1246,56 @@ int tcow_gemm_tn_bf16(hipStream_t stream, int M, int N, int K, const bf16_t* dY,
     const dim3 grid(8 * cdiv(nz, 8) * p.tiles_n * p.tiles_k);
     if (mc == 32) hipLaunchKernelGGL(gemm_tn_bf16_kernel<32>, grid, dim3(256), 32768, stream, p);
     else hipLaunchKernelGGL(gemm_tn_bf16_kernel<64>, grid, dim3(256), 65536, stream, p);
+    TCOW_CHECK_LAUNCH();
+    return TCOW_OK;
+}
+
+// ---- grouped weight-gradient launch (see gemm_tn_bf16_256_group_kernel).  All problems share M and the slice count nz.
+int tcow_tn_group_max(void) { return TN_GROUP_MAX; }
+bool tcow_tn_group_ok(int n, const tcow_tn_problem* pr) {
+    if (n < 2 || n > TN_GROUP_MAX) return false;
+    for (int i = 0; i < n; ++i) {
+        if (pr[i].M != pr[0].M || !tcow_tn_use_256(pr[i].M, pr[i].N, pr[i].K)) return false;
+        if (pr[i].N % 8 || pr[i].K % 8 || pr[i].ldy % 8 || pr[i].ldx % 8) return false;
+    }
+    return true;
+}
+// common slice count: the smallest one whose tiles x slices fill whole rounds of 256 workgroups best (>= 256 token rows per slice)
+int tcow_tn_group_slices(int n, const tcow_tn_problem* pr) {
+    int tiles = 0;
+    for (int i = 0; i < n; ++i) tiles += cdiv(pr[i].N, T2) * cdiv(pr[i].K, T2);
+    int max_s = pr[0].M / 256; if (max_s > 64) max_s = 64; if (max_s < 1) max_s = 1;
+    int best = 1; double best_eff = -1.0;
+    for (int s = 1; s <= max_s; ++s) {
+        const int wg = s * tiles, rounds = cdiv(wg, 256);
+        const double eff = (double)wg / (rounds * 256.0);
+        if (eff > best_eff + 0.01) { best_eff = eff; best = s; }
+    }
+    return best;
+}
+int tcow_gemm_tn_bf16_group(hipStream_t stream, int n, const tcow_tn_problem* pr, int nz_req, float* const* slabs, float* const* bias_parts, int* nz_out,
+                            int* bias_nparts) {
+    TnGroup g;
+    g.n = n;
+    int first = 0, nz = 0;
+    for (int i = 0; i < n; ++i) {
+        TnParams& p = g.p[i];
+        p.M = pr[i].M; p.N = pr[i].N; p.K = pr[i].K; p.dY = (const bf16_t*)pr[i].dY; p.ldy = pr[i].ldy; p.X = (const bf16_t*)pr[i].X; p.ldx = pr[i].ldx;
+        p.slab = slabs[i];
+        p.tiles_n = cdiv(p.N, T2); p.tiles_k = cdiv(p.K, T2);
+        int mps = cdiv(p.M, nz_req); mps = ((mps + 63) / 64) * 64;
+        p.mps = mps; p.nz = cdiv(p.M, mps); nz = p.nz;
+        p.bias_part = bias_parts[i];
+        p.rows_per_pk = cdiv(T2_MC, p.tiles_k);
+        bias_nparts[i] = p.nz * p.tiles_k * 2;
+        g.first[i] = first;
+        first += p.nz * p.tiles_n * p.tiles_k;
+    }
+    g.first[n] = first;
+    for (int i = n + 1; i <= TN_GROUP_MAX; ++i) g.first[i] = first;
+    *nz_out = nz;
+    tcow_ensure_lds(reinterpret_cast<const void*>(gemm_tn_bf16_256_group_kernel), T2_LDS);
+    hipLaunchKernelGGL(gemm_tn_bf16_256_group_kernel, dim3(first), dim3(512), T2_LDS, stream, g);
     TCOW_CHECK_LAUNCH();
     return TCOW_OK;
 }

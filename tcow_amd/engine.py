@@ -412,10 +412,20 @@ def run_backward(module, sv, params, d_mask, d_flags):
     def galloc(idx):
         return grads[idx]
 
-    def linear_bwd(idx_w, dY, Xin):
+    pending = []          # weight-gradient GEMMs of the current block, issued together at its end (one grouped launch, ops.gemm_tn_grouped)
+
+    def linear_bwd(idx_w, dY, Xin, defer=False):
         """dW, db of a Linear whose output-gradient operand is dY [M,N] and input operand Xin [M,K]."""
         dW = galloc(idx_w); db = galloc(idx_w + 1)
-        ops.gemm_tn(gmode, dY, Xin, dW.reshape(dW.shape[0], -1), bias_grad=db)
+        if defer:
+            pending.append((dY, Xin, dW.reshape(dW.shape[0], -1), db))
+        else:
+            ops.gemm_tn(gmode, dY, Xin, dW.reshape(dW.shape[0], -1), bias_grad=db)
+
+    def flush_pending():
+        if pending:
+            ops.gemm_tn_grouped(gmode, pending)
+            pending.clear()
 
     BP, ix = _layout(module)
     joint = module.attention_type != 'divided_space_time'
@@ -476,10 +486,10 @@ def run_backward(module, sv, params, d_mask, d_flags):
             ops.scale_cast(mode, dR3, dp['m'], G3)
         dpre = E(M, Hd)
         ops.gemm_nt(gmode, G3, Wt(q[ix['fc2']]), dpre, act=ACT_MUL_AUX, aux=st['pre'])
-        linear_bwd(o + ix['fc2'], G3, st['H'])
+        linear_bwd(o + ix['fc2'], G3, st['H'], defer=True)
         dWn = E(M, D)
         ops.gemm_nt(gmode, dpre, Wt(q[ix['fc1']]), dWn)
-        linear_bwd(o + ix['fc1'], dpre, st['Wn'])
+        linear_bwd(o + ix['fc1'], dpre, st['Wn'], defer=True)
         dR2 = E(M, D, dtype=f32)
         ops.layernorm_bwd(mode, dWn, st['R2'], st['mu2'], st['rs2'], q[ix['n2']].detach(), dR3, dR2, galloc(o + ix['n2']), galloc(o + ix['n2'] + 1))
         del G3, dpre, dWn
@@ -490,7 +500,7 @@ def run_backward(module, sv, params, d_mask, d_flags):
         ops.scale_cast(mode, dR2, st['rs_s'], G2)
         dO2 = E(M, D)
         ops.gemm_nt(gmode, G2, Wt(q[ix['proj']]), dO2)
-        linear_bwd(o + ix['proj'], G2, st['O_s'])
+        linear_bwd(o + ix['proj'], G2, st['O_s'], defer=True)
         if joint:
             dQJ = E(B * Lj, 3 * D)
             ops.attn_bwd(shape_joint, True, st['QKV_s'], st['OJ'], dO2.index_select(0, jrows), st['lse_s'], dQJ)
@@ -501,7 +511,7 @@ def run_backward(module, sv, params, d_mask, d_flags):
             ops.attn_bwd(shape_attn, True, st['QKV_s'], st['O_s'], dO2, st['lse_s'], dQKV2)
         dV = E(M, D)
         ops.gemm_nt(gmode, dQKV2, Wt(q[ix['qkv']]), dV)
-        linear_bwd(o + ix['qkv'], dQKV2, st['V'])
+        linear_bwd(o + ix['qkv'], dQKV2, st['V'], defer=True)
         dR1 = E(M, D, dtype=f32)
         G1 = E(M, D)                           # bf16(dR1 * row scale), written by the same LayerNorm backward pass
         ops.layernorm_bwd(mode, dV, st['R1'], st['mu1'], st['rs1'], q[ix['n1']].detach(), dR2, dR1, galloc(o + ix['n1']), galloc(o + ix['n1'] + 1), dx_cast=G1,
@@ -514,20 +524,21 @@ def run_backward(module, sv, params, d_mask, d_flags):
             # ---- temporal
             dPj = E(M, D)
             ops.gemm_nt(gmode, G1, Wt(q[ix['tfc']]), dPj, row_scale=dp['t'])
-            linear_bwd(o + ix['tfc'], G1, st['Pj'])
+            linear_bwd(o + ix['tfc'], G1, st['Pj'], defer=True)
             dO = E(M, D)
             ops.gemm_nt(gmode, dPj, Wt(q[ix['tproj']]), dO)
-            linear_bwd(o + ix['tproj'], dPj, st['O_t'])
+            linear_bwd(o + ix['tproj'], dPj, st['O_t'], defer=True)
             dQKV = E(M, 3 * D)
             ops.attn_bwd(shape_attn, False, st['QKV_t'], st['O_t'], dO, st['lse_t'], dQKV)
             dU = E(M, D)
             ops.gemm_nt(gmode, dQKV, Wt(q[ix['tqkv']]), dU)
-            linear_bwd(o + ix['tqkv'], dQKV, st['U'])
+            linear_bwd(o + ix['tqkv'], dQKV, st['U'], defer=True)
             dR0 = E(M, D, dtype=f32)
             G3_next = E(M, D)                  # operand of the next (lower) block's MLP backward, or of the patch-embed weight gradient
             ops.layernorm_bwd(mode, dU, st['R0'], st['mu0'], st['rs0'], q[ix['tn']].detach(), dR1, dR0, galloc(o + ix['tn']), galloc(o + ix['tn'] + 1),
                               dx_cast=G3_next, cast_scale=next_scale)
             dR3 = dR0
+        flush_pending()          # the block's seven (joint: four) weight-gradient GEMMs as one grouped launch
         sv['blocks'][i] = None   # free this block's activations
         if module.grad_hook is not None:
             module.grad_hook(i, blk_flat)

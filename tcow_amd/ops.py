@@ -71,6 +71,19 @@ def gemm_tn(mode, dY, X, dW, bias_grad=None, accumulate=False):
     return dW
 
 
+def gemm_tn_grouped(mode, problems):
+    """Weight / bias gradients of several Linear layers in one call: problems = [(dY [M,N], X [M,K], dW [N,K] f32, bias_grad [N] or None), ...].
+    In bf16 mode problems that share M run as one grid (tcow_gemm_tn_grouped); the other modes loop inside the library."""
+    n = len(problems)
+    arr = (L.TnProblem * n)()
+    for i, (dY, X, dW, db) in enumerate(problems):
+        _need_cuda(dY, X, dW)
+        arr[i] = L.TnProblem(dY.shape[0], dY.shape[1], X.shape[1], dY.data_ptr(), dY.stride(0), X.data_ptr(), X.stride(0), dW.data_ptr(), dW.stride(0), _p(db), 0)
+    lib = L.lib()
+    ws = workspace(lib.tcow_gemm_tn_grouped_workspace_bytes(mode, n, arr), problems[0][0].device, 'tn')
+    L.check(lib.tcow_gemm_tn_grouped(_stream(), mode, n, arr, ws.data_ptr(), ws.numel()), 'tcow_gemm_tn_grouped')
+
+
 def layernorm_fwd(mode, x, gamma, beta, out, mean=None, rstd=None, eps=1e-6):
     rows, D = x.shape
     L.check(L.lib().tcow_layernorm_fwd(_stream(), mode, rows, D, x.data_ptr(), x.stride(0), gamma.data_ptr(), beta.data_ptr(), eps,

@@ -135,6 +135,33 @@ def test_gemm_x3_split_products(ops, cuda, M, K, N):
         assert rel(cb, r0) > 30 * rel(ops.gemm_nt(ops.F32X3, A, W, torch.empty(M, N, device=cuda)), r0)
 
 
+@pytest.mark.parametrize('M', [27090, 9030, 300])
+def test_gemm_tn_grouped_block_weights(ops, cuda, M):
+    """tcow_gemm_tn_grouped on the seven Linear layers of a divided space-time block (vit.py:50-61,74-76,146) at the benchmark's row count
+    (one grid, common slice count), at a smaller M and at one too small for the 256-tile kernel (the library loops there): every dW / db
+    against the f64 product and against the one-by-one entry point."""
+    D = 768
+    shapes = [(D, 4 * D), (4 * D, D), (D, D), (3 * D, D), (D, D), (D, D), (3 * D, D)]      # (N, K) of fc2, fc1, proj, qkv, tfc, tproj, tqkv
+    g = torch.Generator(device='cuda').manual_seed(M)
+    probs, refs = [], []
+    for i, (N, K) in enumerate(shapes):
+        dY = torch.randn(M, N, device=cuda, generator=g).bfloat16(); X = torch.randn(M, K, device=cuda, generator=g).bfloat16()
+        dW = torch.empty(N, K, device=cuda); db = torch.empty(N, device=cuda) if i != 2 else None
+        probs.append((dY, X, dW, db)); refs.append((dY.double().t() @ X.double(), dY.double().sum(0)))
+    ops.gemm_tn_grouped(ops.BF16, probs)
+    for (dY, X, dW, db), (rw, rb) in zip(probs, refs):
+        assert rel(dW, rw) < 1e-5
+        if db is not None:
+            assert rel(db, rb) < 1e-4
+        one = ops.gemm_tn(ops.BF16, dY, X, torch.empty_like(dW))
+        assert rel(dW, one) < 1e-5
+    # f32-storage modes go through the same entry point (library-side loop)
+    small = [(p[0][:257].float(), p[1][:257].float(), torch.empty_like(p[2]), None) for p in probs[2:4]]
+    ops.gemm_tn_grouped(ops.F32X3, small)
+    for dY, X, dW, _ in small:
+        assert rel(dW, dY.double().t() @ X.double()) < 2e-5
+
+
 def test_gemm_rejects_bad_arguments(ops, cuda):
     from tcow_amd._lib import TcowError
     A = torch.zeros(8, 72, device=cuda, dtype=torch.bfloat16); W = torch.zeros(8, 72, device=cuda, dtype=torch.bfloat16)
