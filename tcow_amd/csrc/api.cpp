@@ -51,6 +51,9 @@ bool tcow_tn_use_256(int M, int N, int K);
 int tcow_launch_slab_reduce(hipStream_t stream, const float* slab, int nz, long slab_stride, long rows, long cols, float* out, long ldo, int accumulate,
                             const float* bias_part, int bias_nparts, int bias_n, float* bias_out);
 int tcow_launch_row_reduce(hipStream_t stream, const float* part, int nrows, long ld, int N, float* out, int accumulate);
+bool tcow_fold_vec_ok(const float* slab, long slab_stride, long cols, float* out, long ldo);
+int tcow_launch_slab_reduce_group(hipStream_t stream, int n, const float* const* slab, int nz, const long* rows, const long* cols, float* const* out, const long* ldo,
+                                  const int* accumulate, const float* const* bias_part, const int* bias_nparts, float* const* bias_out);
 int tcow_launch_colsum(hipStream_t stream, int dtype, const void* Y, long ldy, int M, int N, float* out, int accumulate, float* part, int max_parts);
 
 extern "C" {
@@ -207,6 +210,16 @@ int tcow_gemm_tn_grouped(void* stream, int dtype, int n, const tcow_tn_problem* 
     int nz = 0;
     int rc = tcow_gemm_tn_bf16_group((hipStream_t)stream, n, pr, nz_req, slabs, parts, &nz, nparts);
     if (rc) return rc;
+    bool vec = true;
+    for (int i = 0; i < n; ++i) vec = vec && tcow_fold_vec_ok(slabs[i], (long)pr[i].N * pr[i].K, pr[i].K, pr[i].dW, pr[i].lddw);
+    if (vec) {       // one fold launch for the whole group
+        long rows[8], cols[8], ldo[8]; int acc[8]; float* outs[8]; float* bouts[8]; const float* cparts[8]; const float* cslabs[8];
+        for (int i = 0; i < n; ++i) {
+            rows[i] = pr[i].N; cols[i] = pr[i].K; ldo[i] = pr[i].lddw; acc[i] = pr[i].accumulate; outs[i] = pr[i].dW; bouts[i] = pr[i].bias_grad;
+            cparts[i] = parts[i]; cslabs[i] = slabs[i]; if (!parts[i]) nparts[i] = 0;
+        }
+        return tcow_launch_slab_reduce_group((hipStream_t)stream, n, cslabs, nz, rows, cols, outs, ldo, acc, cparts, nparts, bouts);
+    }
     for (int i = 0; i < n; ++i) {
         rc = tcow_launch_slab_reduce((hipStream_t)stream, slabs[i], nz, (long)pr[i].N * pr[i].K, pr[i].N, pr[i].K, pr[i].dW, pr[i].lddw, pr[i].accumulate,
                                      parts[i], parts[i] ? nparts[i] : 0, pr[i].N, pr[i].bias_grad);

@@ -99,12 +99,12 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slab, int nz, long 
 }
 // Workgroups [0, slab_blocks) fold the split-K slabs; the optional tail workgroups fold the bias-gradient partial table of the same
 // weight-gradient GEMM (4 columns x 16 row groups per 64-thread workgroup), so one launch finishes both.
-__global__ __launch_bounds__(64) void slab_reduce4_kernel(const float* __restrict__ slab, int nz, long slab_stride, long n4, float* __restrict__ out, long cols4, long ldo, int accumulate,
+__device__ __forceinline__ void slab_reduce4_body(const int bx, const float* __restrict__ slab, int nz, long slab_stride, long n4, float* __restrict__ out, long cols4, long ldo, int accumulate,
                                                           int slab_blocks, const float* __restrict__ part, int nparts, int N, float* __restrict__ bias_out) {
-    if ((int)blockIdx.x >= slab_blocks) {
+    if (bx >= slab_blocks) {
         __shared__ float red[16][4];
         const int cq = threadIdx.x & 3, g = threadIdx.x >> 2;
-        const int c = ((int)blockIdx.x - slab_blocks) * 4 + cq;
+        const int c = (bx - slab_blocks) * 4 + cq;
         float a = 0.f;
         if (c < N)
             for (int r = g; r < nparts; r += 16) a += part[(size_t)r * N + c];
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(64) void slab_reduce4_kernel(const float* __restric
         }
         return;
     }
-    long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    long i = bx * (long)blockDim.x + threadIdx.x;
     const long stride = (long)slab_blocks * blockDim.x;
     for (; i < n4; i += stride) {
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -133,6 +133,19 @@ __global__ __launch_bounds__(64) void slab_reduce4_kernel(const float* __restric
         if (accumulate) { const float4 p = ld4(o); s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w; }
         st4(o, s);
     }
+}
+
+__global__ __launch_bounds__(64) void slab_reduce4_kernel(const float* __restrict__ slab, int nz, long slab_stride, long n4, float* __restrict__ out, long cols4, long ldo, int accumulate,
+                                                          int slab_blocks, const float* __restrict__ part, int nparts, int N, float* __restrict__ bias_out) {
+    slab_reduce4_body(blockIdx.x, slab, nz, slab_stride, n4, out, cols4, ldo, accumulate, slab_blocks, part, nparts, N, bias_out);
+}
+// the folds of a grouped weight-gradient launch (tcow_gemm_tn_grouped) as one grid: blockIdx.y = job
+struct FoldJob { const float* slab; long slab_stride, n4, cols4, ldo; float* out; const float* part; float* bias_out; int nz, accumulate, slab_blocks, nparts, N, blocks; };
+struct FoldGroup { FoldJob j[8]; };
+__global__ __launch_bounds__(64) void slab_reduce4_group_kernel(FoldGroup g) {
+    const FoldJob j = g.j[blockIdx.y];
+    if ((int)blockIdx.x >= j.blocks) return;
+    slab_reduce4_body(blockIdx.x, j.slab, j.nz, j.slab_stride, j.n4, j.out, j.cols4, j.ldo, j.accumulate, j.slab_blocks, j.part, j.nparts, j.N, j.bias_out);
 }
 
 // out[c] (+)= sum_r part[r][c] for a tall-skinny partial table (many rows, few columns): 16 columns x 16 row groups per block
@@ -222,6 +235,30 @@ int tcow_launch_slab_reduce(hipStream_t stream, const float* slab, int nz, long 
         int blocks = cdiv(n, 256); if (blocks > 2048) blocks = 2048;
         hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, stream, slab, nz, slab_stride, n, out, rows, cols, ldo, accumulate);
     }
+    TCOW_CHECK_LAUNCH();
+    return TCOW_OK;
+}
+
+// n <= 8 folds in one launch; every job must satisfy the vector path's alignment rules (the caller checks with tcow_fold_vec_ok)
+bool tcow_fold_vec_ok(const float* slab, long slab_stride, long cols, float* out, long ldo) {
+    return (cols % 4 == 0) && (ldo % 4 == 0) && (slab_stride % 4 == 0) && ((reinterpret_cast<uintptr_t>(slab) | reinterpret_cast<uintptr_t>(out)) % 16 == 0);
+}
+int tcow_launch_slab_reduce_group(hipStream_t stream, int n, const float* const* slab, int nz, const long* rows, const long* cols, float* const* out, const long* ldo,
+                                  const int* accumulate, const float* const* bias_part, const int* bias_nparts, float* const* bias_out) {
+    FoldGroup g;
+    int gx = 0;
+    for (int i = 0; i < n; ++i) {
+        FoldJob& j = g.j[i];
+        const long nel = rows[i] * cols[i];
+        j.slab = slab[i]; j.slab_stride = nel; j.n4 = nel / 4; j.cols4 = cols[i] / 4; j.ldo = ldo[i]; j.out = out[i];
+        j.part = bias_part[i]; j.bias_out = bias_out[i]; j.nz = nz; j.accumulate = accumulate[i];
+        int blocks = cdiv(nel / 4, 64); if (blocks > 8192) blocks = 8192;
+        j.slab_blocks = blocks; j.nparts = bias_nparts[i]; j.N = (int)rows[i];
+        j.blocks = blocks + (bias_part[i] ? cdiv(rows[i], 4) : 0);
+        if (j.blocks > gx) gx = j.blocks;
+    }
+    for (int i = n; i < 8; ++i) g.j[i] = g.j[0];
+    hipLaunchKernelGGL(slab_reduce4_group_kernel, dim3(gx, n), dim3(64), 0, stream, g);
     TCOW_CHECK_LAUNCH();
     return TCOW_OK;
 }
