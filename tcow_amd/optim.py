@@ -91,8 +91,7 @@ class FusedAdamWClip(torch.optim.Optimizer):
         L.check(L.lib().tcow_adamw_clip_step(torch.cuda.current_stream().cuda_stream, self._table.data_ptr(), self._table.shape[0], float(grp['lr']),
                                              float(grp['betas'][0]), float(grp['betas'][1]), float(grp['eps']), float(grp['weight_decay']), step,
                                              float(self.max_norm or 0.0), self.scratch.data_ptr()), 'tcow_adamw_clip_step')
-        for p in live:
-            self.state[p]['step'] += 1           # CPU scalars, like torch.optim.AdamW keeps them
+        torch._foreach_add_([self.state[p]['step'] for p in live], 1)   # CPU scalars, like torch.optim.AdamW keeps them (one call, not 247)
         torch.autograd.graph.increment_version(live)   # the kernels wrote through raw pointers: make the update visible to version checks
         for cb in self.on_step:
             cb()
