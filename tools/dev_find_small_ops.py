@@ -19,8 +19,17 @@ def step(i):
 for i in range(3): step(i)
 torch.cuda.synchronize()
 from torch.profiler import profile, ProfilerActivity
-with profile(activities=[ProfilerActivity.CPU]) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
     step(3); torch.cuda.synchronize()
+# which of our source lines launch the tiny fill / copy kernels
+import re
+cnt = collections.Counter()
+for ev in prof.events():
+    if ev.name in ('aten::fill_', 'aten::zero_', 'aten::copy_', 'aten::zeros', 'aten::full', 'aten::ones') and ev.device_time_total > 0 or ev.name in ('aten::fill_',):
+        fr = [f for f in (ev.stack or []) if '/tcow_amd/' in f or 'bench' in f]
+        cnt[(ev.name, fr[0] if fr else (ev.stack[0] if ev.stack else '?'))] += 1
+for (n, f), c in cnt.most_common(30):
+    print(f'{c:4d} {n:14s} {f[:130]}')
 ka = prof.key_averages()
 rows = sorted(ka, key=lambda e: -e.count)
 for e in rows[:45]:
