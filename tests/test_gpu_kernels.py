@@ -112,7 +112,7 @@ def test_gemm_tn_weight_and_bias_grad(ops, cuda, mname, tol, M, N, K):
     assert rel(dW, 2 * ref) < max(tol / 4, 1e-5) and rel(db, 2 * dY.double().sum(0)) < 1e-4
 
 
-@pytest.mark.parametrize('M,K,N', [(27090, 768, 768), (27090, 3072, 768), (333, 100, 70), (257, 50, 129)])
+@pytest.mark.parametrize('M,K,N', [(27090, 768, 768), (27090, 3072, 768), (333, 100, 70), (257, 50, 129), (5, 8, 3), (1, 4, 1)])
 def test_gemm_x3_split_products(ops, cuda, M, K, N):
     """TCOW_F32X3 at the benchmark's row count and on ragged / unaligned shapes (K not a multiple of the 32-wide k-slice, K % 4 != 0:
     scalar loader; row views with an odd pitch) against the f64 product, next to the exact-f32 kernel on the same operands:
