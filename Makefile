@@ -7,8 +7,12 @@ HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wno-unused-result -ffp-
 SRCS := $(wildcard $(CSRC)/*.hip) $(wildcard $(CSRC)/*.cpp)
 OBJS := $(patsubst $(CSRC)/%,$(OBJ)/%.o,$(SRCS))
 LIB := tcow_amd/libtcow_hip.so
+# the same sources with the 16-bit storage format set to IEEE binary16 (csrc/common.h): precision='fp16'
+OBJ16 := build/obj_fp16
+OBJS16 := $(patsubst $(CSRC)/%,$(OBJ16)/%.o,$(SRCS))
+LIB16 := tcow_amd/libtcow_hip_fp16.so
 
-all: $(LIB)
+all: $(LIB) $(LIB16)
 
 # (attention: no NaN arithmetic on the path -- lets fmaxf chains become v_max3_f32 without canonicalising v_max instructions)
 $(OBJ)/attention_bf16.hip.o: EXTRA := -fno-honor-nans
@@ -23,6 +27,18 @@ $(OBJ)/%.cpp.o: $(CSRC)/%.cpp $(CSRC)/common.h include/tcow_hip.h
 $(LIB): $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
 
+$(OBJ16)/attention_bf16.hip.o: EXTRA := -fno-honor-nans
+$(OBJ16)/%.hip.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/gemm_f32.h include/tcow_hip.h
+	@mkdir -p $(OBJ16)
+	$(HIPCC) $(HIPFLAGS) $(EXTRA) -DTCOW_FP16 -x hip -c $< -o $@
+
+$(OBJ16)/%.cpp.o: $(CSRC)/%.cpp $(CSRC)/common.h include/tcow_hip.h
+	@mkdir -p $(OBJ16)
+	$(HIPCC) $(HIPFLAGS) -DTCOW_FP16 -x hip -c $< -o $@
+
+$(LIB16): $(OBJS16)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS16)
+
 clean:
-	rm -rf build $(LIB)
+	rm -rf build $(LIB) $(LIB16)
 .PHONY: all clean

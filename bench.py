@@ -28,7 +28,7 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=8)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32', 'bf16x3'])
+    ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp16', 'fp32', 'bf16x3'])
     ap.add_argument('--queries', type=int, default=3)
     ap.add_argument('--frames', type=int, default=30)
     ap.add_argument('--height', type=int, default=240)
@@ -47,18 +47,19 @@ class KernelTimer:
     """HIP-event timing of every NT-GEMM launch (the dominant kernel) inside the timed region, recorded by the library
     itself on the launch stream (tcow_prof_gemm_begin/_end: two hipEventRecord per launch, no Python in the loop)."""
 
-    def __init__(self):
+    def __init__(self, fmt='bf16'):
         from tcow_amd import _lib
         self.L = _lib
+        self.fmt = fmt             # which build of the library launches the GEMMs of this run ('fp16': libtcow_hip_fp16.so)
         self.result = None
 
     def begin(self, max_launches):
-        self.L.check(self.L.lib().tcow_prof_gemm_begin(int(max_launches)), 'tcow_prof_gemm_begin')
+        self.L.check(self.L.lib(self.fmt).tcow_prof_gemm_begin(int(max_launches)), 'tcow_prof_gemm_begin')
 
     def end(self):
         import ctypes
         ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_long()
-        self.L.check(self.L.lib().tcow_prof_gemm_end(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n)), 'tcow_prof_gemm_end')
+        self.L.check(self.L.lib(self.fmt).tcow_prof_gemm_end(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n)), 'tcow_prof_gemm_end')
         if n.value:
             self.result = dict(launches=n.value, avg_us=ms.value * 1e3 / n.value, flops_per_launch=fl.value / n.value,
                                tflops=fl.value / (ms.value * 1e-3) / 1e12)
@@ -117,10 +118,11 @@ def pmc_traffic():
 
 def parity_leg(make_trainer, bf16_net, ref_mask, args):
     """The precision story in the bench line (north_star: mask-logit max|d| < 1e-3 vs the reference):
+      * fp16_mode: the same training step with precision='fp16' (the benchmarked kernels compiled for IEEE binary16 storage: three more
+        significand bits at the same speed) -- the fastest mode inside the 1e-3 bound;
       * fp32_parity_mode: the same training step with precision='fp32' (exact-f32 MFMA / FMA kernels) timed over --parity-steps steps;
-      * bf16x3_mode: the same with precision='bf16x3' (f32 storage, GEMM products as three bf16 MFMAs on hi / lo operand splits) -- the
-        fastest mode inside the 1e-3 bound;
-      * max_abs_d: eval forward of all three modes on the cpu_baseline clip against the oracle's logits computed in this run."""
+      * bf16x3_mode: the same with precision='bf16x3' (f32 storage, GEMM products as three bf16 MFMAs on hi / lo operand splits) -- ~1e-5;
+      * max_abs_d: eval forward of all four modes on the cpu_baseline clip against the oracle's logits computed in this run."""
     from tcow_amd import synth
     out = {}
     clip = rgb = qm = sd = None
@@ -141,15 +143,17 @@ def parity_leg(make_trainer, bf16_net, ref_mask, args):
         net.load_state_dict(trained, strict=True); net.seeker.invalidate_weight_cache(); net.train()
 
     max_abs_d('bf16', bf16_net)
-    for key, precision, dtype in (('fp32_parity_mode', 'fp32', 'f32'), ('bf16x3_mode', 'bf16x3', 'f32 storage, bf16 x 3 GEMM products')):
+    for key, precision, dtype in (('fp16_mode', 'fp16', 'f16 (the bf16 kernels built for binary16 storage, static loss scale 2^14)'),
+                                  ('bf16x3_mode', 'bf16x3', 'f32 storage, bf16 x 3 GEMM products'), ('fp32_parity_mode', 'fp32', 'f32')):
         net, step = make_trainer(precision)
-        step(); torch.cuda.synchronize()
+        nsteps = args.parity_steps * (5 if precision == 'fp16' else 1)          # (a 37 ms step needs more repetitions than a 250 ms one)
+        step(); step(); torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(args.parity_steps):
+        for _ in range(nsteps):
             step()
         torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / args.parity_steps * 1e3
-        out[key] = dict(ms_per_step=ms, clips_s=1e3 / ms, steps=args.parity_steps, dtype=dtype)
+        ms = (time.perf_counter() - t0) / nsteps * 1e3
+        out[key] = dict(ms_per_step=ms, clips_s=1e3 / ms, steps=nsteps, dtype=dtype)
         max_abs_d(precision, net)
         del net, step
         torch.cuda.empty_cache()
@@ -230,7 +234,7 @@ def main():
         return net, step
 
     net, step = make_trainer(args.precision)
-    timer = KernelTimer()
+    timer = KernelTimer('fp16' if args.precision == 'fp16' else 'bf16')
 
     for _ in range(args.warmup):
         step()
@@ -257,15 +261,16 @@ def main():
         g = net.seeker.geometry(Qs)
         fl = flops.seeker_forward_flops(1, g['T'], g['Hp'], g['Wp'], g['D'], g['heads'], args.depth)
         ks = timer.summary()
-        peak = {'bf16': PEAK_BF16_TFLOPS, 'fp32': PEAK_F32_TFLOPS, 'bf16x3': PEAK_BF16_TFLOPS / 3.0}[args.precision]   # bf16x3: three MFMAs per product
-        traffic = pmc_traffic() if args.precision == 'bf16' else None
-        roof = dict(bound='mfma', kernel={'bf16': 'gemm_nt_bf16_320_kernel (+ gemm_nt_bf16_256_kernel, gemm_nt_bf16_kernel)', 'fp32': 'gemm_f32_kernel', 'bf16x3': 'gemm_x3_kernel'}[args.precision],
+        peak = {'bf16': PEAK_BF16_TFLOPS, 'fp16': PEAK_BF16_TFLOPS, 'fp32': PEAK_F32_TFLOPS, 'bf16x3': PEAK_BF16_TFLOPS / 3.0}[args.precision]   # (dense f16 = dense bf16 peak)   # bf16x3: three MFMAs per product
+        traffic = pmc_traffic() if args.precision in ('bf16', 'fp16') else None        # (same kernels, same bytes in both 16-bit builds)
+        roof = dict(bound='mfma', kernel={'bf16': 'gemm_nt_bf16_320_kernel (+ gemm_nt_bf16_256_kernel, gemm_nt_bf16_kernel)', 'fp16': 'gemm_nt_bf16_320_kernel built for binary16 (libtcow_hip_fp16.so)',
+                            'fp32': 'gemm_f32_kernel', 'bf16x3': 'gemm_x3_kernel'}[args.precision],
                     achieved=ks['tflops'], peak=peak, unit='TFLOP/s', frac=ks['tflops'] / peak, traffic=traffic,
                     launches_per_step=ks['launches'] / args.steps, avg_launch_us=ks['avg_us'], flops_per_launch=ks['flops_per_launch'])
         step_tflops = 3.0 * Qs * fl['total'] / (ms_per_step * 1e-3) / 1e12
         res = dict(metric='train clips/sec (T=30, 240x320)', value=clips_per_s, unit='clips/s', n_gpus=world, ranks_seen=(torch.distributed.get_world_size() if world > 1 else 1), steps=args.steps,
                    warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True, scaling='weak', vs_baseline=None,
-                   dtype={'bf16': 'bf16', 'fp32': 'f32', 'bf16x3': 'f32 (bf16x3 products)'}[args.precision], data='synthetic',
+                   dtype={'bf16': 'bf16', 'fp16': 'f16', 'fp32': 'f32', 'bf16x3': 'f32 (bf16x3 products)'}[args.precision], data='synthetic',
                    config=dict(workload=f'TCOW Seeker train step: T={args.frames} {args.height}x{args.width} patch16, {args.depth}-layer divided '
                                f'space-time ViT (D={g["D"]}), num_queries={Qs}, causal_attention=1, 1 clip/GPU',
                                clips_per_gpu=1, num_queries=Qs, parallelism=f'dp{world}', optimizer='AdamW lr 1e-4, clip 0.3',

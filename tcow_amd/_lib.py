@@ -8,6 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('TCOW_LIB') or os.path.join(_HERE, 'libtcow_hip.so')     # TCOW_LIB: A/B builds of the library (dev aid)
+LIB_PATH_FP16 = os.path.join(_HERE, 'libtcow_hip_fp16.so')                          # the binary16 build of the same sources (precision='fp16')
 
 TCOW_F32, TCOW_BF16, TCOW_F32X3 = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_DGELU, ACT_GELU_DSAVE, ACT_MUL_AUX = 0, 1, 2, 3, 4
@@ -47,7 +48,7 @@ class MaskLossArgs(ctypes.Structure):
                 ('ws', ctypes.c_void_p), ('ws_bytes', ctypes.c_size_t)]
 
 
-_lib = None
+_libs = {}
 
 _vp, _i, _l, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 _ash = ctypes.POINTER(AttnShape)
@@ -105,23 +106,26 @@ def _declare(L):
 
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise TcowError(f'{LIB_PATH} not found: build it with `make` (or __graft_entry__.build()); '
+def lib(fmt='bf16'):
+    """The library built for the given 16-bit storage format: 'bf16' -> libtcow_hip.so (also serves the f32-storage modes),
+    'fp16' -> libtcow_hip_fp16.so (the same sources compiled with -DTCOW_FP16, csrc/common.h)."""
+    L = _libs.get(fmt)
+    if L is None:
+        path = LIB_PATH if fmt == 'bf16' else LIB_PATH_FP16
+        if not os.path.exists(path):
+            raise TcowError(f'{path} not found: build it with `make` (or __graft_entry__.build()); '
                             'the Seeker HIP path has no fallback')
         # torch bundles its own libamdhip64; it must be in the process first so that this library binds to the
         # SAME HIP runtime (otherwise device pointers / streams of one runtime are foreign to the other).
         import torch  # noqa: F401
-        L = ctypes.CDLL(LIB_PATH)
+        L = ctypes.CDLL(path)
         L.tcow_last_error.restype = ctypes.c_char_p
         L.tcow_version.restype = ctypes.c_int
         _declare(L)
-        _lib = L
-    return _lib
+        _libs[fmt] = L
+    return L
 
 
-def check(rc, what=''):
+def check(rc, what='', L=None):
     if rc != 0:
-        raise TcowError(f'{what} failed (status {rc}): {lib().tcow_last_error().decode()}')
+        raise TcowError(f'{what} failed (status {rc}): {(L or lib()).tcow_last_error().decode()}')

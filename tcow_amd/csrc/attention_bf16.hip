@@ -114,7 +114,7 @@ __device__ __forceinline__ void fwd_tile(const SeqDesc& sd, const char* ktile, c
 #pragma unroll
     for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(ktile, l31, ks, hi), qf[ks], s, 0, 0, 0);
+    for (int ks = 0; ks < 4; ++ks) s = TCOW_MFMA_32x32x16_H16(frag_row(ktile, l31, ks, hi), qf[ks], s, 0, 0, 0);
     const bool need_mask = (32 * j + 31 >= sd.L) || ((long)32 * j + 31 > (long)32 * qt + sd.diag);
     if (need_mask) {
         TCOW_NO_IFCVT();
@@ -148,10 +148,10 @@ __device__ __forceinline__ void fwd_tile(const SeqDesc& sd, const char* ktile, c
     }
     l += ps;
     const bf16x8 pb0 = pack8(p), pb1 = pack8(p + 8);
-    o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(vtile, 0, 0, lane), pb0, o0, 0, 0, 0);
-    o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(vtile, 1, 0, lane), pb1, o0, 0, 0, 0);
-    o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(vtile, 0, 1, lane), pb0, o1, 0, 0, 0);
-    o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(vtile, 1, 1, lane), pb1, o1, 0, 0, 0);
+    o0 = TCOW_MFMA_32x32x16_H16(frag_tr(vtile, 0, 0, lane), pb0, o0, 0, 0, 0);
+    o0 = TCOW_MFMA_32x32x16_H16(frag_tr(vtile, 1, 0, lane), pb1, o0, 0, 0, 0);
+    o1 = TCOW_MFMA_32x32x16_H16(frag_tr(vtile, 0, 1, lane), pb0, o1, 0, 0, 0);
+    o1 = TCOW_MFMA_32x32x16_H16(frag_tr(vtile, 1, 1, lane), pb1, o1, 0, 0, 0);
 }
 
 // normalise and store one query tile's output (+ log-sum-exp)
@@ -305,8 +305,8 @@ __device__ __forceinline__ void dkv_tile(const SeqDesc& sd, const char* qtile, c
     for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(qtile, l31, ks, hi), kf[ks], s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(dotile, l31, ks, hi), vf[ks], dp, 0, 0, 0);
+        s = TCOW_MFMA_32x32x16_H16(frag_row(qtile, l31, ks, hi), kf[ks], s, 0, 0, 0);
+        dp = TCOW_MFMA_32x32x16_H16(frag_row(dotile, l31, ks, hi), vf[ks], dp, 0, 0, 0);
     }
     // rows of the accumulators are queries q = 32*i + 8*(r>>2) + 4*hi + (r&3); lse/delta for 4 consecutive q per group.
     // (VALU diet: masks only on boundary tiles -- masked scores are pushed to -1e30 so that exp2 underflows to 0; the 1/sqrt(d)
@@ -336,14 +336,14 @@ __device__ __forceinline__ void dkv_tile(const SeqDesc& sd, const char* qtile, c
         }
     }
     const bf16x8 pa0 = pack8(pv), pa1 = pack8(pv + 8), da0 = pack8(dsv), da1 = pack8(dsv + 8);
-    dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(dotile, 0, 0, lane), pa0, dv0, 0, 0, 0);
-    dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(dotile, 1, 0, lane), pa1, dv0, 0, 0, 0);
-    dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(dotile, 0, 1, lane), pa0, dv1, 0, 0, 0);
-    dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(dotile, 1, 1, lane), pa1, dv1, 0, 0, 0);
-    dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(qtile, 0, 0, lane), da0, dk0, 0, 0, 0);
-    dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(qtile, 1, 0, lane), da1, dk0, 0, 0, 0);
-    dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(qtile, 0, 1, lane), da0, dk1, 0, 0, 0);
-    dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(qtile, 1, 1, lane), da1, dk1, 0, 0, 0);
+    dv0 = TCOW_MFMA_32x32x16_H16(frag_tr(dotile, 0, 0, lane), pa0, dv0, 0, 0, 0);
+    dv0 = TCOW_MFMA_32x32x16_H16(frag_tr(dotile, 1, 0, lane), pa1, dv0, 0, 0, 0);
+    dv1 = TCOW_MFMA_32x32x16_H16(frag_tr(dotile, 0, 1, lane), pa0, dv1, 0, 0, 0);
+    dv1 = TCOW_MFMA_32x32x16_H16(frag_tr(dotile, 1, 1, lane), pa1, dv1, 0, 0, 0);
+    dk0 = TCOW_MFMA_32x32x16_H16(frag_tr(qtile, 0, 0, lane), da0, dk0, 0, 0, 0);
+    dk0 = TCOW_MFMA_32x32x16_H16(frag_tr(qtile, 1, 0, lane), da1, dk0, 0, 0, 0);
+    dk1 = TCOW_MFMA_32x32x16_H16(frag_tr(qtile, 0, 1, lane), da0, dk1, 0, 0, 0);
+    dk1 = TCOW_MFMA_32x32x16_H16(frag_tr(qtile, 1, 1, lane), da1, dk1, 0, 0, 0);
 }
 
 // The gradient MFMAs are issued as (transposed-read fragment, P or dS), i.e. they accumulate dV^T / dK^T / dQ^T: lane (l31, hi)
@@ -374,8 +374,8 @@ __device__ __forceinline__ void dq_tile(const SeqDesc& sd, const char* ktile, co
     for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(ktile, l31, ks, hi), qf[ks], s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(vtile, l31, ks, hi), dof[ks], dp, 0, 0, 0);
+        s = TCOW_MFMA_32x32x16_H16(frag_row(ktile, l31, ks, hi), qf[ks], s, 0, 0, 0);
+        dp = TCOW_MFMA_32x32x16_H16(frag_row(vtile, l31, ks, hi), dof[ks], dp, 0, 0, 0);
     }
     const bool need_mask = (32 * j + 31 >= sd.L) || (q - l31 + 31 >= sd.L) || ((long)32 * j + 31 > (long)(q - l31) + sd.diag);
     if (need_mask) {
@@ -394,10 +394,10 @@ __device__ __forceinline__ void dq_tile(const SeqDesc& sd, const char* ktile, co
         dsv[r] = p * (dp[r] - dl);
     }
     const bf16x8 da0 = pack8(dsv), da1 = pack8(dsv + 8);
-    dq0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(ktile, 0, 0, lane), da0, dq0, 0, 0, 0);
-    dq0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(ktile, 1, 0, lane), da1, dq0, 0, 0, 0);
-    dq1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(ktile, 0, 1, lane), da0, dq1, 0, 0, 0);
-    dq1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(ktile, 1, 1, lane), da1, dq1, 0, 0, 0);
+    dq0 = TCOW_MFMA_32x32x16_H16(frag_tr(ktile, 0, 0, lane), da0, dq0, 0, 0, 0);
+    dq0 = TCOW_MFMA_32x32x16_H16(frag_tr(ktile, 1, 0, lane), da1, dq0, 0, 0, 0);
+    dq1 = TCOW_MFMA_32x32x16_H16(frag_tr(ktile, 0, 1, lane), da0, dq1, 0, 0, 0);
+    dq1 = TCOW_MFMA_32x32x16_H16(frag_tr(ktile, 1, 1, lane), da1, dq1, 0, 0, 0);
 }
 
 __device__ __forceinline__ void dq_store(const SeqDesc& sd, long base, long ld3, int head, int qt, int l31, int hi, const f32x16& dq0, const f32x16& dq1,

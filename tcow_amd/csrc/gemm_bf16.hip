@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_ring_kernel(NtParams p) {
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fw[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = TCOW_MFMA_32x32x16_H16(fa[i], fw[j], acc[i][j], 0, 0, 0);
         }
         // slice kt+1 must have landed; slices kt+2, kt+3 (if issued) may stay in flight across the barrier
         int ahead = nk - 2 - kt; ahead = ahead > 2 ? 2 : (ahead < 0 ? 0 : ahead);
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_256_kernel(NtParams p) {
 #define TCOW_MFMA8(buf)                                                                                                   \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                        \
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                    \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[buf][i]), __builtin_bit_cast(bf16x8, fw[buf][j]), acc[i][j], 0, 0, 0)
+            acc[i][j] = TCOW_MFMA_32x32x16_H16(__builtin_bit_cast(bf16x8, fa[buf][i]), __builtin_bit_cast(bf16x8, fw[buf][j]), acc[i][j], 0, 0, 0)
 
     issue(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -499,7 +499,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_320_kernel(NtParams p) {
 #define TCOW_MFMA10(buf)                                                                                                  \
     _Pragma("unroll") for (int i = 0; i < 5; ++i)                                                                        \
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                    \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[buf][j]), __builtin_bit_cast(bf16x8, fa[buf][i]), acc[i][j], 0, 0, 0)
+            acc[i][j] = TCOW_MFMA_32x32x16_H16(__builtin_bit_cast(bf16x8, fw[buf][j]), __builtin_bit_cast(bf16x8, fa[buf][i]), acc[i][j], 0, 0, 0)
 
     issue(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -767,7 +767,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(NtParams p) {
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fw[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = TCOW_MFMA_32x32x16_H16(fa[i], fw[j], acc[i][j], 0, 0, 0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -964,7 +964,7 @@ __global__ __launch_bounds__(256, MC == 32 ? 4 : 2) void gemm_tn_bf16_kernel(TnP
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fy[i], fx[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = TCOW_MFMA_32x32x16_H16(fy[i], fx[j], acc[i][j], 0, 0, 0);
         }
         if (p.bias_part) {
             // bias gradient = column sums of dY: the dY stage is already in LDS; the tiles_k workgroups that share it split
@@ -1120,7 +1120,7 @@ __device__ __forceinline__ void tn256_body(const TnParams& p, const int pid, cha
 #define TCOW_TN_MFMA8(buf)                                                                                                 \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                          \
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                      \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(TCOW_TN_FRAG(fyl[buf][i], fyh[buf][i]), TCOW_TN_FRAG(fxl[buf][j], fxh[buf][j]), acc[i][j], 0, 0, 0)
+            acc[i][j] = TCOW_MFMA_32x32x16_H16(TCOW_TN_FRAG(fyl[buf][i], fyh[buf][i]), TCOW_TN_FRAG(fxl[buf][j], fxh[buf][j]), acc[i][j], 0, 0, 0)
 
     if (nmt > 0) TCOW_TN_READ(0, 0, 0u);
     for (int it = 0; it < nmt; ++it) {

@@ -22,9 +22,17 @@ constexpr int XK = 32;               // k-slice
 constexpr int XP = 80;               // LDS row pitch in bytes (32 bf16 + 16 B pad)
 constexpr int XPLANE = XT * XP;      // 10 KiB per plane
 
+// (always bfloat16 splits, whatever 16-bit format the rest of the library is built for: bf16 keeps the f32 exponent range, so lo never
+// underflows)
+typedef __attribute__((ext_vector_type(8))) __bf16 x3_bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 x3_bf16x2;
+__device__ __forceinline__ uint32_t x3_pack(float a, float b) {
+    f32x2 v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, x3_bf16x2));
+}
 __device__ __forceinline__ void split2(float x0, float x1, uint32_t& h, uint32_t& l) {
-    h = pack_bf2(x0, x1);
-    l = pack_bf2(x0 - bflo(h), x1 - bfhi(h));     // exact differences (Sterbenz-like: hi shares the leading bits of x)
+    h = x3_pack(x0, x1);
+    l = x3_pack(x0 - __builtin_bit_cast(float, h << 16), x1 - __builtin_bit_cast(float, h & 0xffff0000u));     // exact differences (hi shares the leading bits of x)
 }
 
 // Loaders of one 128-row x 32-k operand slice into 16 registers per thread: nothing but loads from clamped addresses -- a guarded load per
@@ -147,8 +155,8 @@ __device__ __forceinline__ void store_split(const f32x4 (&v)[4], char* hi_plane,
 
 __device__ __forceinline__ int cdiv_dev(int a, int b) { return (a + b - 1) / b; }
 
-__device__ __forceinline__ bf16x8 frag(const char* plane, int row, int ks, int hi) {
-    return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(plane + row * XP + ks * 32 + hi * 16));
+__device__ __forceinline__ x3_bf16x8 frag(const char* plane, int row, int ks, int hi) {
+    return __builtin_bit_cast(x3_bf16x8, *reinterpret_cast<const uint4*>(plane + row * XP + ks * 32 + hi * 16));
 }
 
 template <int LD>
@@ -192,7 +200,7 @@ __global__ __launch_bounds__(256, LD == LD_ANY ? 2 : 3) void gemm_x3_kernel(F32P
         fetch(ra, rb, knext);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 ah[2], al[2], bh[2], bl[2];
+            x3_bf16x8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 ah[i] = frag(a_hi, wm * 64 + i * 32 + l31, ks, hi); al[i] = frag(a_lo, wm * 64 + i * 32 + l31, ks, hi);

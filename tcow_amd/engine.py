@@ -57,7 +57,7 @@ def _get_weight(module, p, train):
     w = _w2d(p.detach())
     N, K = w.shape
     dt = ops.tdtype(mode)
-    if mode == ops.BF16:
+    if ops.is16(mode):
         Wc = torch.empty(N, K, dtype=dt, device=w.device)
         Wt = torch.empty(K, N, dtype=dt, device=w.device) if train else None
         ops.cast_transpose(mode, w.contiguous(), Wc, Wt)
@@ -71,7 +71,7 @@ def _get_weight(module, p, train):
     if train:
         # remember the buffers: after an optimizer step refresh_weights() re-casts ALL registered weights in one launch
         reg = module.__dict__.setdefault('_wreg', {})
-        reg[key] = (p, Wc if mode == ops.BF16 else None, Wt, N, K)
+        reg[key] = (p, Wc if ops.is16(mode) else None, Wt, N, K)
     return Wc, Wt
 
 
@@ -382,12 +382,27 @@ def run_backward(module, sv, params, d_mask, d_flags):
     use_cls = ca in (0, 1)
     f32 = torch.float32
     mask0 = sv['mask0']
+    # binary16 activations: gradients of a mean-reduced loss (~1e-6 per element) sit below fp16's normal range, so the whole backward runs
+    # on gradients multiplied by a power of two and every finished gradient bucket is multiplied back (exact) before anyone sees it.
+    # Everything in between is linear in the seed.  Static scale (module.loss_scale, default 2^14): the largest scaled element stays
+    # ~1e2, far from 65 504.
+    gscale = float(getattr(module, 'loss_scale', 1.0)) if mode == ops.FP16 else 1.0
+    if gscale != 1.0:
+        d_mask = None if d_mask is None else d_mask * gscale
+        d_flags = None if d_flags is None else d_flags * gscale
 
     def E(*shape, dtype=dt):
         return torch.empty(*shape, dtype=dtype, device=dev)
 
     Wt = lambda p: _get_weight(module, p, True)[1]
     grads = [None] * len(params)
+
+    def publish(tag, flat):
+        """A finished gradient bucket: undo the loss scale, then hand it to the data-parallel hook."""
+        if gscale != 1.0:
+            flat.mul_(1.0 / gscale)
+        if module.grad_hook is not None:
+            module.grad_hook(tag, flat)
 
     def bucket(indices):
         """One flat f32 buffer per gradient bucket (a transformer block, the heads, the embeddings): the views
@@ -460,8 +475,7 @@ def run_backward(module, sv, params, d_mask, d_flags):
         ops.layernorm_bwd(ops.F32, dFeat, sv['X_final'], sv['muf'], sv['rsf'], params[nb].detach(), None, dX, galloc(nb), galloc(nb + 1))
     else:
         dX = dFeat     # model.norm takes no part when norm_embeddings is False (vision_tf.py:152): its grads stay None
-    if module.grad_hook is not None:
-        module.grad_hook('head', head_flat)
+    publish('head', head_flat)
 
     shape_attn = ops.attn_shape(mode, B, T, S, D, heads, ca)
     if joint:
@@ -540,8 +554,7 @@ def run_backward(module, sv, params, d_mask, d_flags):
             dR3 = dR0
         flush_pending()          # the block's seven (joint: four) weight-gradient GEMMs as one grouped launch
         sv['blocks'][i] = None   # free this block's activations
-        if module.grad_hook is not None:
-            module.grad_hook(i, blk_flat)
+        publish(i, blk_flat)
 
     # ---- embeddings + patch embed backward
     gX = dR3
@@ -574,8 +587,8 @@ def run_backward(module, sv, params, d_mask, d_flags):
     else:
         ops.gemm_tn(gmode, Gpe, sv['A_pe'], dWpe)
     grads[4].copy_(dtime_eff.sum(0))       # bias gradient = sum over all patch rows
+    publish('embed', emb_flat)
     if module.grad_hook is not None:
-        module.grad_hook('embed', emb_flat)
         # The collectives launched above were overlapped with the remaining backward compute; they must be complete (in
         # stream order) before autograd copies the bucket views into param.grad, so the hook is drained here.
         if hasattr(module.grad_hook, 'finish'):

@@ -15,8 +15,20 @@ F32X3 = L.TCOW_F32X3      # GEMM wrappers only: f32 tensors, bf16 x 3 split prod
 ACT_NONE, ACT_GELU, ACT_DGELU, ACT_GELU_DSAVE, ACT_MUL_AUX = L.ACT_NONE, L.ACT_GELU, L.ACT_DGELU, L.ACT_GELU_DSAVE, L.ACT_MUL_AUX
 
 
+FP16 = 16                 # Python-side mode: the 16-bit mode (ABI dtype TCOW_BF16) of the binary16 build of the library, libtcow_hip_fp16.so
+
+
 def tdtype(mode):
-    return torch.bfloat16 if mode == BF16 else torch.float32
+    return torch.bfloat16 if mode == BF16 else torch.float16 if mode == FP16 else torch.float32
+
+
+def is16(mode):
+    return mode in (BF16, FP16)
+
+
+def _sel(mode):
+    """(library, ABI dtype) of a mode: the binary16 build serves FP16 through its 16-bit dtype, everything else is the main library."""
+    return (L.lib('fp16'), BF16) if mode == FP16 else (L.lib(), mode)
 
 
 def _stream():
@@ -38,10 +50,11 @@ def gemm_nt(mode, A, W, out, bias=None, row_scale=None, resid=None, act=ACT_NONE
     _need_cuda(A, W, out)
     M, K = A.shape
     N = W.shape[0]
-    a = L.GemmArgs(M, N, K, mode, A.data_ptr(), A.stride(0), W.data_ptr(), W.stride(0), out.data_ptr(), out.stride(0),
+    lib, dm = _sel(mode)
+    a = L.GemmArgs(M, N, K, dm, A.data_ptr(), A.stride(0), W.data_ptr(), W.stride(0), out.data_ptr(), out.stride(0),
                    1 if out.dtype == torch.float32 else 0, _p(bias), _p(row_scale), _p(resid),
                    resid.stride(0) if resid is not None else 0, act, _p(aux), aux.stride(0) if aux is not None else 0, int(tile))
-    L.check(L.lib().tcow_gemm_nt(_stream(), ctypes.byref(a)), 'tcow_gemm_nt')
+    L.check(lib.tcow_gemm_nt(_stream(), ctypes.byref(a)), 'tcow_gemm_nt', lib)
     return out
 
 
@@ -63,11 +76,11 @@ def gemm_tn(mode, dY, X, dW, bias_grad=None, accumulate=False):
     _need_cuda(dY, X, dW)
     M, N = dY.shape
     K = X.shape[1]
-    lib = L.lib()
+    lib, dm = _sel(mode)
     nbytes = lib.tcow_gemm_tn_workspace_bytes(M, N, K)
     ws = workspace(nbytes, dY.device, 'tn')
-    L.check(lib.tcow_gemm_tn(_stream(), mode, M, N, K, dY.data_ptr(), dY.stride(0), X.data_ptr(), X.stride(0), dW.data_ptr(),
-                             dW.stride(0), _p(bias_grad), int(accumulate), ws.data_ptr(), ws.numel()), 'tcow_gemm_tn')
+    L.check(lib.tcow_gemm_tn(_stream(), dm, M, N, K, dY.data_ptr(), dY.stride(0), X.data_ptr(), X.stride(0), dW.data_ptr(),
+                             dW.stride(0), _p(bias_grad), int(accumulate), ws.data_ptr(), ws.numel()), 'tcow_gemm_tn', lib)
     return dW
 
 
@@ -79,52 +92,57 @@ def gemm_tn_grouped(mode, problems):
     for i, (dY, X, dW, db) in enumerate(problems):
         _need_cuda(dY, X, dW)
         arr[i] = L.TnProblem(dY.shape[0], dY.shape[1], X.shape[1], dY.data_ptr(), dY.stride(0), X.data_ptr(), X.stride(0), dW.data_ptr(), dW.stride(0), _p(db), 0)
-    lib = L.lib()
-    ws = workspace(lib.tcow_gemm_tn_grouped_workspace_bytes(mode, n, arr), problems[0][0].device, 'tn')
-    L.check(lib.tcow_gemm_tn_grouped(_stream(), mode, n, arr, ws.data_ptr(), ws.numel()), 'tcow_gemm_tn_grouped')
+    lib, dm = _sel(mode)
+    ws = workspace(lib.tcow_gemm_tn_grouped_workspace_bytes(dm, n, arr), problems[0][0].device, 'tn')
+    L.check(lib.tcow_gemm_tn_grouped(_stream(), dm, n, arr, ws.data_ptr(), ws.numel()), 'tcow_gemm_tn_grouped', lib)
 
 
 def layernorm_fwd(mode, x, gamma, beta, out, mean=None, rstd=None, eps=1e-6):
     rows, D = x.shape
-    L.check(L.lib().tcow_layernorm_fwd(_stream(), mode, rows, D, x.data_ptr(), x.stride(0), gamma.data_ptr(), beta.data_ptr(), eps,
-                                       out.data_ptr(), out.stride(0), _p(mean), _p(rstd)), 'tcow_layernorm_fwd')
+    lib, dm = _sel(mode)
+    L.check(lib.tcow_layernorm_fwd(_stream(), dm, rows, D, x.data_ptr(), x.stride(0), gamma.data_ptr(), beta.data_ptr(), eps,
+                                       out.data_ptr(), out.stride(0), _p(mean), _p(rstd)), 'tcow_layernorm_fwd', lib)
     return out
 
 
 def layernorm_bwd(mode, dy, x, mean, rstd, gamma, dres, dx, dgamma=None, dbeta=None, accumulate=False, dx_cast=None, cast_scale=None):
     """dx = dres + dLN(dy); dx_cast (mode dtype, optional) = dx * cast_scale[row]: the next input-gradient GEMM's operand."""
     rows, D = x.shape
-    lib = L.lib()
+    lib, dm = _sel(mode)
     ws = workspace(lib.tcow_layernorm_bwd_workspace_bytes(D), x.device, 'ln')
-    L.check(lib.tcow_layernorm_bwd(_stream(), mode, rows, D, dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), mean.data_ptr(),
+    L.check(lib.tcow_layernorm_bwd(_stream(), dm, rows, D, dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), mean.data_ptr(),
                                    rstd.data_ptr(), gamma.data_ptr(), _p(dres), dres.stride(0) if dres is not None else 0, dx.data_ptr(),
                                    dx.stride(0), _p(dgamma), _p(dbeta), int(accumulate), ws.data_ptr(), ws.numel(),
-                                   _p(dx_cast), dx_cast.stride(0) if dx_cast is not None else 0, _p(cast_scale)), 'tcow_layernorm_bwd')
+                                   _p(dx_cast), dx_cast.stride(0) if dx_cast is not None else 0, _p(cast_scale)), 'tcow_layernorm_bwd', lib)
     return dx
 
 
 def attn_shape(mode, B, T, S, D, heads, causal):
-    return L.AttnShape(B, T, S, D, heads, int(causal), mode)
+    lib, dm = _sel(mode)
+    sh = L.AttnShape(B, T, S, D, heads, int(causal), dm)
+    sh.tcow_lib = lib              # which build of the library this shape's calls go to
+    return sh
 
 
 def attn_fwd(shape, spatial, qkv, out, lse=None):
-    fn = L.lib().tcow_attn_spatial_fwd if spatial else L.lib().tcow_attn_temporal_fwd
-    L.check(fn(_stream(), ctypes.byref(shape), qkv.data_ptr(), out.data_ptr(), _p(lse)), 'tcow_attn_fwd')
+    lib = shape.tcow_lib
+    fn = lib.tcow_attn_spatial_fwd if spatial else lib.tcow_attn_temporal_fwd
+    L.check(fn(_stream(), ctypes.byref(shape), qkv.data_ptr(), out.data_ptr(), _p(lse)), 'tcow_attn_fwd', lib)
     return out
 
 
 def attn_bwd(shape, spatial, qkv, out, dout, lse, dqkv):
-    lib = L.lib()
+    lib = shape.tcow_lib
     ws = workspace(lib.tcow_attn_bwd_workspace_bytes(ctypes.byref(shape)), qkv.device, 'attn')
     fn = lib.tcow_attn_spatial_bwd if spatial else lib.tcow_attn_temporal_bwd
     L.check(fn(_stream(), ctypes.byref(shape), qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(),
-               ws.data_ptr(), ws.numel()), 'tcow_attn_bwd')
+               ws.data_ptr(), ws.numel()), 'tcow_attn_bwd', lib)
     return dqkv
 
 
 def im2col(mode, rgb, query, P, pretrained_norm, out):
     B, _, T, H, W = rgb.shape
-    L.check(L.lib().tcow_im2col(_stream(), mode, B, T, H, W, P, rgb.data_ptr(), query.data_ptr(), int(pretrained_norm), out.data_ptr()), 'tcow_im2col')
+    L.check(_sel(mode)[0].tcow_im2col(_stream(), _sel(mode)[1], B, T, H, W, P, rgb.data_ptr(), query.data_ptr(), int(pretrained_norm), out.data_ptr()), 'tcow_im2col', _sel(mode)[0])
     return out
 
 
@@ -146,7 +164,7 @@ def gather_frames(frames, frame_idx, src_y, src_x):
 def im2col_channels(mode, src, P, normalise, out):
     """src (B,C,T,H,W) f32 -> out [B*T*S, C*P*P] (see tcow_im2col_channels)."""
     B, C, T, H, W = src.shape
-    L.check(L.lib().tcow_im2col_channels(_stream(), mode, B, T, H, W, P, C, src.data_ptr(), int(normalise), out.data_ptr()), 'tcow_im2col_channels')
+    L.check(_sel(mode)[0].tcow_im2col_channels(_stream(), _sel(mode)[1], B, T, H, W, P, C, src.data_ptr(), int(normalise), out.data_ptr()), 'tcow_im2col_channels', _sel(mode)[0])
     return out
 
 
@@ -165,12 +183,12 @@ def cls_merge(x, B, T, S, mode, backward=False):
 
 
 def unpatchify_pool_fwd(mode, pm, BT, Hp, Wp, P, C, st, pooled):
-    L.check(L.lib().tcow_unpatchify_pool_fwd(_stream(), mode, BT, Hp, Wp, P, C, st, pm.data_ptr(), pooled.data_ptr()), 'tcow_unpatchify_pool_fwd')
+    L.check(_sel(mode)[0].tcow_unpatchify_pool_fwd(_stream(), _sel(mode)[1], BT, Hp, Wp, P, C, st, pm.data_ptr(), pooled.data_ptr()), 'tcow_unpatchify_pool_fwd', _sel(mode)[0])
     return pooled
 
 
 def unpatchify_pool_bwd(mode, dpooled, BT, Hp, Wp, P, C, st, dpm):
-    L.check(L.lib().tcow_unpatchify_pool_bwd(_stream(), mode, BT, Hp, Wp, P, C, st, dpooled.data_ptr(), dpm.data_ptr()), 'tcow_unpatchify_pool_bwd')
+    L.check(_sel(mode)[0].tcow_unpatchify_pool_bwd(_stream(), _sel(mode)[1], BT, Hp, Wp, P, C, st, dpooled.data_ptr(), dpm.data_ptr()), 'tcow_unpatchify_pool_bwd', _sel(mode)[0])
     return dpm
 
 
@@ -191,18 +209,18 @@ def flags_fwd(x, BT, S, Wf, bf, flags):
 
 def scale_cast(mode, src, row_scale, dst):
     rows, D = src.shape
-    L.check(L.lib().tcow_scale_cast(_stream(), mode, rows, D, src.data_ptr(), src.stride(0), _p(row_scale), dst.data_ptr(), dst.stride(0)), 'tcow_scale_cast')
+    L.check(_sel(mode)[0].tcow_scale_cast(_stream(), _sel(mode)[1], rows, D, src.data_ptr(), src.stride(0), _p(row_scale), dst.data_ptr(), dst.stride(0)), 'tcow_scale_cast', _sel(mode)[0])
     return dst
 
 
 def cast_transpose(mode, W, Wc=None, Wt=None):
     N, K = W.shape
-    L.check(L.lib().tcow_cast_transpose(_stream(), mode, N, K, W.data_ptr(), _p(Wc), _p(Wt)), 'tcow_cast_transpose')
+    L.check(_sel(mode)[0].tcow_cast_transpose(_stream(), _sel(mode)[1], N, K, W.data_ptr(), _p(Wc), _p(Wt)), 'tcow_cast_transpose', _sel(mode)[0])
 
 
 def cast_transpose_batched(mode, table, n, total_tiles):
     """One launch for all operand copies; `table` is the uint8 device tensor of tcow_cast_desc records (see tcow_cast_transpose_batched)."""
-    L.check(L.lib().tcow_cast_transpose_batched(_stream(), mode, table.data_ptr(), int(n), int(total_tiles)), 'tcow_cast_transpose_batched')
+    L.check(_sel(mode)[0].tcow_cast_transpose_batched(_stream(), _sel(mode)[1], table.data_ptr(), int(n), int(total_tiles)), 'tcow_cast_transpose_batched', _sel(mode)[0])
 
 
 def mask_loss(logits, target, channel, pixel_w=None, frame_w=None, weighted_aot=False, aot_loss=0.8, topk_frac=1.0,

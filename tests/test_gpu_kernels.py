@@ -1,6 +1,7 @@
 """GPU: every libtcow_hip entry point, called through the C ABI, against a plain PyTorch fp32 reference of the same op.
 Tolerances: f32 mode ~1e-5 relative (exact-f32 MFMA/FMA, different summation order); bf16 mode ~1e-2 relative of the
-tensor's max (bf16 operands, f32 accumulation)."""
+tensor's max (bf16 operands, f32 accumulation); fp16 = the same kernels built for binary16 storage (libtcow_hip_fp16.so): 1/8 of the
+bf16 bounds (11 instead of 8 significand bits)."""
 import numpy as np
 import pytest
 import torch
@@ -22,12 +23,12 @@ def ops(cuda):
     return o
 
 
-MODES = [('f32', 2e-5), ('bf16', 2e-2)]
+MODES = [('f32', 2e-5), ('bf16', 2e-2), ('fp16', 2.5e-3)]
 GEMM_MODES = MODES + [('f32x3', 4e-5)]      # f32 tensors, bf16 x 3 split products (csrc/gemm_x3.hip): ~2^-17 per product
 
 
 def _mode(ops, name):
-    return {'f32': (ops.F32, torch.float32), 'f32x3': (ops.F32X3, torch.float32), 'bf16': (ops.BF16, torch.bfloat16)}[name]
+    return {'f32': (ops.F32, torch.float32), 'f32x3': (ops.F32X3, torch.float32), 'bf16': (ops.BF16, torch.bfloat16), 'fp16': (ops.FP16, torch.float16)}[name]
 
 
 @pytest.mark.parametrize('mname,tol', GEMM_MODES)
@@ -62,39 +63,41 @@ def test_gemm_nt_epilogues(ops, cuda, mname, tol, M, K, N):
     assert rel(C, ref0 * pre.double()) < tol
 
 
+@pytest.mark.parametrize('fmt', ['bf16', 'fp16'])
 @pytest.mark.parametrize('N,K', [(768, 768), (2304, 768), (3072, 768), (768, 3072)])
-def test_gemm_nt_every_tile_kernel_at_bench_size(ops, cuda, N, K):
+def test_gemm_nt_every_tile_kernel_at_bench_size(ops, cuda, N, K, fmt):
     """The benchmarked instantiations against an f64 product: M = 27 090 token rows (3 queries x 30 frames x 301 slots, BASELINE
     configs[1]) with the four weight shapes of a block, on each bf16 tile kernel (forced through tcow_gemm_args.tile: 320 x 256
     incl. its compile-time epilogues, 256 x 256, 128 x 128) and every epilogue combination the engine issues.  Operands are bf16
     values, so the only error is f32 accumulation order + the output rounding: bf16 outputs within 2^-8 of the tile maximum, f32
     outputs within 2e-5."""
     M = 27090
+    H16, h16 = _mode(ops, fmt)
     g = torch.Generator(device='cuda').manual_seed(N + K)
-    A = torch.randn(M, K, device=cuda, generator=g).bfloat16(); W = (torch.randn(N, K, device=cuda, generator=g) * 0.05).bfloat16()
+    A = torch.randn(M, K, device=cuda, generator=g).to(h16); W = (torch.randn(N, K, device=cuda, generator=g) * 0.05).to(h16)
     bias = torch.randn(N, device=cuda, generator=g); rs = torch.rand(M, device=cuda, generator=g) + 0.5; rs[::7] = 0.0
-    resid = torch.randn(M, N, device=cuda, generator=g); pre = torch.randn(M, N, device=cuda, generator=g).bfloat16()
+    resid = torch.randn(M, N, device=cuda, generator=g); pre = torch.randn(M, N, device=cuda, generator=g).to(h16)
     ref0 = A.double() @ W.double().t()
     refb = ref0 + bias.double()
     xv = refb.clone().requires_grad_(True)
     gel = F.gelu(xv); dgel = torch.autograd.grad(gel.sum(), xv)[0]; gel = gel.detach()
-    BF, F32 = 4e-3, 2e-5
-    bf = lambda: torch.empty(M, N, device=cuda, dtype=torch.bfloat16)
+    BF, F32 = (4e-3 if fmt == 'bf16' else 5e-4), 2e-5
+    bf = lambda: torch.empty(M, N, device=cuda, dtype=h16)
     f32 = lambda: torch.empty(M, N, device=cuda)
     for tile in (320, 256, 128, 0):
         t = dict(tile=tile)
-        assert rel(ops.gemm_nt(ops.BF16, A, W, bf(), bias=bias, **t), refb) < BF                                              # EpiCfg<NONE, 0>: qkv, proj-input grads
-        assert rel(ops.gemm_nt(ops.BF16, A, W, f32(), **t), ref0) < F32                                                     # f32 output (dFeat)
-        assert rel(ops.gemm_nt(ops.BF16, A, W, bf(), bias=bias, row_scale=rs, **t), refb * rs.double()[:, None]) < BF         # <NONE, 1>: temporal proj + DropPath row scale
-        assert rel(ops.gemm_nt(ops.BF16, A, W, f32(), bias=bias, resid=resid, **t), refb + resid.double()) < F32             # <NONE, 2>: residual
-        assert rel(ops.gemm_nt(ops.BF16, A, W, f32(), bias=bias, row_scale=rs, resid=resid, **t), refb * rs.double()[:, None] + resid.double()) < F32   # <NONE, 3>
+        assert rel(ops.gemm_nt(H16, A, W, bf(), bias=bias, **t), refb) < BF                                              # EpiCfg<NONE, 0>: qkv, proj-input grads
+        assert rel(ops.gemm_nt(H16, A, W, f32(), **t), ref0) < F32                                                     # f32 output (dFeat)
+        assert rel(ops.gemm_nt(H16, A, W, bf(), bias=bias, row_scale=rs, **t), refb * rs.double()[:, None]) < BF         # <NONE, 1>: temporal proj + DropPath row scale
+        assert rel(ops.gemm_nt(H16, A, W, f32(), bias=bias, resid=resid, **t), refb + resid.double()) < F32             # <NONE, 2>: residual
+        assert rel(ops.gemm_nt(H16, A, W, f32(), bias=bias, row_scale=rs, resid=resid, **t), refb * rs.double()[:, None] + resid.double()) < F32   # <NONE, 3>
         inplace = resid.clone()
-        ops.gemm_nt(ops.BF16, A, W, inplace, bias=bias, row_scale=rs, resid=inplace, **t)                                    # eval: residual aliases the output
+        ops.gemm_nt(H16, A, W, inplace, bias=bias, row_scale=rs, resid=inplace, **t)                                    # eval: residual aliases the output
         assert rel(inplace, refb * rs.double()[:, None] + resid.double()) < F32
         aux = bf()
-        assert rel(ops.gemm_nt(ops.BF16, A, W, bf(), bias=bias, act=ops.ACT_GELU_DSAVE, aux=aux, **t), gel) < BF and rel(aux, dgel) < BF   # <GELU_DSAVE, 0>: fc1 (training)
-        assert rel(ops.gemm_nt(ops.BF16, A, W, bf(), bias=bias, act=ops.ACT_GELU, **t), gel) < BF                            # <GELU, 0>: fc1 (inference)
-        assert rel(ops.gemm_nt(ops.BF16, A, W, bf(), act=ops.ACT_MUL_AUX, aux=pre, **t), ref0 * pre.double()) < BF           # <MUL_AUX, 0>: fc2 input gradient x GELU'
+        assert rel(ops.gemm_nt(H16, A, W, bf(), bias=bias, act=ops.ACT_GELU_DSAVE, aux=aux, **t), gel) < BF and rel(aux, dgel) < BF   # <GELU_DSAVE, 0>: fc1 (training)
+        assert rel(ops.gemm_nt(H16, A, W, bf(), bias=bias, act=ops.ACT_GELU, **t), gel) < BF                            # <GELU, 0>: fc1 (inference)
+        assert rel(ops.gemm_nt(H16, A, W, bf(), act=ops.ACT_MUL_AUX, aux=pre, **t), ref0 * pre.double()) < BF           # <MUL_AUX, 0>: fc2 input gradient x GELU'
 
 
 @pytest.mark.parametrize('mname,tol', GEMM_MODES)
@@ -135,25 +138,27 @@ def test_gemm_x3_split_products(ops, cuda, M, K, N):
         assert rel(cb, r0) > 30 * rel(ops.gemm_nt(ops.F32X3, A, W, torch.empty(M, N, device=cuda)), r0)
 
 
+@pytest.mark.parametrize('fmt', ['bf16', 'fp16'])
 @pytest.mark.parametrize('M', [27090, 9030, 300])
-def test_gemm_tn_grouped_block_weights(ops, cuda, M):
+def test_gemm_tn_grouped_block_weights(ops, cuda, M, fmt):
     """tcow_gemm_tn_grouped on the seven Linear layers of a divided space-time block (vit.py:50-61,74-76,146) at the benchmark's row count
     (one grid, common slice count), at a smaller M and at one too small for the 256-tile kernel (the library loops there): every dW / db
     against the f64 product and against the one-by-one entry point."""
     D = 768
+    H16, h16 = _mode(ops, fmt)
     shapes = [(D, 4 * D), (4 * D, D), (D, D), (3 * D, D), (D, D), (D, D), (3 * D, D)]      # (N, K) of fc2, fc1, proj, qkv, tfc, tproj, tqkv
     g = torch.Generator(device='cuda').manual_seed(M)
     probs, refs = [], []
     for i, (N, K) in enumerate(shapes):
-        dY = torch.randn(M, N, device=cuda, generator=g).bfloat16(); X = torch.randn(M, K, device=cuda, generator=g).bfloat16()
+        dY = torch.randn(M, N, device=cuda, generator=g).to(h16); X = torch.randn(M, K, device=cuda, generator=g).to(h16)
         dW = torch.empty(N, K, device=cuda); db = torch.empty(N, device=cuda) if i != 2 else None
         probs.append((dY, X, dW, db)); refs.append((dY.double().t() @ X.double(), dY.double().sum(0)))
-    ops.gemm_tn_grouped(ops.BF16, probs)
+    ops.gemm_tn_grouped(H16, probs)
     for (dY, X, dW, db), (rw, rb) in zip(probs, refs):
         assert rel(dW, rw) < 1e-5
         if db is not None:
             assert rel(db, rb) < 1e-4
-        one = ops.gemm_tn(ops.BF16, dY, X, torch.empty_like(dW))
+        one = ops.gemm_tn(H16, dY, X, torch.empty_like(dW))
         assert rel(dW, one) < 1e-5
     # f32-storage modes go through the same entry point (library-side loop)
     small = [(p[0][:257].float(), p[1][:257].float(), torch.empty_like(p[2]), None) for p in probs[2:4]]
@@ -214,7 +219,7 @@ def _ref_attn(qkv, B, T, S, D, heads, ca, spatial):
     return out.reshape(B * T * S, D)
 
 
-@pytest.mark.parametrize('mname,tol', [('f32', 2e-5), ('bf16', 1.5e-2)])
+@pytest.mark.parametrize('mname,tol', [('f32', 2e-5), ('bf16', 1.5e-2), ('fp16', 2e-3)])
 @pytest.mark.parametrize('spatial,B,T,S,heads,ca', [
     (False, 1, 4, 17, 4, 1), (False, 2, 30, 21, 2, 1), (False, 1, 30, 9, 2, 0), (False, 1, 7, 9, 2, 3), (False, 1, 40, 9, 2, 1), (False, 1, 70, 5, 1, 2),
     (True, 1, 2, 17, 4, 1), (True, 2, 3, 301, 2, 1), (True, 1, 2, 77, 2, 2), (True, 1, 1, 2, 1, 0), (True, 1, 1, 333, 1, 1),
@@ -252,7 +257,7 @@ def test_im2col_matches_reference_patch_order(ops, cuda):
     assert np.array_equal(out[1:].cpu().numpy().astype(np.int32), pat)
 
 
-@pytest.mark.parametrize('mname', ['f32', 'bf16'])
+@pytest.mark.parametrize('mname', ['f32', 'bf16', 'fp16'])
 def test_im2col_normalisation_and_embeddings(ops, cuda, mname):
     mode, dt = _mode(ops, mname)
     B, T, H, W, P, D = 2, 3, 32, 48, 16, 64
@@ -335,3 +340,10 @@ def test_flags_casts(ops, cuda):
     rs = torch.rand(50, device=cuda); src = torch.randn(50, 64, device=cuda); dst = torch.empty(50, 64, device=cuda, dtype=torch.bfloat16)
     ops.scale_cast(ops.BF16, src, rs, dst)
     assert torch.equal(dst, (src * rs[:, None]).bfloat16())
+    # the binary16 build rounds to nearest even as well
+    Wh = torch.empty(100, 72, device=cuda, dtype=torch.float16); Wth = torch.empty(72, 100, device=cuda, dtype=torch.float16)
+    ops.cast_transpose(ops.FP16, W, Wh, Wth)
+    assert torch.equal(Wh, W.half()) and torch.equal(Wth, W.half().t().contiguous())
+    dh = torch.empty(50, 64, device=cuda, dtype=torch.float16)
+    ops.scale_cast(ops.FP16, src, rs, dh)
+    assert torch.equal(dh, (src * rs[:, None]).half())

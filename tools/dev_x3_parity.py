@@ -3,11 +3,11 @@ import sys, numpy as np, torch
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 from conftest import build_hip_seeker, golden_inputs, load_golden
 from tcow_amd import synth
-for name in ['g1_cfg1_d256', 'g2_ca0', 'g2_ca3', 'g2_normemb_nearest', 'g2_stride1_prenorm', 'g11_depth18', 'g14_joint']:
+for name in ['g1_cfg1_d256', 'g2_ca3', 'g2_normemb_nearest', 'g2_stride1_prenorm', 'g11_depth18']:
     meta, g = load_golden(name)
     cfg, sd, rgb, qm = golden_inputs(meta)
     key = 'output_mask' if 'output_mask' in g else 'eval::output_mask'
-    for prec in ('fp32', 'bf16x3'):
+    for prec in ('fp32', 'bf16x3', 'fp16', 'bf16'):
         try:
             net = build_hip_seeker(cfg, sd, prec).cuda().eval()
         except Exception as e:
@@ -19,7 +19,7 @@ for name in ['g1_cfg1_d256', 'g2_ca0', 'g2_ca3', 'g2_normemb_nearest', 'g2_strid
 # gradients at g1
 meta, g = load_golden('g1_cfg1_d256')
 cfg, sd, rgb, qm = golden_inputs(meta)
-for prec in ('fp32', 'bf16x3'):
+for prec in ('fp32', 'bf16x3', 'fp16', 'bf16'):
     net = build_hip_seeker(cfg, sd, prec).cuda().train()
     om, fl = net(rgb.cuda(), qm.cuda())
     Gm = torch.from_numpy(synth._rng(meta['seed'], 'gradprobe_mask').standard_normal(size=tuple(om.shape), dtype=np.float32)).cuda()
