@@ -70,7 +70,9 @@ def test_backward_drains_the_hook_before_returning_grads():
     import inspect
     from tcow_amd import engine
     src = inspect.getsource(engine.run_backward)
-    assert src.index("module.grad_hook('embed', emb_flat)") < src.index('module.grad_hook.finish()') < src.rindex('return grads')
+    assert src.index("publish('embed', emb_flat)") < src.index('module.grad_hook.finish()') < src.rindex('return grads')
+    # every bucket goes through publish(): the loss scale of the fp16 mode is undone BEFORE the data-parallel hook sees the bucket
+    assert src.index('flat.mul_(1.0 / gscale)') < src.index('module.grad_hook(tag, flat)')
 
 
 def test_bench_self_launches_n_ranks():
