@@ -143,7 +143,7 @@ def parity_leg(make_trainer, bf16_net, ref_mask, args):
         net.load_state_dict(trained, strict=True); net.seeker.invalidate_weight_cache(); net.train()
 
     max_abs_d('bf16', bf16_net)
-    for key, precision, dtype in (('fp16_mode', 'fp16', 'f16 (the bf16 kernels built for binary16 storage, static loss scale 2^14)'),
+    for key, precision, dtype in (('fp16_mode', 'fp16', 'f16 (the bf16 kernels built for binary16 storage, power-of-two loss scale chosen on the device)'),
                                   ('bf16x3_mode', 'bf16x3', 'f32 storage, bf16 x 3 GEMM products'), ('fp32_parity_mode', 'fp32', 'f32')):
         net, step = make_trainer(precision)
         nsteps = args.parity_steps * (5 if precision == 'fp16' else 1)          # (a 37 ms step needs more repetitions than a 250 ms one)

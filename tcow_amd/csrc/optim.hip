@@ -3,7 +3,8 @@
 // every parameter).  The reference's foreach implementation walks ~250 tensors from Python / ATen per step;
 // here a device-resident chunk table (<= 65536 elements per chunk) lets one grid cover every tensor.
 //   1. sumsq_kernel   : per-chunk sum of squares of the gradient
-//   2. clipcoef_kernel: total norm -> clip coefficient min(1, max_norm / (norm + 1e-6))   (torch.nn.utils.clip_grad_norm_)
+//   2. clipcoef_kernel: total norm -> clip coefficient min(1, max_norm / (norm + 1e-6))   (torch.nn.utils.clip_grad_norm_);
+//                       a NaN / infinite norm -> -1 = "skip this step" (the update kernel returns at once)
 //   3. adamw_kernel   : p, m, v update with the clipped gradient (decoupled weight decay, bias correction as torch.optim.AdamW)
 #include "common.h"
 
@@ -34,7 +35,8 @@ __global__ __launch_bounds__(256) void clipcoef_kernel(const float* __restrict__
     if (threadIdx.x == 0) {
         const float norm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
         float coef = max_norm > 0.f ? max_norm / (norm + 1e-6f) : 1.0f;
-        out[0] = coef < 1.0f ? coef : 1.0f;
+        // a non-finite gradient norm (an overflow in a 16-bit backward) marks the step as skipped: coefficient -1
+        out[0] = !(norm <= 3.0e38f) ? -1.0f : (coef < 1.0f ? coef : 1.0f);
         out[1] = norm;
     }
 }
@@ -43,6 +45,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(const Chunk* __restrict__ ch
                                                     float weight_decay, float bc1, float bc2_sqrt) {
     const Chunk c = chunks[blockIdx.x];
     const float coef = coef_ptr[0];
+    if (coef < 0.f) return;                        // non-finite gradients: parameters and moments stay as they are (like a GradScaler skip)
     const float decay = 1.0f - lr * weight_decay, step_size = lr / bc1;
     const long n4 = c.n >> 2;
     auto upd = [&](float& p, float g, float& m, float& v) {

@@ -13,7 +13,11 @@ saved here loads into torch.optim.AdamW.
 The kernels write the parameters through raw pointers; after every step the parameters' autograd version counters are bumped
 (torch.autograd.graph.increment_version), so anything that caches derived copies keyed on `p._version` -- the Seeker's bf16
 operand copies are -- can never serve stale weights.  `on_step` callbacks (e.g. QueryMaskTracker.invalidate_weight_cache, which
-re-casts all GEMM operands in ONE launch) are an optimisation on top of that, not a correctness requirement."""
+re-casts all GEMM operands in ONE launch) are an optimisation on top of that, not a correctness requirement.
+
+One extension over torch's pair: a step whose total gradient norm is NaN / infinite is SKIPPED (parameters and moments untouched) instead
+of poisoning the weights -- the overflow guard of the binary16 mode (precision='fp16'), whose loss-scale exponent is lowered in the same
+step (device side, no synchronisation)."""
 import numpy as np
 import torch
 
@@ -32,8 +36,10 @@ class FusedAdamWClip(torch.optim.Optimizer):
         self._key = None
         self.scratch = None
         self.on_step = []          # callables run after every step
+        self._tracker = None
         if module is not None:     # a Seeker / QueryMaskTracker: batch re-cast of its GEMM operand copies right after the update
             tracker = getattr(module, 'seeker', module)
+            self._tracker = tracker
             if hasattr(tracker, 'invalidate_weight_cache'):
                 self.on_step.append(tracker.invalidate_weight_cache)
         assert L.lib().tcow_adamw_chunk_bytes() == 40
@@ -91,6 +97,12 @@ class FusedAdamWClip(torch.optim.Optimizer):
         L.check(L.lib().tcow_adamw_clip_step(torch.cuda.current_stream().cuda_stream, self._table.data_ptr(), self._table.shape[0], float(grp['lr']),
                                              float(grp['betas'][0]), float(grp['betas'][1]), float(grp['eps']), float(grp['weight_decay']), step,
                                              float(self.max_norm or 0.0), self.scratch.data_ptr()), 'tcow_adamw_clip_step')
+        # precision='fp16': a non-finite gradient norm means the scaled backward overflowed binary16 -- the kernels above skipped the update
+        # (clip coefficient -1); lower the module's loss-scale exponent by 4, otherwise let it creep back towards -2.  All on the device.
+        ls = getattr(self._tracker, 'ls_log2', None) if self._tracker is not None else None
+        if ls is not None and ls.device == self.scratch.device:
+            ok = torch.isfinite(self.scratch[-1])
+            ls.copy_(torch.minimum(ls + torch.where(ok, 1.0 / 256.0, -4.0), torch.full_like(ls, -2.0)))
         torch._foreach_add_([self.state[p]['step'] for p in live], 1)   # CPU scalars, like torch.optim.AdamW keeps them (one call, not 247)
         torch.autograd.graph.increment_version(live)   # the kernels wrote through raw pointers: make the update visible to version checks
         for cb in self.on_step:

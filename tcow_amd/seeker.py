@@ -12,7 +12,7 @@ precision:
   'bf16' (default)  bf16 GEMM/attention operands, f32 accumulation, f32 residual stream / LayerNorm / softmax.
   'fp16'            the bf16 mode's kernels built for IEEE binary16 storage (libtcow_hip_fp16.so: 11 instead of 8 significand bits,
                     same speed): mask logits within 1e-3 of the fp32 reference (measured ~6e-4 at BASELINE configs[1]); the backward
-                    runs on gradients scaled by `loss_scale` (2^14, exact) to stay inside binary16's range.
+                    runs on gradients scaled by a power of two (exact; `loss_scale`, chosen per backward on the device) to stay inside binary16's range.
   'fp32'            everything f32 on the exact-f32 MFMA/FMA kernels: the parity mode (mask logits within 1e-3
                     of the fp32 reference; measured ~1e-6).
   'bf16x3'          the fp32 mode with its GEMMs on the bf16 matrix cores: every f32 operand is split into two bf16
@@ -197,7 +197,8 @@ class QueryMaskTracker(nn.Module):
             raise ValueError("precision must be 'bf16', 'fp16', 'fp32' or 'bf16x3'")
         self.precision = precision
         self.mode = ops.BF16 if precision == 'bf16' else ops.FP16 if precision == 'fp16' else ops.F32
-        self.loss_scale = 16384.0                                               # fp16 only: power-of-two factor on the backward's gradients (engine.run_backward)
+        self.ls_log2 = None                                                     # device scalar of the dynamic loss scale (created by the first fp16 backward)
+        self.loss_scale = 'dynamic'                                             # fp16 only: power-of-two factor on the backward's gradients (engine.run_backward); a number = static
         self.gemm_mode = ops.F32X3 if precision == 'bf16x3' else self.mode     # GEMM arithmetic; storage / every other kernel follow `mode`
         self._wcache = {}
         self.__dict__.pop('_wreg', None); self.__dict__.pop('_wtab', None)

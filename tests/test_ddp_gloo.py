@@ -72,7 +72,7 @@ def test_backward_drains_the_hook_before_returning_grads():
     src = inspect.getsource(engine.run_backward)
     assert src.index("publish('embed', emb_flat)") < src.index('module.grad_hook.finish()') < src.rindex('return grads')
     # every bucket goes through publish(): the loss scale of the fp16 mode is undone BEFORE the data-parallel hook sees the bucket
-    assert src.index('flat.mul_(1.0 / gscale)') < src.index('module.grad_hook(tag, flat)')
+    assert src.index('flat.mul_(inv_gscale)') < src.index('module.grad_hook(tag, flat)')
 
 
 def test_bench_self_launches_n_ranks():

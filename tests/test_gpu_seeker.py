@@ -470,6 +470,31 @@ def test_fused_adamw_clip_matches_torch(cuda):
     assert opt.step_count == 3
 
 
+def test_fp16_overflow_skips_the_step_and_lowers_the_loss_scale(cuda):
+    """precision='fp16': a non-finite gradient (an overflow of the scaled binary16 backward) must not poison the weights: the fused
+    clip + AdamW kernels skip the update (parameters and moments untouched) and the module's loss-scale exponent drops by 4, on the device;
+    the next good step applies normally and the exponent creeps back."""
+    from tcow_amd.optim import FusedAdamWClip
+    cfg = synth.seeker_config(num_total_frames=4, frame_height=32, frame_width=32, embed_dim=128, depth=2, num_heads=2, causal_attention=1)
+    net = build_hip_seeker(cfg, synth.make_state_dict(cfg, 5), 'fp16').cuda().train()
+    opt = FusedAdamWClip(list(net.parameters()), lr=1e-3, max_norm=0.3, module=net)
+    clip = synth.make_clip(1, 4, 32, 32, seed=2)
+    rgb = torch.from_numpy(clip['rgb']).cuda(); qm = torch.from_numpy(synth.make_query_mask(clip, 0, 0)).cuda()
+    opt.zero_grad(set_to_none=True); om, fl = net(rgb, qm); (om.square().mean() + fl.square().mean()).backward(); opt.step()          # a normal step creates the scale state
+    assert float(net.seeker.ls_log2) == -2.0 and all(bool(torch.isfinite(p).all()) for p in net.parameters())
+    before = [p.detach().clone() for p in net.parameters()]
+    m_before = opt.state[next(iter(net.parameters()))]['exp_avg'].clone()
+    opt.zero_grad(set_to_none=True); om, fl = net(rgb, qm); (om.square().mean() + fl.square().mean()).backward()
+    next(p for p in net.parameters() if p.grad is not None).grad.view(-1)[0] = float('inf')        # what an overflow looks like to the optimizer
+    opt.step()
+    assert all(torch.equal(a, p.detach()) for a, p in zip(before, net.parameters()))                # skipped
+    assert torch.equal(m_before, opt.state[next(iter(net.parameters()))]['exp_avg'])
+    assert float(net.seeker.ls_log2) == -6.0
+    opt.zero_grad(set_to_none=True); om, fl = net(rgb, qm); (om.square().mean() + fl.square().mean()).backward(); opt.step()          # scale 2^-4 of before: still a good step
+    assert not all(torch.equal(a, p.detach()) for a, p in zip(before, net.parameters()))
+    assert all(bool(torch.isfinite(p).all()) for p in net.parameters()) and -6.0 < float(net.seeker.ls_log2) < -5.9
+
+
 def test_persistent_gradient_buckets(cuda):
     """persistent_grads=True: same gradient values, delivered in storage that is stable across steps (no autograd copy)."""
     cfg = synth.seeker_config(num_total_frames=4, frame_height=32, frame_width=32, embed_dim=128, depth=2, num_heads=2, causal_attention=1)
