@@ -29,6 +29,9 @@
  *    entry points only (tcow_gemm_nt, tcow_gemm_tn): storage, arguments and epilogues of TCOW_F32, products computed as
  *    three bf16 MFMAs on hi / lo splits of the f32 operands (~1e-5 relative per product; gemm_x3.hip) -- every other
  *    entry point of the module's precision='bf16x3' mode is called with TCOW_F32.
+ *  - Two builds of this ABI exist: libtcow_hip.so stores the 16-bit mode (TCOW_BF16) as bfloat16; libtcow_hip_fp16.so is the same
+ *    source compiled with -DTCOW_FP16 and stores it as IEEE binary16 (csrc/common.h) -- identical entry points, argument meaning and
+ *    speed, 8x smaller rounding error, binary16's range (the host scales gradients by a power of two, see tcow_amd/engine.py).
  */
 #ifndef TCOW_HIP_H
 #define TCOW_HIP_H
