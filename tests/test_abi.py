@@ -20,11 +20,13 @@ def test_header_declares_entry_points():
 
 def test_library_exports_every_declared_symbol():
     from tcow_amd import _lib
-    lib = _lib.lib()                      # raises TcowError if the .so is missing: the product has no fallback
-    for name in _declared():
-        assert hasattr(lib, name), f'{name} declared in tcow_hip.h but not exported by libtcow_hip.so'
-    assert lib.tcow_version() >= 1
-    assert isinstance(lib.tcow_last_error(), bytes)
+    for fmt in ('bf16', 'fp16'):          # both builds of the same sources: bfloat16 and binary16 storage of the 16-bit mode
+        lib = _lib.lib(fmt)               # raises TcowError if the .so is missing: the product has no fallback
+        for name in _declared():
+            assert hasattr(lib, name), f'{name} declared in tcow_hip.h but not exported by the {fmt} build'
+        assert lib.tcow_version() >= 4
+        assert isinstance(lib.tcow_last_error(), bytes)
+    assert _lib.lib('bf16') is not _lib.lib('fp16') and _lib.lib('bf16').tcow_version() == _lib.lib('fp16').tcow_version()
 
 
 def test_python_signatures_cover_the_header():
