@@ -8,7 +8,7 @@
 // side's tiles stream through LDS two at a time (f32, rows padded to 65 floats: conflict-free both for "lane = row" and "lane = column"
 // reads).  MFMA operand map (A: lane (l31, hi) supplies A[i = l31][k = hi], B: B[k = hi][j = l31], D register r of lane (l31, hi) =
 // D[crow32(r, hi)][l31]):
-//   forward   S^T?  no: S[key][query] = K Q^T   A = K tile (LDS, lane = key), B = Q fragment (registers)  -> lane = query, regs = 16 keys
+//   forward   S[key][query] = K Q^T             A = K tile (LDS, lane = key), B = Q fragment (registers)  -> lane = query, regs = 16 keys
 //             O^T[d][query] += V^T P^T          A = V tile (LDS, lane = d),   B = the lane's own probability registers (the contraction
 //                                               slot of step s is key crow32(s, hi) -- exactly the key register s of the lane holds)
 //   dQ        S, dP = V dO^T as above; dQ^T[d][query] += K^T dS^T with B = the lane's dS registers
@@ -301,6 +301,174 @@ __global__ __launch_bounds__(256, 2) void attn_f32_bwd_dkv(SeqDesc sd, int nt, c
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ one-tile sequences (temporal attention, T <= 32)
+// A sequence of <= 32 positions is ONE 32 x 32 work unit: in the kernels above three of a workgroup's four waves would idle.  Here every
+// wave owns its own (sequence, head): it stages its K / V (or Q / dO) tile in a private LDS region itself -- no workgroup barrier -- and
+// consecutive waves take consecutive heads of one site, so their 256-byte row pieces are neighbours in memory.
+__device__ __forceinline__ void stage_tile_wave(const float* __restrict__ src, long stride, int L, float* __restrict__ dst, int lane) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int i = lane + 64 * it, r = i >> 4, c4 = (i & 15) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < L) v = ld4(src + (size_t)r * stride + c4);
+        float* d = dst + r * TP + c4;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+}
+// fragment of tile row l31 read back from the wave's staged tile (per-lane row reads straight from global memory touch 32 cache lines per
+// 4-byte instruction: at T = 30 that, not the arithmetic, was the kernel)
+__device__ __forceinline__ void frag_from_tile(const float* __restrict__ tile, int l31, int hi, float scale, float (&f)[32]) {
+#pragma unroll
+    for (int s = 0; s < 32; ++s) f[s] = tile[l31 * TP + 2 * s + hi] * scale;
+}
+#define TCOW_WAVE_LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")     /* a wave's LDS operations execute in order; this keeps hipcc from reordering them */
+
+__global__ __launch_bounds__(256, 2) void attn_f32_fwd_solo(SeqDesc sd, const float* __restrict__ qkv, float* __restrict__ out, float* __restrict__ lse) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int pair = blockIdx.x * 4 + wave;
+    if (pair >= sd.n_outer * sd.n_inner * sd.heads) return;
+    const int item = pair / sd.heads, head = pair - item * sd.heads;
+    const long base = seq_base(sd, item);
+    const long ld3 = 3L * sd.D, pse = sd.pos_stride * ld3;
+    const float* qh = qkv + base * ld3 + head * HD;
+    // (Q stays a per-lane read from global memory here: a third staged tile would halve the workgroups per CU, measured 189 vs 121 us --
+    // this kernel moves 333 MB and sits at its memory time)
+    float* kt = smem + wave * (2 * TILE_F); float* vt = kt + TILE_F;
+    stage_tile_wave(qh + sd.D, pse, sd.L, kt, lane);
+    stage_tile_wave(qh + 2 * sd.D, pse, sd.L, vt, lane);
+    const int q = l31, qc = q < sd.L ? q : sd.L - 1;
+    float qf[32];
+    load_frag(qh + (size_t)qc * pse, hi, kScale, qf);
+    TCOW_WAVE_LDS_FENCE();
+    f32x16 s = mm_rows(kt, qf, l31, hi, zero16());
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int key = crow32(r, hi);
+        if (key >= sd.L || (long)key > (long)q + sd.diag) s[r] = kNeg;
+    }
+    float m = s[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) m = fmaxf(m, s[r]);
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    f32x16 p;
+    float l = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { p[r] = __expf(s[r] - m); l += p[r]; }
+    l += __shfl_xor(l, 32, 64);
+    const f32x16 o0 = mm_cols(vt, p, 0, l31, hi, zero16()), o1 = mm_cols(vt, p, 1, l31, hi, zero16());
+    if (q < sd.L) {
+        const float inv = 1.0f / l;
+        const long row = base + (long)q * sd.pos_stride;
+        float* orow = out + row * sd.D + head * HD;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            st4(orow + 8 * g + 4 * hi, make_float4(o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv));
+            st4(orow + 32 + 8 * g + 4 * hi, make_float4(o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv));
+        }
+        if (lse && hi == 0) lse[row * sd.heads + head] = m + __logf(l);
+    }
+}
+
+// dQ, dK and dV of a one-tile sequence in one pass: the wave stages all four tiles (K, V, Q, dO), computes the scores in both
+// orientations (lane = query for dQ, lane = key for dK / dV) and needs no delta round trip through memory.
+__global__ __launch_bounds__(256, 1) void attn_f32_bwd_solo(SeqDesc sd, const float* __restrict__ qkv, const float* __restrict__ o, const float* __restrict__ dout,
+                                                             const float* __restrict__ lse, float* __restrict__ dqkv) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int pair = blockIdx.x * 4 + wave;
+    if (pair >= sd.n_outer * sd.n_inner * sd.heads) return;
+    const int item = pair / sd.heads, head = pair - item * sd.heads;
+    const long base = seq_base(sd, item);
+    const long ld3 = 3L * sd.D, pse = sd.pos_stride * ld3, pso = sd.pos_stride * sd.D;
+    const float* qh = qkv + base * ld3 + head * HD;
+    const float* doh = dout + base * sd.D + head * HD;
+    float* kt = smem + wave * (4 * TILE_F + 64); float* vt = kt + TILE_F; float* qt_ = vt + TILE_F; float* ot_ = qt_ + TILE_F;
+    float* Ls = ot_ + TILE_F; float* Dl = Ls + 32;
+    stage_tile_wave(qh + sd.D, pse, sd.L, kt, lane);
+    stage_tile_wave(qh + 2 * sd.D, pse, sd.L, vt, lane);
+    stage_tile_wave(qh, pse, sd.L, qt_, lane);
+    stage_tile_wave(doh, pso, sd.L, ot_, lane);
+    const int pos = l31, pc = pos < sd.L ? pos : sd.L - 1;           // this lane's query (dQ side) and key (dK / dV side) position
+    const long row = base + (long)pc * sd.pos_stride;
+    // delta[q] = rowsum(dO * O): coalesced (16 lanes x 16 B per row), folded over the 16 lanes of a row
+    {
+        const float* oh = o + base * sd.D + head * HD;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int i = lane + 64 * it, r = i >> 4, c4 = (i & 15) * 4;
+            float part = 0.f;
+            if (r < sd.L) {
+                const float4 a = ld4(oh + (size_t)r * pso + c4), b = ld4(doh + (size_t)r * pso + c4);
+                part = (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w);
+            }
+            part += __shfl_xor(part, 1, 64); part += __shfl_xor(part, 2, 64); part += __shfl_xor(part, 4, 64); part += __shfl_xor(part, 8, 64);
+            if ((lane & 15) == 0) Dl[r] = part;
+        }
+        if (lane < 32) Ls[lane] = lse[(base + (long)(lane < sd.L ? lane : sd.L - 1) * sd.pos_stride) * sd.heads + head];
+    }
+    TCOW_WAVE_LDS_FENCE();
+    float qf[32], dof[32];
+    frag_from_tile(qt_, l31, hi, kScale, qf);
+    frag_from_tile(ot_, l31, hi, 1.0f, dof);
+    const float dl = Dl[l31], ls = Ls[l31];
+    // ---- dQ: lane = query
+    {
+        const f32x16 s = mm_rows(kt, qf, l31, hi, zero16());
+        const f32x16 dp = mm_rows(vt, dof, l31, hi, zero16());
+        f32x16 ds;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = crow32(r, hi);
+            const bool ok = key < sd.L && (long)key <= (long)pos + sd.diag;
+            const float p = ok ? __expf(s[r] - ls) : 0.f;
+            ds[r] = p * (dp[r] - dl);
+        }
+        const f32x16 dq0 = mm_cols(kt, ds, 0, l31, hi, zero16()), dq1 = mm_cols(kt, ds, 1, l31, hi, zero16());
+        if (pos < sd.L) {
+            float* drow = dqkv + row * ld3 + head * HD;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                st4(drow + 8 * g + 4 * hi, make_float4(dq0[4 * g] * kScale, dq0[4 * g + 1] * kScale, dq0[4 * g + 2] * kScale, dq0[4 * g + 3] * kScale));
+                st4(drow + 32 + 8 * g + 4 * hi, make_float4(dq1[4 * g] * kScale, dq1[4 * g + 1] * kScale, dq1[4 * g + 2] * kScale, dq1[4 * g + 3] * kScale));
+            }
+        }
+    }
+    // ---- dK, dV: lane = key
+    {
+        float kf[32], vf[32];
+        frag_from_tile(kt, l31, hi, 1.0f, kf);
+        frag_from_tile(vt, l31, hi, 1.0f, vf);
+        const f32x16 s = mm_rows(qt_, kf, l31, hi, zero16());          // S[query crow32(r, hi)][key l31], unscaled
+        const f32x16 dp = mm_rows(ot_, vf, l31, hi, zero16());
+        f32x16 p, ds;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qi = crow32(r, hi);
+            const bool ok = qi < sd.L && pos < sd.L && (long)pos <= (long)qi + sd.diag;
+            p[r] = ok ? __expf(s[r] * kScale - Ls[qi]) : 0.f;
+            ds[r] = p[r] * (dp[r] - Dl[qi]);
+        }
+        const f32x16 dv0 = mm_cols(ot_, p, 0, l31, hi, zero16()), dv1 = mm_cols(ot_, p, 1, l31, hi, zero16());
+        const f32x16 dk0 = mm_cols(qt_, ds, 0, l31, hi, zero16()), dk1 = mm_cols(qt_, ds, 1, l31, hi, zero16());
+        if (pos < sd.L) {
+            float* dkr = dqkv + row * ld3 + sd.D + head * HD;
+            float* dvr = dqkv + row * ld3 + 2 * sd.D + head * HD;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                st4(dkr + 8 * g + 4 * hi, make_float4(dk0[4 * g] * kScale, dk0[4 * g + 1] * kScale, dk0[4 * g + 2] * kScale, dk0[4 * g + 3] * kScale));
+                st4(dkr + 32 + 8 * g + 4 * hi, make_float4(dk1[4 * g] * kScale, dk1[4 * g + 1] * kScale, dk1[4 * g + 2] * kScale, dk1[4 * g + 3] * kScale));
+                st4(dvr + 8 * g + 4 * hi, make_float4(dv0[4 * g], dv0[4 * g + 1], dv0[4 * g + 2], dv0[4 * g + 3]));
+                st4(dvr + 32 + 8 * g + 4 * hi, make_float4(dv1[4 * g], dv1[4 * g + 1], dv1[4 * g + 2], dv1[4 * g + 3]));
+            }
+        }
+    }
+}
+
+constexpr int kLdsFwdSolo = 4 * 2 * TILE_F * 4;
+constexpr int kLdsBwdSolo = 4 * (4 * TILE_F + 64) * 4;
+
 constexpr int kLdsFwd = 2 * NC * TILE_F * 4;
 constexpr int kLdsDkv = (2 * NC * TILE_F + 2 * NC * 32) * 4;
 
@@ -308,6 +476,12 @@ constexpr int kLdsDkv = (2 * NC * TILE_F + 2 * NC * 32) * 4;
 
 int tcow_attn_f32_fwd(hipStream_t st, const SeqDesc& d, const void* qkv, void* out, float* lse) {
     const int nt = cdiv(d.L, 32), grid = grid_of(d.n_outer * d.n_inner * d.heads, cdiv(nt, 4));
+    if (nt == 1) {
+        tcow_ensure_lds((const void*)attn_f32_fwd_solo, kLdsFwdSolo);
+        hipLaunchKernelGGL(attn_f32_fwd_solo, dim3(cdiv(d.n_outer * d.n_inner * d.heads, 4)), dim3(256), kLdsFwdSolo, st, d, (const float*)qkv, (float*)out, lse);
+        TCOW_CHECK_LAUNCH();
+        return TCOW_OK;
+    }
     tcow_ensure_lds((const void*)attn_f32_fwd, kLdsFwd);
     hipLaunchKernelGGL(attn_f32_fwd, dim3(grid), dim3(256), kLdsFwd, st, d, nt, (const float*)qkv, (float*)out, lse);
     TCOW_CHECK_LAUNCH();
@@ -317,6 +491,13 @@ int tcow_attn_f32_fwd(hipStream_t st, const SeqDesc& d, const void* qkv, void* o
 // `delta` = rows * heads floats of workspace (the layout of lse)
 int tcow_attn_f32_bwd(hipStream_t st, const SeqDesc& d, const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv) {
     const int nt = cdiv(d.L, 32), grid = grid_of(d.n_outer * d.n_inner * d.heads, cdiv(nt, 4));
+    if (nt == 1) {
+        tcow_ensure_lds((const void*)attn_f32_bwd_solo, kLdsBwdSolo);
+        hipLaunchKernelGGL(attn_f32_bwd_solo, dim3(cdiv(d.n_outer * d.n_inner * d.heads, 4)), dim3(256), kLdsBwdSolo, st, d, (const float*)qkv, (const float*)out, (const float*)dout, lse,
+                           (float*)dqkv);
+        TCOW_CHECK_LAUNCH();
+        return TCOW_OK;
+    }
     tcow_ensure_lds((const void*)attn_f32_bwd_dq, kLdsFwd);
     tcow_ensure_lds((const void*)attn_f32_bwd_dkv, kLdsDkv);
     hipLaunchKernelGGL(attn_f32_bwd_dq, dim3(grid), dim3(256), kLdsFwd, st, d, nt, (const float*)qkv, (const float*)out, (const float*)dout, lse, delta, (float*)dqkv);
