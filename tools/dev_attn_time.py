@@ -23,4 +23,4 @@ ref = o.permute(1, 0, 2).reshape(S, D)
 ef = (out[:S].float() - ref).abs().max().item()
 (ref * dout[:S].float()).sum().backward()
 eb = (dqkv[:S].float().reshape(S, 3, heads, 64) - x.grad).abs().max().item()
-print(f'RES={os.environ.get("TCOW_ATTN_RES","1")} PIPE={os.environ.get("TCOW_ATTN_PIPE","0")}: spatial fwd {tf:.1f} us, bwd {tb:.1f} us | max|d| fwd {ef:.2e} bwd {eb:.2e} (ref max {ref.abs().max().item():.2f} / {x.grad.abs().max().item():.2f})', flush=True)
+print(f'spatial fwd {tf:.1f} us, bwd {tb:.1f} us | max|d| fwd {ef:.2e} bwd {eb:.2e} (ref max {ref.abs().max().item():.2f} / {x.grad.abs().max().item():.2f})', flush=True)
