@@ -68,6 +68,25 @@ def test_hard_negative_band_matches_reference_blur():
     assert int(hard_negative_band(tm, H, W).sum()) == int(g['hard_negative_band_sum'])   # equality with gaussian_blur>0 asserted at generation
 
 
+def test_hard_negative_band_equals_an_independent_gaussian_blur():
+    """loss.py:136-146 calls torchvision's gaussian_blur(target, k, sigma=k) (not installed here: no vector of the reference's can pin it).
+    Its published definition -- taps exp(-x^2 / 2 sigma^2) on x = -(k-1)/2 .. (k-1)/2, normalised, separable, reflect padding -- is what
+    scipy.ndimage.gaussian_filter(sigma=k, radius=k//2, mode='mirror') computes, so the box-dilation shortcut of hard_negative_band is checked
+    against that independent implementation on random masks, thin structures and border cases."""
+    from scipy.ndimage import gaussian_filter
+    from tcow_amd.tcow_loss import hard_negative_band
+    rng = np.random.default_rng(5)
+    for Hh, Ww in ((64, 64), (48, 80), (240, 320)):
+        k = int(np.sqrt(Hh * Ww) / 12.0); k += (k % 2 == 0)
+        for density in (0.0005, 0.01, 0.3):
+            t = (rng.random((2, Hh, Ww)) < density).astype(np.float32)
+            t[0, 0, :3] = 1.0; t[1, -1, -1] = 1.0; t[1, Hh // 2, :] = 1.0            # corners / borders / a line
+            blur = np.stack([gaussian_filter(x.astype(np.float64), sigma=float(k), radius=k // 2, mode='mirror') for x in t])
+            want = (blur > 0.0) & ~(t >= 0.5)
+            got = hard_negative_band(torch.from_numpy(t), Hh, Ww).numpy()
+            assert np.array_equal(got, want), (Hh, Ww, density)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('precision,tol', [('fp32', 2e-5), ('bf16', 2e-2)])
 def test_full_step_on_gpu_matches_reference(cuda, precision, tol):
