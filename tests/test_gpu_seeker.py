@@ -470,6 +470,30 @@ def test_fused_adamw_clip_matches_torch(cuda):
     assert opt.step_count == 3
 
 
+@pytest.mark.parametrize('precision', ['bf16', 'fp16', 'fp32'])
+def test_inference_forward_is_hipgraph_capturable(cuda, precision):
+    """The forward makes no host synchronisation and no allocation outside torch's pool, so it can be captured once and replayed as a
+    hipGraph (torch.cuda.CUDAGraph): replay == eager bit for bit, and the replay follows the static input buffers."""
+    cfg = synth.seeker_config(num_total_frames=4, frame_height=32, frame_width=48, embed_dim=128, depth=2, num_heads=2, causal_attention=1)
+    net = build_hip_seeker(cfg, synth.make_state_dict(cfg, 5), precision).cuda().eval()
+    clip = synth.make_clip(1, 4, 32, 48, seed=2)
+    rgb = torch.from_numpy(clip['rgb']).cuda(); qm = torch.from_numpy(synth.make_query_mask(clip, 0, 0)).cuda()
+    with torch.no_grad():
+        ref, ref_f = net(rgb, qm)
+        side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            net(rgb, qm)                                      # warm-up on the capture stream (weight copies, LDS attributes)
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out, fl = net(rgb, qm)
+        graph.replay(); torch.cuda.synchronize()
+        assert torch.equal(out, ref) and torch.equal(fl, ref_f)
+        rgb.mul_(0.5); graph.replay(); torch.cuda.synchronize()
+        again, _ = net(rgb, qm)
+        assert torch.equal(out, again) and not torch.equal(again, ref)
+
+
 def test_fp16_overflow_skips_the_step_and_lowers_the_loss_scale(cuda):
     """precision='fp16': a non-finite gradient (an overflow of the scaled binary16 backward) must not poison the weights: the fused
     clip + AdamW kernels skip the update (parameters and moments untouched) and the module's loss-scale exponent drops by 4, on the device;
