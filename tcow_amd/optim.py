@@ -37,6 +37,7 @@ class FusedAdamWClip(torch.optim.Optimizer):
         self.scratch = None
         self.on_step = []          # callables run after every step
         self._tracker = None
+        self.skipped_steps = None      # precision='fp16': how many steps the overflow guard has skipped (device int32 tensor once a step has run)
         if module is not None:     # a Seeker / QueryMaskTracker: batch re-cast of its GEMM operand copies right after the update
             tracker = getattr(module, 'seeker', module)
             self._tracker = tracker
@@ -103,6 +104,7 @@ class FusedAdamWClip(torch.optim.Optimizer):
         if ls is not None and ls.device == self.scratch.device:
             ok = torch.isfinite(self.scratch[-1])
             ls.copy_(torch.minimum(ls + torch.where(ok, 1.0 / 256.0, -4.0), torch.full_like(ls, -2.0)))
+            self.skipped_steps = (~ok).to(torch.int32) + (self.skipped_steps if self.skipped_steps is not None else 0)     # device counter, no sync
         torch._foreach_add_([self.state[p]['step'] for p in live], 1)   # CPU scalars, like torch.optim.AdamW keeps them (one call, not 247)
         torch.autograd.graph.increment_version(live)   # the kernels wrote through raw pointers: make the update visible to version checks
         for cb in self.on_step:

@@ -24,6 +24,8 @@ def run():
         mr = pipe.forward_kubric(data); loss = pipe.step_losses(data, mr, i / 1000.0)['total_seeker']; loss.backward(); opt.step()
         losses.append(loss.detach())
     torch.cuda.synchronize()
+    if precision == 'fp16':
+        print('fp16 loss-scale exponent at the end:', float(net.seeker.ls_log2), ' skipped steps:', int(opt.skipped_steps))
     return torch.stack(losses).cpu().numpy()
 a = run(); b = run()
 print(precision, 'finite:', bool(np.isfinite(a).all()), ' first/last loss: %.5f %.5f' % (a[0], a[-1]), ' identical runs:', bool((a == b).all()), ' max |a-b|: %.3e' % float(np.abs(a - b).max()))
