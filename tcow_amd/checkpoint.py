@@ -129,3 +129,38 @@ def load_tcow_checkpoint(path, logger=None, device='cuda', precision='bf16'):
     net.load_state_dict(ck['net_seeker'], strict=True)
     net.seeker.tracker_pretrained = flag
     return net.to(device)
+
+
+def save_tcow_checkpoint(directory, epoch, net, optimizer=None, lr_scheduler=None, seeker_args=None, train_args=None, dset_args=None, name='tcow_amd'):
+    """train.py:269-304 (`save_model_checkpoint`): the reference's checkpoint dictionary and side files, so that its own `--resume`
+    (train.py:246-257) and eval/inference.py:38-54 read what this framework trained.  `net` is the Seeker (un-wrapped: the reference
+    saves `networks_nodp`); optimizer / lr_scheduler state dicts use torch's layout (FusedAdamWClip keeps torch.optim.AdamW's)."""
+    import os
+    import numpy as np
+    os.makedirs(directory, exist_ok=True)
+    checkpoint = {'epoch': epoch, 'train_args': train_args, 'dset_args': dset_args if dset_args is not None else {},
+                  'seeker_args': dict(seeker_args) if seeker_args is not None else dict(getattr(net, 'seeker_args', {})),
+                  'net_seeker': {k: v.detach().cpu() for k, v in net.state_dict().items()}}
+    if optimizer is not None:
+        checkpoint['optim_seeker'] = optimizer.state_dict()
+    if lr_scheduler is not None:
+        checkpoint['lr_sched_seeker'] = lr_scheduler.state_dict()
+    path = os.path.join(directory, 'checkpoint.pth')
+    torch.save(checkpoint, path)
+    np.savetxt(os.path.join(directory, 'checkpoint_epoch.txt'), np.array([epoch], dtype=np.int32), fmt='%d')       # train.py:292-295
+    np.savetxt(os.path.join(directory, 'checkpoint_name.txt'), np.array([name]), fmt='%s')
+    return path
+
+
+def resume_tcow_checkpoint(path, net, optimizer=None, lr_scheduler=None):
+    """train.py:246-257: weights, optimizer and scheduler state of a checkpoint.pth into live objects; returns the epoch to start from."""
+    ck = _torch_load(path)
+    net.load_state_dict(ck['net_seeker'], strict=True)
+    tracker = getattr(net, 'seeker', None)
+    if tracker is not None and hasattr(tracker, 'invalidate_weight_cache'):
+        tracker.invalidate_weight_cache()
+    if optimizer is not None and ck.get('optim_seeker'):
+        optimizer.load_state_dict(ck['optim_seeker'])
+    if lr_scheduler is not None and ck.get('lr_sched_seeker'):
+        lr_scheduler.load_state_dict(ck['lr_sched_seeker'])
+    return int(ck['epoch']) + 1

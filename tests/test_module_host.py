@@ -154,3 +154,37 @@ def test_plugin_usage_modes_and_items():
     # snitch: round((t - start) / stride) -> t=4 -> 1, t=9 -> round(3.5) = 4 (banker's), t=11 -> round(4.5) = 4 (last write wins); occl: (11 - 2) // 2 = 4
     assert (tg[0, 1] == 1).all() and (tg[0, 4] == 1).all() and (tg[0, [0, 2, 3, 5]] == -1).all()
     assert (tg[1, 4] == 1).all() and (tg[1, [0, 1, 2, 3, 5]] == -1).all() and (tg[2] == -1).all()
+
+
+def test_checkpoint_written_here_resumes_the_reference_way(tmp_path):
+    """train.py:269-304 / :246-257: save_tcow_checkpoint writes the reference's dictionary (+ its side files); the reference's resume recipe
+    -- load_state_dict of net / torch.optim.AdamW / MultiStepLR from 'net_seeker' / 'optim_seeker' / 'lr_sched_seeker' -- accepts it, and
+    eval/inference.py's recipe (load_tcow_checkpoint) rebuilds the module from 'seeker_args'."""
+    import argparse
+    from tcow_amd.checkpoint import load_tcow_checkpoint, resume_tcow_checkpoint, save_tcow_checkpoint
+    from tcow_amd.optim import FusedAdamWClip
+    args = dict(num_total_frames=4, num_visible_frames=4, frame_height=32, frame_width=48, tracker_pretrained='0', attention_type='divided_space_time',
+                patch_size=16, causal_attention=1, norm_embeddings=False, drop_path_rate=0.1, network_depth=2, track_map_stride=4,
+                track_map_resize='bilinear', query_channels=1, output_channels=3, flag_channels=3, embed_dim=64, num_heads=1)      # (explicit small geometry: a host-logic test)
+    net = Seeker(None, **args)
+    opt = FusedAdamWClip(list(net.parameters()), lr=1e-4, max_norm=0.3)
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt, [3, 6], gamma=0.3)
+    for p_ in list(net.parameters())[:4]:                                  # give the optimizer some state in torch.optim.AdamW's layout
+        opt.state[p_] = {'step': torch.tensor(5.0), 'exp_avg': torch.full_like(p_, 0.25), 'exp_avg_sq': torch.full_like(p_, 0.5)}
+    sched.last_epoch = 4
+    path = save_tcow_checkpoint(str(tmp_path), 4, net, opt, sched, seeker_args=args, train_args=argparse.Namespace(name='run'), dset_args={'n': 1}, name='run')
+    assert (tmp_path / 'checkpoint_epoch.txt').read_text().strip() == '4' and (tmp_path / 'checkpoint_name.txt').read_text().strip() == 'run'
+    ck = torch.load(path, map_location='cpu', weights_only=False)
+    assert sorted(ck) == ['dset_args', 'epoch', 'lr_sched_seeker', 'net_seeker', 'optim_seeker', 'seeker_args', 'train_args']
+    # the reference's resume (train.py:246-257) with stock torch objects
+    net2 = Seeker(None, **args)
+    ref_opt = torch.optim.AdamW(net2.parameters(), lr=1e-4); ref_sched = torch.optim.lr_scheduler.MultiStepLR(ref_opt, [3, 6], gamma=0.3)
+    net2.load_state_dict(ck['net_seeker']); ref_opt.load_state_dict(ck['optim_seeker']); ref_sched.load_state_dict(ck['lr_sched_seeker'])
+    assert all(torch.equal(a, b) for a, b in zip(net.state_dict().values(), net2.state_dict().values()))
+    first = next(iter(net2.parameters()))
+    assert float(ref_opt.state[first]['exp_avg'].flatten()[0]) == 0.25 and ref_sched.last_epoch == 4
+    # ... and ours
+    net3 = Seeker(None, **args); opt3 = FusedAdamWClip(list(net3.parameters()), lr=1e-4); sched3 = torch.optim.lr_scheduler.MultiStepLR(opt3, [3, 6], gamma=0.3)
+    assert resume_tcow_checkpoint(path, net3, opt3, sched3) == 5 and opt3.step_count == 5
+    net4 = load_tcow_checkpoint(path, device='cpu')
+    assert all(torch.equal(a, b) for a, b in zip(net.state_dict().values(), net4.state_dict().values()))
