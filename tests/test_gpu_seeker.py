@@ -576,3 +576,44 @@ def test_training_is_bitwise_reproducible(cuda):
     assert np.isfinite(la).all()
     assert np.array_equal(la, lb), (la, lb)
     assert np.array_equal(wa, wb)
+
+
+@pytest.mark.parametrize('seed', list(range(16)))
+def test_random_geometries_vs_oracle(cuda, seed):
+    """Sixteen random small geometries (frames 1..9, 1..5 x 1..6 patches, D in {64, 128, 192}, depth 1..3, every causal_attention value,
+    track-map stride / resize, norm_embeddings, rgb normalisation, 1..3 clips): forward AND gradients of the HIP module against the
+    oracle (the CPU restatement pinned to the reference by tests/test_oracle_golden.py) -- fp32 to 1e-5 / 2e-4, fp16 and bf16 to their
+    rounding bounds.  Catches what fixed goldens cannot: single-frame clips, one-patch frames, sequences of length 2, ragged tiles."""
+    from oracle import seeker_oracle as so
+    rng = np.random.default_rng(1000 + seed)
+    T = int(rng.integers(1, 10)); Hp = int(rng.integers(1, 6)); Wp = int(rng.integers(1, 7)); D = int(rng.choice([64, 128, 192]))
+    st = int(rng.choice([1, 2, 4]))
+    cfg = synth.seeker_config(num_total_frames=T, frame_height=16 * Hp, frame_width=16 * Wp, embed_dim=D, depth=int(rng.integers(1, 4)), num_heads=D // 64,
+                              causal_attention=int(rng.choice([-1, 0, 1, 2, 3, 4])), norm_embeddings=bool(rng.integers(0, 2)), track_map_stride=st,
+                              track_map_resize=str(rng.choice(['bilinear', 'nearest'])), pretrained_norm=bool(rng.integers(0, 2)))
+    sd = synth.make_state_dict(cfg, 2000 + seed)
+    B = int(rng.integers(1, 4))
+    clip = synth.make_clip(B, T, 16 * Hp, 16 * Wp, seed=3000 + seed)
+    rgb = torch.from_numpy(clip['rgb']); qm = torch.cat([torch.from_numpy(synth.make_query_mask(clip, 0, 0))] * 1, 0)
+    if qm.shape[0] != B:
+        qm = qm.expand(B, -1, -1, -1, -1).contiguous()
+    tsd = so.to_torch_state_dict(sd)
+    for v in tsd.values():
+        v.requires_grad_(True)
+    om_r, fl_r = so.seeker_forward(tsd, cfg, rgb, qm)
+    Gm = torch.from_numpy(rng.standard_normal(size=tuple(om_r.shape)).astype(np.float32)); Gf = torch.from_numpy(rng.standard_normal(size=tuple(fl_r.shape)).astype(np.float32))
+    ((om_r * Gm).sum() + (fl_r * Gf).sum()).backward()
+    std = float(om_r.detach().std()) + 1e-6; fstd = float(fl_r.detach().std()) + 1e-6
+    for precision, tol, ftol, gtol in (('fp32', 1e-5, 1e-5, 2e-4), ('fp16', 0.00625 * std + 1e-5, 0.0015 * fstd + 2e-5, 5e-3), ('bf16', 0.05 * std + 1e-4, 0.012 * fstd + 2e-4, 4e-2)):
+        net = build_hip_seeker(cfg, sd, precision).cuda().train()           # drop_path_rate 0: train mode only to get gradients
+        om, fl = net(rgb.cuda(), qm.cuda())
+        assert float((om.detach().cpu() - om_r.detach()).abs().max()) < tol, (precision, cfg)
+        assert float((fl.detach().cpu() - fl_r.detach()).abs().max()) < ftol, (precision, cfg)
+        ((om * Gm.cuda()).sum() + (fl * Gf.cuda()).sum()).backward()
+        for k, p_ in net.named_parameters():
+            ref = tsd[k].grad
+            if ref is None or float(ref.abs().max()) == 0.0:
+                assert p_.grad is None or float(p_.grad.abs().max()) <= gtol, (precision, k)
+                continue
+            assert p_.grad is not None, (precision, k)
+            assert float((p_.grad.cpu() - ref).abs().max()) <= gtol * float(ref.abs().max()) + 1e-7, (precision, k, cfg)
