@@ -88,7 +88,7 @@ def test_hard_negative_band_equals_an_independent_gaussian_blur():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('precision,tol', [('fp32', 2e-5), ('bf16', 2e-2)])
+@pytest.mark.parametrize('precision,tol', [('fp32', 2e-5), ('bf16x3', 1e-4), ('fp16', 2.5e-3), ('bf16', 2e-2)])
 def test_full_step_on_gpu_matches_reference(cuda, precision, tol):
     """Synthetic Kubric batch -> HIP Seeker (3 queries batched) -> TCOW loss -> backward, vs the reference's scalars."""
     _, g = load_golden('g5_pipeline_cfg1')
@@ -97,15 +97,15 @@ def test_full_step_on_gpu_matches_reference(cuda, precision, tol):
     pipe = SeekerPipeline(net, num_queries=Qs, train_args=default_args(hard_negative_factor=1.0), phase='train', device='cuda')
     data = _data('cuda')
     mr = pipe.forward_kubric(data, sel_query_inds=torch.from_numpy(g['train::sel_query_inds']))
-    assert float((mr['output_mask'].detach().cpu() - torch.from_numpy(g['train::output_mask'])).abs().max()) < (1e-4 if precision == 'fp32' else 5e-3)
+    assert float((mr['output_mask'].detach().cpu() - torch.from_numpy(g['train::output_mask'])).abs().max()) < {'fp32': 1e-4, 'bf16x3': 1e-4, 'fp16': 6.3e-4}.get(precision, 5e-3)
     res = pipe.step_losses(data, mr, 0.0)
     assert abs(float(res['total_seeker']) - float(g['train_p0::total_seeker'])) < tol
     res['total_seeker'].backward()
     gn = sum(float(p.grad.norm()) ** 2 for p in net.parameters() if p.grad is not None) ** 0.5
-    assert abs(gn - float(g['train::grad_norm_total'])) < (1e-3 if precision == 'fp32' else 5e-2) * float(g['train::grad_norm_total'])
+    assert abs(gn - float(g['train::grad_norm_total'])) < {'fp32': 1e-3, 'bf16x3': 1e-3, 'fp16': 6.3e-3}.get(precision, 5e-2) * float(g['train::grad_norm_total'])
     gb = net.seeker.tracker_post_linear.bias.grad.cpu().numpy()
     ref = g['train::grad::seeker.tracker_post_linear.bias']
-    assert np.abs(gb - ref).max() < (1e-4 if precision == 'fp32' else 5e-2) * np.abs(ref).max() + 1e-8
+    assert np.abs(gb - ref).max() < {'fp32': 1e-4, 'bf16x3': 2e-4, 'fp16': 6.3e-3}.get(precision, 5e-2) * np.abs(ref).max() + 1e-8
 
 
 @pytest.mark.gpu
