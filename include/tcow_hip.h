@@ -214,8 +214,9 @@ int tcow_scale_cast(void* stream, int dtype, long rows, int D, const float* src,
                     void* dst, long ld_dst);
 int tcow_cast_transpose(void* stream, int dtype, int N, int K, const float* W, void* Wc, void* Wt);
 /* The same for many weights in one launch: `table` is a device array of n records {const float* W; void* Wc; void* Wt; int N;
- * int K; int tile_begin; int pad} (tcow_cast_desc_bytes() bytes each, 8-byte aligned), tile_begin = running sum of
- * ceil(N/32) * ceil(K/32) over the preceding records, total_tiles = that sum over all records.  Wc / Wt may be NULL per record. */
+ * int K; int tile_begin; int tile} (tcow_cast_desc_bytes() bytes each, 8-byte aligned), tile = tile edge E of the record: 64 (only
+ * if N % 64 == 0 and K % 64 == 0: the vectorised path) or anything else = 32; tile_begin = running sum of ceil(N/E) * ceil(K/E)
+ * over the preceding records, total_tiles = that sum over all records.  Wc / Wt may be NULL per record. */
 long tcow_cast_desc_bytes(void);
 int tcow_cast_transpose_batched(void* stream, int dtype, const void* table, int n, int total_tiles);
 

@@ -287,20 +287,43 @@ __global__ __launch_bounds__(1024) void flags_fwd_kernel(int S, int D, int F, co
     }
 }
 
-// All operand copies of a step in ONE launch: a device-resident table of (W, Wc, Wt, N, K, first tile) records, one 32x32 tile per
-// workgroup; the workgroup finds its record by bisection on the first-tile column (86 weights -> 7 steps).
-struct CastDesc { const float* W; void* Wc; void* Wt; int N, K, tile_begin, pad; };
+// All operand copies of a step in ONE launch: a device-resident table of (W, Wc, Wt, N, K, first tile) records, one tile per workgroup; the
+// workgroup finds its record by bisection on the first-tile column (86 weights -> 7 steps).  Tile edge = record.tile (32 or 64): the caller
+// counts 64 x 64 tiles when every N and K is a multiple of 64 (all GEMM weights of the reference geometries) -- 16-byte loads and 8-byte
+// (16-bit) / 16-byte (f32) stores instead of one element per thread (389 -> ~200 us for the 120 M weights of ViT-B).
+struct CastDesc { const float* W; void* Wc; void* Wt; int N, K, tile_begin, tile; };
 template <typename T>
 __global__ __launch_bounds__(256) void cast_transpose_batched_kernel(const CastDesc* __restrict__ tab, int n) {
-    __shared__ float tile[32][33];
+    __shared__ float tile[64][65];
     int lo = 0, hi = n - 1;
     const int b = blockIdx.x;
     while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (tab[mid].tile_begin <= b) lo = mid; else hi = mid - 1; }
     const CastDesc d = tab[lo];
+    T* Wc = reinterpret_cast<T*>(d.Wc); T* Wt = reinterpret_cast<T*>(d.Wt);
+    if (d.tile == 64) {                                   // N % 64 == 0 and K % 64 == 0: no edge handling
+        const int t = b - d.tile_begin, tiles_k = d.K >> 6;
+        const int n0 = (t / tiles_k) * 64, k0 = (t - (t / tiles_k) * tiles_k) * 64;
+        const int c4 = (threadIdx.x & 15) * 4, r0 = threadIdx.x >> 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = r0 + 16 * i;
+            const float4 v = ld4(d.W + (size_t)(n0 + r) * d.K + k0 + c4);
+            if (Wc) st4(Wc + (size_t)(n0 + r) * d.K + k0 + c4, v);
+            tile[r][c4] = v.x; tile[r][c4 + 1] = v.y; tile[r][c4 + 2] = v.z; tile[r][c4 + 3] = v.w;
+        }
+        __syncthreads();
+        if (Wt) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int k = r0 + 16 * i;
+                st4(Wt + (size_t)(k0 + k) * d.N + n0 + c4, make_float4(tile[c4][k], tile[c4 + 1][k], tile[c4 + 2][k], tile[c4 + 3][k]));
+            }
+        }
+        return;
+    }
     const int t = b - d.tile_begin, tiles_k = (d.K + 31) / 32;
     const int n0 = (t / tiles_k) * 32, k0 = (t - (t / tiles_k) * tiles_k) * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    T* Wc = reinterpret_cast<T*>(d.Wc); T* Wt = reinterpret_cast<T*>(d.Wt);
     for (int r = ty; r < 32; r += 8) {
         const int nn = n0 + r, k = k0 + tx;
         float v = 0.f;

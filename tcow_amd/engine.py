@@ -88,9 +88,10 @@ def refresh_weights(module):
     tab = module.__dict__.get('_wtab')
     if tab is None or tab[0] != sig:
         rec, tiles = [], 0
+        edge = 64 if all(N % 64 == 0 and K % 64 == 0 for _, (_, _, _, N, K) in ents) else 32     # tile edge of tcow_cast_transpose_batched (all records alike)
         for k, (p, Wc, Wt, N, K) in ents:
-            rec.append(struct.pack('<QQQiiii', p.data_ptr(), 0 if Wc is None else Wc.data_ptr(), 0 if Wt is None else Wt.data_ptr(), N, K, tiles, 0))
-            tiles += ((N + 31) // 32) * ((K + 31) // 32)
+            rec.append(struct.pack('<QQQiiii', p.data_ptr(), 0 if Wc is None else Wc.data_ptr(), 0 if Wt is None else Wt.data_ptr(), N, K, tiles, edge))
+            tiles += ((N + edge - 1) // edge) * ((K + edge - 1) // edge)
         assert len(rec[0]) == L_cast_desc_bytes()
         dev = ents[0][1][0].device
         buf = torch.frombuffer(bytearray(b''.join(rec)), dtype=torch.uint8).to(dev)
