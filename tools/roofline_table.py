@@ -31,7 +31,7 @@ c, t = fam('gemm_nt_bf16'); row('NT GEMM (forward + input gradients, fused epilo
 c, t = fam('gemm_tn_bf16'); c2, t2 = fam('slab_reduce4'); row('weight-gradient GEMM (grouped) + folds', c + c2, t + t2, tn_flops, None, 'LDS-bound on the transpose reads')
 c, t = fam('attn_fwd_stream'); row('spatial attention forward', c, t, sp_f, L * (qkv_b + o_b), 'VALU-bound (d = 64: 16 v_exp_f32 per 8 MFMAs)')
 c, t = fam('attn_bwd_dq_stream', 'attn_bwd_dkv_stream'); row('spatial attention backward (dQ + dK/dV)', c, t, 2.5 * sp_f, L * (2 * qkv_b + 2 * o_b + qkv_b), 'VALU / latency-bound (d = 64)')
-c, t = fam('attn_fwd_mfma<false>'); row('temporal attention forward', c, t, tp_f, L * (qkv_b + o_b), 'HBM-bound')
+c, t = fam('attn_fwd_mfma<false>'); row('temporal attention forward', c, t, tp_f, L * (qkv_b + o_b), 'HBM-bound; the strided row pattern itself streams at 3.9 TB/s (tools/dev_stride_copy.py)')
 c, t = fam('attn_bwd_one_tile'); row('temporal attention backward', c, t, 2.5 * tp_f, L * (2 * qkv_b + 2 * o_b), 'HBM-bound')
 c, t = fam('ln_fwd_kernel'); row('LayerNorm forward', c, t, None, c * M * D * 6.0, 'HBM-bound')
 c, t = fam('ln_bwd_kernel'); row('LayerNorm backward (+ residual add, + cast of dx on 2 of 3)', c, t, None, c * M * D * (2 + 4 + 4 + 4 + 2 * 2 / 3.0), 'HBM-bound')
