@@ -2,6 +2,8 @@
 // vit.py:135 norm1, :142 temporal_norm1, :150 norm2, :283 norm; eps from vit.py:428).
 // One wave per token row, the row lives in registers (D <= 2048), statistics by wavefront reduction.
 // Memory-bound: reads 4*D bytes and writes sizeof(T)*D bytes per row.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -12,43 +14,59 @@ template <typename T, int NV>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(int rows, int D, const float* __restrict__ x, long ldx, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float eps, T* __restrict__ y, long ldy,
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+    // Grid-stride over rows with the NEXT row's loads issued before this row's reductions and stores (one row per wave and launch-sized
+    // grids left every wave a serial load -> reduce -> reduce -> store chain: 5.0 TB/s where a plain copy of the same bytes reaches 7).
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
     const int nv = D >> 2;  // float4 count
-    const float* xr = x + (size_t)row * ldx;
-    float4 v[NV];
-    float s = 0.f;
+    const int rstep = gridDim.x * 4;
+    int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float4 g[NV], b[NV], nx[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = lane + i * 64;
-        if (c < nv) { v[i] = ld4(xr + c * 4); s += (v[i].x + v[i].y) + (v[i].z + v[i].w); }
+        if (c < nv) { g[i] = ld4(gamma + c * 4); b[i] = ld4(beta + c * 4); nx[i] = ld4(x + (size_t)row * ldx + c * 4); }
     }
-    const float mean = wave_sum(s) / (float)D;
-    float q = 0.f;
+    for (; row < rows; row += rstep) {
+        float4 v[NV];
+        float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c = lane + i * 64;
-        if (c < nv) {
-            const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
-            q += (a * a + b * b) + (cc * cc + d * d);
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + i * 64;
+            if (c < nv) { v[i] = nx[i]; s += (v[i].x + v[i].y) + (v[i].z + v[i].w); }
         }
-    }
-    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
-    if (lane == 0) {
-        if (mean_out) mean_out[row] = mean;
-        if (rstd_out) rstd_out[row] = rstd;
-    }
-    T* yr = y + (size_t)row * ldy;
+        if (row + rstep < rows) {
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c = lane + i * 64;
-        if (c < nv) {
-            const float4 g = ld4(gamma + c * 4), b = ld4(beta + c * 4);
-            float4 o;
-            o.x = (v[i].x - mean) * rstd * g.x + b.x; o.y = (v[i].y - mean) * rstd * g.y + b.y;
-            o.z = (v[i].z - mean) * rstd * g.z + b.z; o.w = (v[i].w - mean) * rstd * g.w + b.w;
-            st4(yr + c * 4, o);
+            for (int i = 0; i < NV; ++i) {
+                const int c = lane + i * 64;
+                if (c < nv) nx[i] = ld4(x + (size_t)(row + rstep) * ldx + c * 4);
+            }
+        }
+        const float mean = wave_sum(s) / (float)D;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + i * 64;
+            if (c < nv) {
+                const float a = v[i].x - mean, bb = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+                q += (a * a + bb * bb) + (cc * cc + d * d);
+            }
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+        if (lane == 0) {
+            if (mean_out) mean_out[row] = mean;
+            if (rstd_out) rstd_out[row] = rstd;
+        }
+        T* yr = y + (size_t)row * ldy;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + i * 64;
+            if (c < nv) {
+                float4 o;
+                o.x = (v[i].x - mean) * rstd * g[i].x + b[i].x; o.y = (v[i].y - mean) * rstd * g[i].y + b[i].y;
+                o.z = (v[i].z - mean) * rstd * g[i].z + b[i].z; o.w = (v[i].w - mean) * rstd * g[i].w + b[i].w;
+                st4(yr + c * 4, o);
+            }
         }
     }
 }
@@ -149,6 +167,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int D, const T* _
 int tcow_launch_row_reduce2(hipStream_t stream, const float* part, int nrows, long ld, int N1, float* out1, int N2, float* out2, int accumulate);
 
 static const int kLnBwdBlocks = 512;
+static const int kLnFwdBlocks = [] { const char* e = getenv("TCOW_LN_FWD_BLOCKS"); return e ? atoi(e) : 4096; }();     // grid-stride blocks of the forward (512 ... 8192 measured within 6 %: tools/dev_ln_time.py)
 
 extern "C" {
 
@@ -156,7 +175,8 @@ int tcow_layernorm_fwd(void* stream, int dtype, int rows, int D, const float* x,
                        long ldy, float* mean, float* rstd) {
     TCOW_CHECK_ARG(rows > 0 && D > 0 && D % 4 == 0 && D <= 64 * 4 * LN_MAXV, "tcow_layernorm_fwd: D=%d must be a multiple of 4 and <= %d", D, 64 * 4 * LN_MAXV);
     TCOW_CHECK_ARG(x && gamma && beta && y && ldx % 4 == 0 && ldy % 4 == 0, "tcow_layernorm_fwd: bad pointers / strides");
-    const dim3 grid(cdiv(rows, 4)), block(256);
+    int fblocks = cdiv(rows, 4); if (fblocks > kLnFwdBlocks) fblocks = kLnFwdBlocks;
+    const dim3 grid(fblocks), block(256);
     if (dtype != TCOW_BF16 && dtype != TCOW_F32) { tcow_set_error("tcow_layernorm_fwd: unknown dtype %d", dtype); return TCOW_ERR_INVALID_ARG; }
     const int nvl = (D / 4 + 63) / 64;
 #define LN_FWD(NVV)                                                                                                                               \
