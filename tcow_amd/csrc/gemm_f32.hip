@@ -155,8 +155,17 @@ __global__ __launch_bounds__(256) void row_reduce_kernel(const float* __restrict
     __shared__ float red[16][17];
     const int c = blockIdx.x * 16 + (threadIdx.x & 15), g = threadIdx.x >> 4;
     float s = 0.f;
-    if (c < N)
-        for (int r = g; r < nrows; r += 16) s += part[(size_t)r * ld + c];
+    if (c < N) {
+        // 8 independent loads in flight per thread: the table is small (a few MB), the kernel is pure load latency
+        int r = g;
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (; r + 7 * 16 < nrows; r += 8 * 16) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] += part[(size_t)(r + 16 * u) * ld + c];
+        }
+        for (; r < nrows; r += 16) a[0] += part[(size_t)r * ld + c];
+        s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    }
     red[g][threadIdx.x & 15] = s;
     __syncthreads();
     if (g == 0 && c < N) {
