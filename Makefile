@@ -15,7 +15,7 @@ LIB16 := tcow_amd/libtcow_hip_fp16.so
 all: $(LIB) $(LIB16)
 
 # (attention: no NaN arithmetic on the path -- lets fmaxf chains become v_max3_f32 without canonicalising v_max instructions)
-$(OBJ)/attention_bf16.hip.o: EXTRA := -fno-honor-nans
+$(OBJ)/attention_bf16.hip.o: EXTRA := -fno-honor-nans -fno-slp-vectorize
 $(OBJ)/%.hip.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/gemm_f32.h include/tcow_hip.h
 	@mkdir -p $(OBJ)
 	$(HIPCC) $(HIPFLAGS) $(EXTRA) -x hip -c $< -o $@
@@ -27,7 +27,7 @@ $(OBJ)/%.cpp.o: $(CSRC)/%.cpp $(CSRC)/common.h include/tcow_hip.h
 $(LIB): $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
 
-$(OBJ16)/attention_bf16.hip.o: EXTRA := -fno-honor-nans
+$(OBJ16)/attention_bf16.hip.o: EXTRA := -fno-honor-nans -fno-slp-vectorize
 $(OBJ16)/%.hip.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/gemm_f32.h include/tcow_hip.h
 	@mkdir -p $(OBJ16)
 	$(HIPCC) $(HIPFLAGS) $(EXTRA) -DTCOW_FP16 -x hip -c $< -o $@
@@ -42,3 +42,9 @@ $(LIB16): $(OBJS16)
 clean:
 	rm -rf build $(LIB) $(LIB16)
 .PHONY: all clean
+
+# microbenchmarks (run on the GPU box: build/ubench_valu > profiles/rNN_ubench_valu.txt)
+ubench: build/ubench_valu
+build/ubench_valu: tools/ubench_valu.hip $(CSRC)/attention_bf16.hip $(CSRC)/common.h
+	@mkdir -p build
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fno-honor-nans -fno-slp-vectorize -Wno-unused-result -x hip $< -o $@

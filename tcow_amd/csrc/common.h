@@ -14,9 +14,11 @@
 #ifdef TCOW_FP16
 typedef _Float16 tcow_h16;
 #define TCOW_MFMA_32x32x16_H16 __builtin_amdgcn_mfma_f32_32x32x16_f16
+#define TCOW_MFMA_32x32x16_H16_ASM "v_mfma_f32_32x32x16_f16"
 #else
 typedef __bf16 tcow_h16;
 #define TCOW_MFMA_32x32x16_H16 __builtin_amdgcn_mfma_f32_32x32x16_bf16
+#define TCOW_MFMA_32x32x16_H16_ASM "v_mfma_f32_32x32x16_bf16"
 #endif
 typedef __attribute__((ext_vector_type(8))) tcow_h16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) tcow_h16 bf16x4;
