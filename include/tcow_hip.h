@@ -60,12 +60,15 @@ int tcow_version(void);
 const char* tcow_last_error(void);
 
 /* ------------------------------------------------------------------------------------------------ GEMM
- * C[M,N] = epilogue( A[M,K] . W[N,K]^T ),  v = acc + bias[n];  v *= row_scale[m];  act;  v += resid[m,n].
+ * C[M,N] = epilogue( A[M,K] . W[N,K]^T ),  v = acc + bias[n];  v *= row_scale[m];  act;  v += row_scale2[m] * bias2[n];  v += resid[m,n].
  * Replaces every nn.Linear on the path: Attention.qkv / .proj (vit.py:74-76,81,111), Block.temporal_fc
  * (vit.py:146,174), Mlp.fc1 / GELU / fc2 (vit.py:50-61), PatchEmbed.proj as a GEMM over flattened patches
  * (vit.py:233-240), tracker_post_linear (mask_tracker.py:113) and their input-gradient GEMMs
  * (dA = dC . W with W passed pre-transposed).  Residual adds x + f(x) (vit.py:176,215-216) and DropPath row
- * scaling (vit_utils.py:139-154) are fused through `resid` / `row_scale`.
+ * scaling (vit_utils.py:139-154) are fused through `resid` / `row_scale`.  bias2 / row_scale2 (both or neither; NULL row_scale2 = 1)
+ * serve the FOLDED temporal projection: temporal_attn.proj -> DropPath -> temporal_fc (vit.py:111,172-176) are two Linear layers with
+ * only a per-row scale s between them, so R1 = R0 + mask0 * (s * (O W'^T + b') + b_fc) with W' = W_fc W_proj, b' = W_fc b_proj:
+ * one GEMM with bias = b', row_scale = mask0 * s, bias2 = b_fc, row_scale2 = mask0 (engine.py).
  * A, W: `dtype` elements, K-contiguous rows (lda, ldw in elements, multiples of 8; K % 8 == 0).
  * C: `dtype` elements, or f32 when out_f32 != 0.  resid: f32 [M, ldr] or NULL (may alias C when out_f32).
  * aux: `dtype` [M, ldaux]; written for TCOW_ACT_GELU (when non-NULL) and TCOW_ACT_GELU_DSAVE, read for TCOW_ACT_DGELU
@@ -84,6 +87,8 @@ typedef struct {
     int act;
     void* aux; long ldaux;
     int tile;              /* 0 = choose by shape; 128 / 256 / 320 = force that bf16 NT tile kernel (tests and A/B runs) */
+    const float* bias2;        /* second bias [N] with its own row scale (may be NULL) */
+    const float* row_scale2;   /* [M] or NULL */
 } tcow_gemm_args;
 int tcow_gemm_nt(void* stream, const tcow_gemm_args* args);
 
@@ -118,6 +123,19 @@ typedef struct {
 long tcow_gemm_tn_grouped_workspace_bytes(int dtype, int n, const tcow_tn_problem* problems);
 int tcow_gemm_tn_grouped(void* stream, int dtype, int n, const tcow_tn_problem* problems, void* workspace, long workspace_bytes);
 
+/* Small f32 products C[M,N] = A B for the folded temporal projection (W' = W_fc W_proj after every optimizer step;
+ * dW_fc = dW' W_proj^T + db' b_proj^T, dW_proj = W_fc^T dW', db_proj = W_fc^T db' in the backward): up to 24 problems per launch on the split-bf16 arithmetic of TCOW_F32X3
+ * (three bf16 MFMAs per product, ~5e-6 relative).  A(i,k) = A[i*sai + k*sak], B(j,k) = B[j*sbj + k*sbk] -- one stride of each operand
+ * should be 1 (16-byte aligned, extents multiples of 4) for the vector loaders; all problems of a call should share the operand forms. */
+typedef struct {
+    int M, N, K;
+    const float* A; long sai, sak;
+    const float* B; long sbj, sbk;
+    float* C; long ldc;
+    int accumulate;        /* != 0: C += A B */
+} tcow_sgemm;
+int tcow_sgemm_x3_batched(void* stream, int n, const tcow_sgemm* problems);
+
 /* ------------------------------------------------------------------------------------------- LayerNorm
  * y = (x - mean) / sqrt(var + eps) * gamma + beta over the last dimension of the f32 residual stream
  * (nn.LayerNorm(D, eps=1e-6): vit.py:135 norm1, :142 temporal_norm1, :150 norm2, :283 norm; eps vit.py:428).
@@ -125,14 +143,17 @@ int tcow_gemm_tn_grouped(void* stream, int dtype, int n, const tcow_tn_problem* 
  * Backward: dx = dres + dLN(dy) (dres = gradient arriving through the residual connection, may be NULL),
  * dgamma / dbeta (+)= column sums (both NULL to skip; otherwise workspace of tcow_layernorm_bwd_workspace_bytes).
  * dx_cast (may be NULL) additionally receives dtype(dx * cast_row_scale[row]) (scale NULL = 1): the operand of the
- * input-gradient GEMM that consumes this gradient next, without a separate tcow_scale_cast pass. */
+ * input-gradient GEMM that consumes this gradient next, without a separate tcow_scale_cast pass.
+ * colsum_out (may be NULL; needs dgamma / dbeta) (+)= sum_rows colsum_row_scale[row] * dx[row] (scale NULL = 1) in f32: the bias gradient
+ * of the Linear layer whose output fed this norm's residual stream under a row mask (temporal_fc.bias, vit.py:146,174-176). */
 int tcow_layernorm_fwd(void* stream, int dtype, int rows, int D, const float* x, long ldx, const float* gamma,
                        const float* beta, float eps, void* y, long ldy, float* mean, float* rstd);
 long tcow_layernorm_bwd_workspace_bytes(int D);
 int tcow_layernorm_bwd(void* stream, int dtype, int rows, int D, const void* dy, long lddy, const float* x, long ldx,
                        const float* mean, const float* rstd, const float* gamma, const float* dres, long lddres,
                        float* dx, long lddx, float* dgamma, float* dbeta, int accumulate, void* workspace,
-                       long workspace_bytes, void* dx_cast, long lddx_cast, const float* cast_row_scale);
+                       long workspace_bytes, void* dx_cast, long lddx_cast, const float* cast_row_scale,
+                       const float* colsum_row_scale, float* colsum_out);
 
 /* ------------------------------------------------------------------------------------------- attention
  * softmax(q k^T / 8 [mask]) v per head (head_dim 64) straight on the qkv GEMM output [rows, 3D]

@@ -28,7 +28,15 @@ class GemmArgs(ctypes.Structure):
                 ('A', ctypes.c_void_p), ('lda', ctypes.c_long), ('W', ctypes.c_void_p), ('ldw', ctypes.c_long),
                 ('C', ctypes.c_void_p), ('ldc', ctypes.c_long), ('out_f32', ctypes.c_int),
                 ('bias', ctypes.c_void_p), ('row_scale', ctypes.c_void_p), ('resid', ctypes.c_void_p),
-                ('ldr', ctypes.c_long), ('act', ctypes.c_int), ('aux', ctypes.c_void_p), ('ldaux', ctypes.c_long), ('tile', ctypes.c_int)]
+                ('ldr', ctypes.c_long), ('act', ctypes.c_int), ('aux', ctypes.c_void_p), ('ldaux', ctypes.c_long), ('tile', ctypes.c_int),
+                ('bias2', ctypes.c_void_p), ('row_scale2', ctypes.c_void_p)]
+
+
+class SGemm(ctypes.Structure):
+    _fields_ = [('M', ctypes.c_int), ('N', ctypes.c_int), ('K', ctypes.c_int),
+                ('A', ctypes.c_void_p), ('sai', ctypes.c_long), ('sak', ctypes.c_long),
+                ('B', ctypes.c_void_p), ('sbj', ctypes.c_long), ('sbk', ctypes.c_long),
+                ('C', ctypes.c_void_p), ('ldc', ctypes.c_long), ('accumulate', ctypes.c_int)]
 
 
 class TnProblem(ctypes.Structure):
@@ -64,9 +72,10 @@ SIGNATURES = {
     'tcow_gemm_tn': (_i, [_vp, _i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _vp, _i, _vp, _l]),
     'tcow_gemm_tn_grouped_workspace_bytes': (_l, [_i, _i, _vp]),
     'tcow_gemm_tn_grouped': (_i, [_vp, _i, _i, _vp, _vp, _l]),
+    'tcow_sgemm_x3_batched': (_i, [_vp, _i, _vp]),
     'tcow_layernorm_fwd': (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _vp, _f, _vp, _l, _vp, _vp]),
     'tcow_layernorm_bwd_workspace_bytes': (_l, [_i]),
-    'tcow_layernorm_bwd': (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _l, _vp, _vp, _vp, _vp, _l, _vp, _l, _vp, _vp, _i, _vp, _l, _vp, _l, _vp]),
+    'tcow_layernorm_bwd': (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _l, _vp, _vp, _vp, _vp, _l, _vp, _l, _vp, _vp, _i, _vp, _l, _vp, _l, _vp, _vp, _vp]),
     'tcow_attn_temporal_fwd': (_i, [_vp, _ash, _vp, _vp, _vp]),
     'tcow_attn_spatial_fwd': (_i, [_vp, _ash, _vp, _vp, _vp]),
     'tcow_attn_bwd_workspace_bytes': (_l, [_ash]),

@@ -58,7 +58,7 @@ int tcow_launch_colsum(hipStream_t stream, int dtype, const void* Y, long ldy, i
 
 extern "C" {
 
-int tcow_version(void) { return 4; }
+int tcow_version(void) { return 5; }
 const char* tcow_last_error(void) { return g_err; }
 
 // ---- optional low-overhead HIP-event timing of the dominant kernel (the NT GEMM), on the launch stream
@@ -118,6 +118,7 @@ static int gemm_nt_dispatch(void* stream, const tcow_gemm_args* a) {
     TCOW_CHECK_ARG(a->A && a->W && a->C, "tcow_gemm_nt: null operand");
     TCOW_CHECK_ARG((a->act != TCOW_ACT_DGELU && a->act != TCOW_ACT_GELU_DSAVE && a->act != TCOW_ACT_MUL_AUX) || a->aux, "tcow_gemm_nt: this activation needs aux");
     TCOW_CHECK_ARG(a->act >= TCOW_ACT_NONE && a->act <= TCOW_ACT_MUL_AUX, "tcow_gemm_nt: unknown activation %d", a->act);
+    TCOW_CHECK_ARG(a->bias2 || !a->row_scale2, "tcow_gemm_nt: row_scale2 without bias2");
     if (a->dtype == TCOW_BF16) return tcow_gemm_nt_bf16((hipStream_t)stream, a);
     if (a->dtype == TCOW_F32) return tcow_gemm_nt_f32((hipStream_t)stream, a);
     if (a->dtype == TCOW_F32X3) return tcow_gemm_nt_x3((hipStream_t)stream, a);

@@ -36,6 +36,7 @@ struct NtParams {
     int act;
     bf16_t* aux; long ldaux;
     int tiles_m, tiles_n;
+    const float* bias2; const float* row_scale2;      // second bias with its own row scale (the folded temporal projection), or NULL
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
@@ -81,10 +82,10 @@ __device__ __forceinline__ void gelu_both4(float4 v, float4& g, float4& d) {
     gelu_parts(v.w, c, q); g.w = v.w * c; d.w = fmaf(v.w, q, c);
 }
 
-struct EpiRow { float4 ext; float rs; };
+struct EpiRow { float4 ext; float rs, rs2; };
 
 // Epilogue configuration: ACT / ROWS < 0 = decided at run time from NtParams (the generic kernels); >= 0 = compile-time constants
-// (ROWS bit 0 = row_scale present, bit 1 = resid present).  The specialised instantiations keep the epilogue of the 320-tile
+// (ROWS bit 0 = row_scale present, bit 1 = resid present, bit 2 = bias2 / row_scale2 present).  The specialised instantiations keep the epilogue of the 320-tile
 // kernel small: with every activation inlined behind run-time branches its unrolled row loops were ~100 KB of code.
 template <int ACT, int ROWS> struct EpiCfg {
     static constexpr bool kStatic = ACT >= 0 && ROWS >= 0;
@@ -92,14 +93,16 @@ template <int ACT, int ROWS> struct EpiCfg {
     static __device__ __forceinline__ int act(const NtParams& p) { return ACT < 0 ? p.act : ACT; }
     static __device__ __forceinline__ bool rs(const NtParams& p) { return ROWS < 0 ? p.row_scale != nullptr : (ROWS & 1) != 0; }
     static __device__ __forceinline__ bool res(const NtParams& p) { return ROWS < 0 ? p.resid != nullptr : (ROWS & 2) != 0; }
+    static __device__ __forceinline__ bool b2(const NtParams& p) { return ROWS < 0 ? p.bias2 != nullptr : (ROWS & 4) != 0; }
 };
 typedef EpiCfg<-1, -1> EpiAny;
 
 template <typename E = EpiAny>
 __device__ __forceinline__ EpiRow epi_row_fetch(const NtParams& p, int gm, int gn, bool ok) {
-    EpiRow o; o.ext = make_float4(0.f, 0.f, 0.f, 0.f); o.rs = 1.0f;
+    EpiRow o; o.ext = make_float4(0.f, 0.f, 0.f, 0.f); o.rs = 1.0f; o.rs2 = 1.0f;
     if (ok && gm < p.M) {
         if (E::rs(p)) o.rs = p.row_scale[gm];
+        if (E::b2(p) && p.row_scale2) o.rs2 = p.row_scale2[gm];
         if (E::res(p)) o.ext = ld4(p.resid + (size_t)gm * p.ldr + gn);
         else if (E::act(p) == TCOW_ACT_DGELU || E::act(p) == TCOW_ACT_MUL_AUX) o.ext = ld4(p.aux + (size_t)gm * p.ldaux + gn);
     }
@@ -123,6 +126,7 @@ __device__ __forceinline__ void epi_row_apply(const NtParams& p, const EpiRow& o
     } else if (act == TCOW_ACT_MUL_AUX) {
         v.x *= o.ext.x; v.y *= o.ext.y; v.z *= o.ext.z; v.w *= o.ext.w;
     }
+    if (E::b2(p)) { const float4 c4 = ld4(p.bias2 + gn); v.x = fmaf(o.rs2, c4.x, v.x); v.y = fmaf(o.rs2, c4.y, v.y); v.z = fmaf(o.rs2, c4.z, v.z); v.w = fmaf(o.rs2, c4.w, v.w); }
     if (E::res(p)) { v.x += o.ext.x; v.y += o.ext.y; v.z += o.ext.z; v.w += o.ext.w; }
     if (p.out_f32) st4(reinterpret_cast<float*>(p.C) + (size_t)gm * p.ldc + gn, v);
     else st4(reinterpret_cast<bf16_t*>(p.C) + (size_t)gm * p.ldc + gn, v);
@@ -134,9 +138,9 @@ __device__ __forceinline__ void epi_row_apply(const NtParams& p, const EpiRow& o
 // contains no loads at all; with row operands ALL of them are fetched up front and the loop only stores.
 template <int NIT = 16, typename E = EpiAny>
 __device__ __forceinline__ void epi_rows(const NtParams& p, const float* ct, int ct_ld, float4 b4, int gm_first, int row_first, int row_step, int c4, int gn) {
-    const bool rowops = E::rs(p) || E::res(p) || E::act(p) == TCOW_ACT_DGELU || E::act(p) == TCOW_ACT_MUL_AUX;
+    const bool rowops = E::rs(p) || E::res(p) || E::b2(p) || E::act(p) == TCOW_ACT_DGELU || E::act(p) == TCOW_ACT_MUL_AUX;
     if (!rowops) {
-        EpiRow o; o.ext = make_float4(0.f, 0.f, 0.f, 0.f); o.rs = 1.0f;
+        EpiRow o; o.ext = make_float4(0.f, 0.f, 0.f, 0.f); o.rs = 1.0f; o.rs2 = 1.0f;
 #pragma unroll 1
         for (int it = 0; it < NIT; ++it) {
             const int gm = gm_first + it * row_step;
@@ -563,20 +567,23 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_320_kernel(NtParams p) {
         // in rotation; registers at the peak: 128 accumulators + 2 x 8 row operands.
         // Each lane handles 8 consecutive columns of a row (16-byte bf16 / 2 x 16-byte f32 accesses): half as many global
         // instructions per byte as the 4-column mapping, i.e. twice the bytes in flight for these latency-bound operand reads.
-        struct Row8 { float4 e0, e1; float rs; };
+        struct Row8 { float4 e0, e1; float rs, rs2; };
         const int c8 = (lane & 7) * 8, r8 = lane >> 3;                       // 8 lanes x 8 columns = 64 columns, 8 rows per pass
         const int gn8 = n0 + wn * 64 + c8;
         const bool ok8 = gn8 < p.N;                                          // N % 8 == 0 in bf16 mode
         float4 b40 = make_float4(0.f, 0.f, 0.f, 0.f), b41 = b40;
         if (p.bias && ok8) { b40 = ld4(p.bias + gn8); b41 = ld4(p.bias + gn8 + 4); }
+        float4 c40 = make_float4(0.f, 0.f, 0.f, 0.f), c41 = c40;
+        if (E::b2(p) && ok8) { c40 = ld4(p.bias2 + gn8); c41 = ld4(p.bias2 + gn8 + 4); }
         Row8 oa[4], ob[4];
         auto fetch = [&](Row8* o, int u) {
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int gm = mrow8 + u * 32 + it * 8;
-                Row8 r; r.e0 = make_float4(0.f, 0.f, 0.f, 0.f); r.e1 = r.e0; r.rs = 1.0f;
+                Row8 r; r.e0 = make_float4(0.f, 0.f, 0.f, 0.f); r.e1 = r.e0; r.rs = 1.0f; r.rs2 = 1.0f;
                 if (ok8 && gm < p.M) {
                     if (E::rs(p)) r.rs = p.row_scale[gm];
+                    if (E::b2(p) && p.row_scale2) r.rs2 = p.row_scale2[gm];
                     if (E::res(p)) { const float* q = p.resid + (size_t)gm * p.ldr + gn8; r.e0 = ld4(q); r.e1 = ld4(q + 4); }
                     else if (E::act(p) == TCOW_ACT_MUL_AUX || E::act(p) == TCOW_ACT_DGELU) {
                         const uint4 u4 = *reinterpret_cast<const uint4*>(p.aux + (size_t)gm * p.ldaux + gn8);
@@ -586,11 +593,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_320_kernel(NtParams p) {
                 o[it] = r;
             }
         };
-        auto fin = [&](float4 v, float4 bb, float4 e, float rs) {
+        auto fin = [&](float4 v, float4 bb, float4 cc, float4 e, float rs, float rs2) {
             v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
             if (E::rs(p)) { v.x *= rs; v.y *= rs; v.z *= rs; v.w *= rs; }
             if (E::act(p) == TCOW_ACT_MUL_AUX) { v.x *= e.x; v.y *= e.y; v.z *= e.z; v.w *= e.w; }
             else if (E::act(p) == TCOW_ACT_DGELU) v = dgelu4(v, e);
+            if (E::b2(p)) { v.x = fmaf(rs2, cc.x, v.x); v.y = fmaf(rs2, cc.y, v.y); v.z = fmaf(rs2, cc.z, v.z); v.w = fmaf(rs2, cc.w, v.w); }
             if (E::res(p)) { v.x += e.x; v.y += e.y; v.z += e.z; v.w += e.w; }
             return v;
         };
@@ -600,8 +608,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_320_kernel(NtParams p) {
                 const int gm = mrow8 + u * 32 + it * 8;
                 if (!(ok8 && gm < p.M)) continue;
                 const float* cr = ct + (half * 32 + r8 + it * 8) * CT_LD + c8;
-                const float4 v0 = fin(*reinterpret_cast<const float4*>(cr), b40, o[it].e0, o[it].rs);
-                const float4 v1 = fin(*reinterpret_cast<const float4*>(cr + 4), b41, o[it].e1, o[it].rs);
+                const float4 v0 = fin(*reinterpret_cast<const float4*>(cr), b40, c40, o[it].e0, o[it].rs, o[it].rs2);
+                const float4 v1 = fin(*reinterpret_cast<const float4*>(cr + 4), b41, c41, o[it].e1, o[it].rs, o[it].rs2);
                 if (p.out_f32) {
                     float* d = reinterpret_cast<float*>(p.C) + (size_t)gm * p.ldc + gn8;
                     st4(d, v0); st4(d + 4, v1);
@@ -787,6 +795,7 @@ int tcow_gemm_nt_bf16(hipStream_t stream, const tcow_gemm_args* a) {
     p.A = (const bf16_t*)a->A; p.lda = a->lda; p.W = (const bf16_t*)a->W; p.ldw = a->ldw;
     p.C = a->C; p.ldc = a->ldc; p.out_f32 = a->out_f32; p.bias = a->bias; p.row_scale = a->row_scale;
     p.resid = a->resid; p.ldr = a->ldr; p.act = a->act; p.aux = (bf16_t*)a->aux; p.ldaux = a->ldaux;
+    p.bias2 = a->bias2; p.row_scale2 = a->row_scale2;
     p.tiles_m = cdiv(a->M, BM); p.tiles_n = cdiv(a->N, BN);
     TCOW_CHECK_ARG(a->tile == 0 || a->tile == 128 || a->tile == 256 || a->tile == 320, "tcow_gemm_nt(bf16): tile must be 0, 128, 256 or 320 (got %d)", a->tile);
     static const int big = [] { const char* e = getenv("TCOW_GEMM_BIG"); return e ? atoi(e) : 1; }();
@@ -800,7 +809,7 @@ int tcow_gemm_nt_bf16(hipStream_t stream, const tcow_gemm_args* a) {
             p.tiles_m = cdiv(a->M, C_BM); p.tiles_n = cdiv(a->N, C_BN);
             // epilogue specialisations for the combinations the path uses; anything else takes the run-time-configured kernel
             typedef void (*Kern)(NtParams);
-            const int rows = (a->row_scale ? 1 : 0) | (a->resid ? 2 : 0);
+            const int rows = (a->row_scale ? 1 : 0) | (a->resid ? 2 : 0) | (a->bias2 ? 4 : 0);
             Kern k = gemm_nt_bf16_320_kernel<EpiAny>;
             const bool vec8 = a->N % 8 == 0 && a->ldc % 8 == 0 && a->ldr % 8 == 0 && a->ldaux % 8 == 0;   // the row-operand epilogues move 8 columns per lane
             if (!vec8) { /* run-time configured kernel */ }
@@ -808,6 +817,7 @@ int tcow_gemm_nt_bf16(hipStream_t stream, const tcow_gemm_args* a) {
             else if (a->act == TCOW_ACT_NONE && rows == 1) k = gemm_nt_bf16_320_kernel<EpiCfg<TCOW_ACT_NONE, 1>>;
             else if (a->act == TCOW_ACT_NONE && rows == 2) k = gemm_nt_bf16_320_kernel<EpiCfg<TCOW_ACT_NONE, 2>>;
             else if (a->act == TCOW_ACT_NONE && rows == 3) k = gemm_nt_bf16_320_kernel<EpiCfg<TCOW_ACT_NONE, 3>>;
+            else if (a->act == TCOW_ACT_NONE && rows == 7) k = gemm_nt_bf16_320_kernel<EpiCfg<TCOW_ACT_NONE, 7>>;
             else if (a->act == TCOW_ACT_GELU_DSAVE && rows == 0) k = gemm_nt_bf16_320_kernel<EpiCfg<TCOW_ACT_GELU_DSAVE, 0>>;
             else if (a->act == TCOW_ACT_MUL_AUX && rows == 0) k = gemm_nt_bf16_320_kernel<EpiCfg<TCOW_ACT_MUL_AUX, 0>>;
             else if (a->act == TCOW_ACT_GELU && rows == 0) k = gemm_nt_bf16_320_kernel<EpiCfg<TCOW_ACT_GELU, 0>>;
@@ -1269,7 +1279,8 @@ int tcow_tn_group_slices(int n, const tcow_tn_problem* pr) {
     for (int s = 1; s <= max_s; ++s) {
         const int wg = s * tiles, rounds = cdiv(wg, 256);
         const double eff = (double)wg / (rounds * 256.0);
-        if (eff > best_eff + 0.01) { best_eff = eff; best = s; }
+        // (every slice writes and re-reads one f32 image of all the group's weights: beyond 8 slices a finer fill of the last round must buy >= 5 %)
+        if (eff > best_eff + (s > 8 ? 0.05 : 0.01)) { best_eff = eff; best = s; }
     }
     return best;
 }

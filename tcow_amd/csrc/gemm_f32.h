@@ -10,6 +10,7 @@ struct F32Params {
     void* C; long ldc;
     const float* bias; const float* row_scale; const float* resid; long ldr;
     int act; float* aux; long ldaux;
+    const float* bias2; const float* row_scale2;      // second bias with its own row scale (folded temporal projection), or NULL
     int kps;          // contraction elements per z-slice (multiple of the kernel's k-slice)
     float* slab;      // if non-NULL: raw partial sums to slab[z][M][N], no epilogue
 };
@@ -29,6 +30,7 @@ __device__ __forceinline__ void f32_epilogue_store(const F32Params& p, int gm, i
     } else if (p.act == TCOW_ACT_MUL_AUX) {
         x *= p.aux[(size_t)gm * p.ldaux + gn];
     }
+    if (p.bias2) x += (p.row_scale2 ? p.row_scale2[gm] : 1.0f) * p.bias2[gn];
     if (p.resid) x += p.resid[(size_t)gm * p.ldr + gn];
     reinterpret_cast<float*>(p.C)[(size_t)gm * p.ldc + gn] = x;
 }
@@ -51,6 +53,7 @@ __device__ __forceinline__ void f32_epilogue_store4(const F32Params& p, int gm, 
         const float4 a = ld4(ax);
         x.x *= a.x; x.y *= a.y; x.z *= a.z; x.w *= a.w;
     }
+    if (p.bias2) { const float r2 = p.row_scale2 ? p.row_scale2[gm] : 1.0f; const float4 b2 = ld4(p.bias2 + gn); x.x += r2 * b2.x; x.y += r2 * b2.y; x.z += r2 * b2.z; x.w += r2 * b2.w; }
     if (p.resid) { const float4 r = ld4(p.resid + (size_t)gm * p.ldr + gn); x.x += r.x; x.y += r.y; x.z += r.z; x.w += r.w; }
     st4(reinterpret_cast<float*>(p.C) + (size_t)gm * p.ldc + gn, x);
 }

@@ -151,7 +151,7 @@ __global__ __launch_bounds__(64) void slab_reduce4_group_kernel(FoldGroup g) {
 // out[c] (+)= sum_r part[r][c] for a tall-skinny partial table (many rows, few columns): 16 columns x 16 row groups per block
 // (columns >= N1 go to out2[c - N1]: LayerNorm's dgamma | dbeta table is folded by one launch)
 __global__ __launch_bounds__(256) void row_reduce_kernel(const float* __restrict__ part, int nrows, long ld, int N, float* __restrict__ out, int accumulate,
-                                                         int N1, float* __restrict__ out2) {
+                                                         int N1, float* __restrict__ out2, int N12 = 1 << 30, float* __restrict__ out3 = nullptr) {
     __shared__ float red[16][17];
     const int c = blockIdx.x * 16 + (threadIdx.x & 15), g = threadIdx.x >> 4;
     float s = 0.f;
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void row_reduce_kernel(const float* __restrict
     __syncthreads();
     if (g == 0 && c < N) {
         for (int k = 1; k < 16; ++k) s += red[k][threadIdx.x & 15];
-        float* o = c < N1 ? out + c : out2 + (c - N1);
+        float* o = c < N1 ? out + c : (c < N12 ? out2 + (c - N1) : out3 + (c - N12));      // (columns >= N12: a third table, LayerNorm's fused bias gradient)
         *o = accumulate ? *o + s : s;
     }
 }
@@ -210,7 +210,7 @@ int tcow_gemm_nt_f32(hipStream_t stream, const tcow_gemm_args* a) {
     p.A = (const float*)a->A; p.sai = a->lda; p.sak = 1;
     p.B = (const float*)a->W; p.sbj = a->ldw; p.sbk = 1;
     p.C = a->C; p.ldc = a->ldc; p.bias = a->bias; p.row_scale = a->row_scale; p.resid = a->resid; p.ldr = a->ldr;
-    p.act = a->act; p.aux = (float*)a->aux; p.ldaux = a->ldaux; p.kps = ((a->K + FK - 1) / FK) * FK; p.slab = nullptr;
+    p.act = a->act; p.aux = (float*)a->aux; p.ldaux = a->ldaux; p.bias2 = a->bias2; p.row_scale2 = a->row_scale2; p.kps = ((a->K + FK - 1) / FK) * FK; p.slab = nullptr;
     hipLaunchKernelGGL(gemm_f32_kernel, dim3(cdiv(a->N, FT), cdiv(a->M, FT), 1), dim3(256), 0, stream, p);
     TCOW_CHECK_LAUNCH();
     return TCOW_OK;
@@ -285,6 +285,12 @@ int tcow_launch_row_reduce2(hipStream_t stream, const float* part, int nrows, lo
     return TCOW_OK;
 }
 
+int tcow_launch_row_reduce3(hipStream_t stream, const float* part, int nrows, long ld, int N1, float* out1, int N2, float* out2, int N3, float* out3, int accumulate) {
+    hipLaunchKernelGGL(row_reduce_kernel, dim3(cdiv(N1 + N2 + N3, 16)), dim3(256), 0, stream, part, nrows, ld, N1 + N2 + N3, out1, accumulate, N1, out2, N1 + N2, out3);
+    TCOW_CHECK_LAUNCH();
+    return TCOW_OK;
+}
+
 int tcow_launch_colsum(hipStream_t stream, int dtype, const void* Y, long ldy, int M, int N, float* out, int accumulate, float* part, int max_parts) {
     int parts = cdiv(M, 256); if (parts > max_parts) parts = max_parts; if (parts < 1) parts = 1;
     const int rpb = cdiv(M, parts);
@@ -303,7 +309,7 @@ int tcow_gemm_tn_f32(hipStream_t stream, int M, int N, int K, const float* dY, l
     p.M = N; p.N = K; p.K = M;                       // output [N,K], contraction over tokens
     p.A = dY; p.sai = 1; p.sak = ldy;
     p.B = X; p.sbj = 1; p.sbk = ldx;
-    p.C = nullptr; p.ldc = 0; p.bias = nullptr; p.row_scale = nullptr; p.resid = nullptr; p.ldr = 0; p.act = 0; p.aux = nullptr; p.ldaux = 0;
+    p.C = nullptr; p.ldc = 0; p.bias = nullptr; p.row_scale = nullptr; p.resid = nullptr; p.ldr = 0; p.act = 0; p.aux = nullptr; p.ldaux = 0; p.bias2 = nullptr; p.row_scale2 = nullptr;
     int kps = cdiv(M, splits); kps = ((kps + FK - 1) / FK) * FK;
     const int nz = cdiv(M, kps);
     p.kps = kps; p.slab = slab;

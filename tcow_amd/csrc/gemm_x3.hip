@@ -159,20 +159,21 @@ __device__ __forceinline__ x3_bf16x8 frag(const char* plane, int row, int ks, in
     return __builtin_bit_cast(x3_bf16x8, *reinterpret_cast<const uint4*>(plane + row * XP + ks * 32 + hi * 16));
 }
 
-template <int LD>
-__global__ __launch_bounds__(256, LD == LD_ANY ? 2 : 3) void gemm_x3_kernel(F32Params p) {
-    __shared__ __attribute__((aligned(16))) char smem[4 * XPLANE];
+// (LDA / LDB: the loader of each operand -- the same for both in the NT / TN forms of the module's GEMMs, mixed for the small
+// "plain" products A B of tcow_sgemm_x3_batched)
+template <int LDA, int LDB>
+__device__ __forceinline__ void gemm_x3_body(const F32Params& p, const int bid, const int kz, char* smem) {
     char* a_hi = smem; char* a_lo = smem + XPLANE; char* b_hi = smem + 2 * XPLANE; char* b_lo = smem + 3 * XPLANE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, hi = lane >> 5;
     // blocks are dispatched round-robin over the 8 XCDs: hand every XCD a contiguous range of tile ids (column tiles fastest), so the
     // workgroups that share an A row-tile run on ONE private L2 instead of fetching it from HBM once per XCD
     const int tiles_n = cdiv_dev(p.N, XT), nblk = tiles_n * cdiv_dev(p.M, XT);
-    const int bid = blockIdx.x, q = nblk >> 3, rr = nblk & 7, xcd = bid & 7;
+    const int q = nblk >> 3, rr = nblk & 7, xcd = bid & 7;
     const int pid = ((xcd < rr) ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
     const int pm = pid / tiles_n;
     const int m0 = pm * XT, n0 = (pid - pm * tiles_n) * XT;
-    const int kbeg = blockIdx.y * p.kps;
+    const int kbeg = kz * p.kps;
     const int kend = (kbeg + p.kps < p.K) ? kbeg + p.kps : p.K;
     f32x16 acc[2][2];
 #pragma unroll
@@ -185,17 +186,17 @@ __global__ __launch_bounds__(256, LD == LD_ANY ? 2 : 3) void gemm_x3_kernel(F32P
     // time to land: the kernel ran at the memory latency, 5.8 us per slice)
     f32x4 ra0[4], rb0[4], ra1[4], rb1[4];
     auto fetch = [&](f32x4 (&ra)[4], f32x4 (&rb)[4], int k0) {
-        load_regs<LD>(p.A, p.sai, p.sak, m0, p.M, k0, p.K, ra, tid);
-        load_regs<LD>(p.B, p.sbj, p.sbk, n0, p.N, k0, p.K, rb, tid);
+        load_regs<LDA>(p.A, p.sai, p.sak, m0, p.M, k0, p.K, ra, tid);
+        load_regs<LDB>(p.B, p.sbj, p.sbk, n0, p.N, k0, p.K, rb, tid);
     };
     // One slice: split + store the registers of slice kcur, request slice knext into the same registers, multiply.  The body is
     // unconditional on purpose -- loads past the range read clamped (valid) addresses and are masked to zero when they are split, an odd
     // slice count runs one all-zero slice: any branch around a half of the 2x-unrolled loop makes hipcc rotate the register sets with
     // copies on the back edge, i.e. wait for every outstanding load once per iteration.
     auto step = [&](f32x4 (&ra)[4], f32x4 (&rb)[4], int kcur, int knext) {
-        if (kcur + XK > kend) { mask_tail<LD>(ra, kcur, kend, tid); mask_tail<LD>(rb, kcur, kend, tid); }
-        store_split<LD>(ra, a_hi, a_lo, tid);
-        store_split<LD>(rb, b_hi, b_lo, tid);
+        if (kcur + XK > kend) { mask_tail<LDA>(ra, kcur, kend, tid); mask_tail<LDB>(rb, kcur, kend, tid); }
+        store_split<LDA>(ra, a_hi, a_lo, tid);
+        store_split<LDB>(rb, b_hi, b_lo, tid);
         __syncthreads();
         fetch(ra, rb, knext);
 #pragma unroll
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(256, LD == LD_ANY ? 2 : 3) void gemm_x3_kernel(F32P
         if (gn + 2 < p.N) b4.z = p.bias[gn + 2];
         if (gn + 3 < p.N) b4.w = p.bias[gn + 3];
     }
-    float* slab = p.slab ? p.slab + (size_t)blockIdx.y * p.M * p.N : nullptr;
+    float* slab = p.slab ? p.slab + (size_t)kz * p.M * p.N : nullptr;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -276,6 +277,23 @@ __global__ __launch_bounds__(256, LD == LD_ANY ? 2 : 3) void gemm_x3_kernel(F32P
     }
 }
 
+template <int LD>
+__global__ __launch_bounds__(256, LD == LD_ANY ? 2 : 3) void gemm_x3_kernel(F32Params p) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * XPLANE];
+    gemm_x3_body<LD, LD>(p, blockIdx.x, blockIdx.y, smem);
+}
+
+// several small products in one launch: blockIdx.y = problem, blockIdx.x = tile (grid sized for the largest problem)
+constexpr int X3_MAX_BATCH = 24;
+struct X3Batch { F32Params p[X3_MAX_BATCH]; };
+template <int LDA, int LDB>
+__global__ __launch_bounds__(256, (LDA == LD_ANY || LDB == LD_ANY) ? 2 : 3) void gemm_x3_batch_kernel(X3Batch b) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * XPLANE];
+    const F32Params& p = b.p[blockIdx.y];
+    if ((int)blockIdx.x >= cdiv_dev(p.N, XT) * cdiv_dev(p.M, XT)) return;
+    gemm_x3_body<LDA, LDB>(p, blockIdx.x, 0, smem);
+}
+
 }  // namespace
 
 int tcow_launch_slab_reduce(hipStream_t stream, const float* slab, int nz, long slab_stride, long rows, long cols, float* out, long ldo, int accumulate,
@@ -287,7 +305,7 @@ int tcow_gemm_nt_x3(hipStream_t stream, const tcow_gemm_args* a) {
     p.A = (const float*)a->A; p.sai = a->lda; p.sak = 1;
     p.B = (const float*)a->W; p.sbj = a->ldw; p.sbk = 1;
     p.C = a->C; p.ldc = a->ldc; p.bias = a->bias; p.row_scale = a->row_scale; p.resid = a->resid; p.ldr = a->ldr;
-    p.act = a->act; p.aux = (float*)a->aux; p.ldaux = a->ldaux; p.kps = ((a->K + XK - 1) / XK) * XK; p.slab = nullptr;
+    p.act = a->act; p.aux = (float*)a->aux; p.ldaux = a->ldaux; p.bias2 = a->bias2; p.row_scale2 = a->row_scale2; p.kps = ((a->K + XK - 1) / XK) * XK; p.slab = nullptr;
     const bool vec = ((reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.B)) & 15) == 0 && ((p.sai | p.sbj | p.K) & 3) == 0;
     const dim3 grid(cdiv(a->N, XT) * cdiv(a->M, XT), 1);
     if (vec) hipLaunchKernelGGL(gemm_x3_kernel<LD_KVEC>, grid, dim3(256), 0, stream, p);
@@ -314,7 +332,7 @@ int tcow_gemm_tn_x3(hipStream_t stream, int M, int N, int K, const float* dY, lo
     p.M = N; p.N = K; p.K = M;                       // output [N,K], contraction over tokens
     p.A = dY; p.sai = 1; p.sak = ldy;
     p.B = X; p.sbj = 1; p.sbk = ldx;
-    p.C = nullptr; p.ldc = 0; p.bias = nullptr; p.row_scale = nullptr; p.resid = nullptr; p.ldr = 0; p.act = 0; p.aux = nullptr; p.ldaux = 0;
+    p.C = nullptr; p.ldc = 0; p.bias = nullptr; p.row_scale = nullptr; p.resid = nullptr; p.ldr = 0; p.act = 0; p.aux = nullptr; p.ldaux = 0; p.bias2 = nullptr; p.row_scale2 = nullptr;
     int kps = cdiv(M, splits); kps = ((kps + XK - 1) / XK) * XK;
     const int nz = cdiv(M, kps);
     p.kps = kps; p.slab = slab;
@@ -324,4 +342,41 @@ int tcow_gemm_tn_x3(hipStream_t stream, int M, int N, int K, const float* dY, lo
     else hipLaunchKernelGGL(gemm_x3_kernel<LD_ANY>, grid, dim3(256), 0, stream, p);
     TCOW_CHECK_LAUNCH();
     return tcow_launch_slab_reduce(stream, slab, nz, (long)N * K, N, K, dW, lddw, accumulate, nullptr, 0, 0, nullptr);
+}
+
+// ---- tcow_sgemm_x3_batched: C = A B for up to 24 small f32 problems in one launch; every operand is addressed by (row stride, k stride),
+// one of them 1 -- which picks the vector loader per operand (all problems of a call share the two loaders)
+static int x3_loader(const float* P, long s_row, long s_k, int nrows, int K) {
+    const bool al = (reinterpret_cast<uintptr_t>(P) & 15) == 0;
+    if (s_k == 1 && al && (s_row & 3) == 0 && (K & 3) == 0 && K >= 4) return LD_KVEC;
+    if (s_row == 1 && al && (s_k & 3) == 0 && (nrows & 3) == 0 && nrows >= 4) return LD_RVEC;
+    return LD_ANY;
+}
+
+extern "C" int tcow_sgemm_x3_batched(void* stream, int n, const tcow_sgemm* probs) {
+    TCOW_CHECK_ARG(n >= 1 && n <= X3_MAX_BATCH && probs, "tcow_sgemm_x3_batched: 1 .. %d problems per call (got %d)", X3_MAX_BATCH, n);
+    X3Batch b;
+    int lda = -1, ldb = -1, maxtiles = 0;
+    for (int i = 0; i < n; ++i) {
+        const tcow_sgemm& s = probs[i];
+        TCOW_CHECK_ARG(s.M > 0 && s.N > 0 && s.K > 0 && s.A && s.B && s.C && s.ldc >= s.N, "tcow_sgemm_x3_batched: bad problem %d", i);
+        F32Params& p = b.p[i];
+        p.M = s.M; p.N = s.N; p.K = s.K; p.A = s.A; p.sai = s.sai; p.sak = s.sak; p.B = s.B; p.sbj = s.sbj; p.sbk = s.sbk;
+        p.C = s.C; p.ldc = s.ldc; p.bias = nullptr; p.row_scale = nullptr; p.resid = nullptr; p.ldr = 0; p.act = 0; p.aux = nullptr; p.ldaux = 0; p.bias2 = nullptr; p.row_scale2 = nullptr;
+        p.kps = ((s.K + XK - 1) / XK) * XK; p.slab = nullptr;
+        if (s.accumulate) { p.resid = s.C; p.ldr = s.ldc; }           // (the epilogue reads the residual element it then overwrites)
+        const int la = x3_loader(s.A, s.sai, s.sak, s.M, s.K), lb = x3_loader(s.B, s.sbj, s.sbk, s.N, s.K);
+        lda = (lda < 0 || lda == la) ? la : LD_ANY; ldb = (ldb < 0 || ldb == lb) ? lb : LD_ANY;
+        const int t = cdiv(s.N, XT) * cdiv(s.M, XT);
+        if (t > maxtiles) maxtiles = t;
+    }
+    const dim3 grid(maxtiles, n);
+    hipStream_t st = (hipStream_t)stream;
+    if (lda == LD_KVEC && ldb == LD_KVEC) hipLaunchKernelGGL((gemm_x3_batch_kernel<LD_KVEC, LD_KVEC>), grid, dim3(256), 0, st, b);
+    else if (lda == LD_KVEC && ldb == LD_RVEC) hipLaunchKernelGGL((gemm_x3_batch_kernel<LD_KVEC, LD_RVEC>), grid, dim3(256), 0, st, b);
+    else if (lda == LD_RVEC && ldb == LD_RVEC) hipLaunchKernelGGL((gemm_x3_batch_kernel<LD_RVEC, LD_RVEC>), grid, dim3(256), 0, st, b);
+    else if (lda == LD_RVEC && ldb == LD_ANY) hipLaunchKernelGGL((gemm_x3_batch_kernel<LD_RVEC, LD_ANY>), grid, dim3(256), 0, st, b);
+    else hipLaunchKernelGGL((gemm_x3_batch_kernel<LD_ANY, LD_ANY>), grid, dim3(256), 0, st, b);
+    TCOW_CHECK_LAUNCH();
+    return TCOW_OK;
 }

@@ -75,19 +75,23 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(int rows, int D, const floa
 // dx_out = dres + dx (the gradient arriving through the residual connection is added here).
 // dgamma / dbeta partial sums: each wave keeps per-column partials over the rows it visits, the block folds its
 // 4 waves through LDS and writes one partial row per block; tcow_launch_slab_reduce finishes the sum.
-template <typename T, int NV>
+template <typename T, int NV, bool CSUM>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int D, const T* __restrict__ dy, long lddy, const float* __restrict__ x, long ldx,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const float* __restrict__ dres, long lddres,
-                                                     float* __restrict__ dx, long lddx, float* __restrict__ part /* [grid][2][D] or NULL */,
-                                                     T* __restrict__ dxc, long lddxc, const float* __restrict__ cscale) {
-    extern __shared__ __attribute__((aligned(16))) float red[];  // [4][2*D]
+                                                     float* __restrict__ dx, long lddx, float* __restrict__ part /* [grid][NP][D] or NULL */,
+                                                     T* __restrict__ dxc, long lddxc, const float* __restrict__ cscale, const float* __restrict__ sumscale) {
+    // CSUM: a third column sum rides along, sum_rows sumscale[row] * dx[row] -- the bias gradient of the Linear layer BELOW this norm when
+    // that layer's output was row-masked (temporal_fc: vit.py:174-176 with the cls rows excluded), in f32 instead of from the bf16 operand
+    constexpr int NP = CSUM ? 3 : 2;
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [4][NP*D]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = D >> 2;
-    float4 gsum[NV], bsum[NV], gam[NV];
+    float4 gsum[NV], bsum[NV], gam[NV], csum[CSUM ? NV : 1];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         gsum[i] = make_float4(0.f, 0.f, 0.f, 0.f); bsum[i] = gsum[i];
+        if (CSUM) csum[i] = gsum[i];
         const int c = lane + i * 64;
         gam[i] = (c < nv) ? ld4(gamma + c * 4) : gsum[i];
     }
@@ -132,6 +136,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int D, const T* _
         const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
         float* dxr = dx + (size_t)row * lddx;
         const float cs_row = (dxc && cscale) ? cscale[row] : 1.0f;
+        const float ss_row = (CSUM && sumscale) ? sumscale[row] : 1.0f;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = lane + i * 64;
@@ -140,6 +145,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int D, const T* _
                                        rs * (g[i].w - m1 - xh[i].w * m2));
                 if (dres) { o.x += rr[i].x; o.y += rr[i].y; o.z += rr[i].z; o.w += rr[i].w; }
                 st4(dxr + c * 4, o);
+                if (CSUM) { csum[i].x = fmaf(ss_row, o.x, csum[i].x); csum[i].y = fmaf(ss_row, o.y, csum[i].y); csum[i].z = fmaf(ss_row, o.z, csum[i].z); csum[i].w = fmaf(ss_row, o.w, csum[i].w); }
                 if (dxc) {       // the same gradient as the next GEMM's operand: dtype(dx * row scale), saves a separate cast pass
                     const float cs = cs_row;
                     st4(dxc + (size_t)row * lddxc + c * 4, make_float4(o.x * cs, o.y * cs, o.z * cs, o.w * cs));
@@ -152,22 +158,24 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int D, const T* _
     for (int i = 0; i < NV; ++i) {
         const int c = lane + i * 64;
         if (c < nv) {
-            *reinterpret_cast<float4*>(red + (size_t)wave * 2 * D + c * 4) = gsum[i];
-            *reinterpret_cast<float4*>(red + (size_t)wave * 2 * D + D + c * 4) = bsum[i];
+            *reinterpret_cast<float4*>(red + (size_t)wave * NP * D + c * 4) = gsum[i];
+            *reinterpret_cast<float4*>(red + (size_t)wave * NP * D + D + c * 4) = bsum[i];
+            if (CSUM) *reinterpret_cast<float4*>(red + (size_t)wave * NP * D + 2 * D + c * 4) = csum[i];
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * D; i += 256) {
-        part[(size_t)blockIdx.x * 2 * D + i] = (red[i] + red[2 * D + i]) + (red[4 * D + i] + red[6 * D + i]);
+    for (int i = threadIdx.x; i < NP * D; i += 256) {
+        part[(size_t)blockIdx.x * NP * D + i] = (red[i] + red[NP * D + i]) + (red[2 * NP * D + i] + red[3 * NP * D + i]);
     }
 }
 
 }  // namespace
 
 int tcow_launch_row_reduce2(hipStream_t stream, const float* part, int nrows, long ld, int N1, float* out1, int N2, float* out2, int accumulate);
+int tcow_launch_row_reduce3(hipStream_t stream, const float* part, int nrows, long ld, int N1, float* out1, int N2, float* out2, int N3, float* out3, int accumulate);
 
 static const int kLnBwdBlocks = 512;
-static const int kLnFwdBlocks = [] { const char* e = getenv("TCOW_LN_FWD_BLOCKS"); return e ? atoi(e) : 4096; }();     // grid-stride blocks of the forward (512 ... 8192 measured within 6 %: tools/dev_ln_time.py)
+static const int kLnFwdBlocks = [] { const char* e = getenv("TCOW_LN_FWD_BLOCKS"); const int v = e ? atoi(e) : 4096; return v >= 1 ? v : 4096; }();     // grid-stride blocks of the forward (512 ... 8192 measured within 6 %: tools/dev_ln_time.py)
 
 extern "C" {
 
@@ -190,32 +198,38 @@ int tcow_layernorm_fwd(void* stream, int dtype, int rows, int D, const float* x,
     return TCOW_OK;
 }
 
-long tcow_layernorm_bwd_workspace_bytes(int D) { return (long)kLnBwdBlocks * 2 * D * 4; }
+long tcow_layernorm_bwd_workspace_bytes(int D) { return (long)kLnBwdBlocks * 3 * D * 4; }
 
 int tcow_layernorm_bwd(void* stream, int dtype, int rows, int D, const void* dy, long lddy, const float* x, long ldx, const float* mean,
                        const float* rstd, const float* gamma, const float* dres, long lddres, float* dx, long lddx, float* dgamma, float* dbeta,
-                       int accumulate, void* workspace, long workspace_bytes, void* dx_cast, long lddx_cast, const float* cast_row_scale) {
+                       int accumulate, void* workspace, long workspace_bytes, void* dx_cast, long lddx_cast, const float* cast_row_scale,
+                       const float* colsum_row_scale, float* colsum_out) {
     TCOW_CHECK_ARG(rows > 0 && D > 0 && D % 4 == 0 && D <= 64 * 4 * LN_MAXV, "tcow_layernorm_bwd: bad D=%d", D);
     TCOW_CHECK_ARG(dy && x && mean && rstd && gamma && dx, "tcow_layernorm_bwd: null pointer");
     TCOW_CHECK_ARG(!dx_cast || lddx_cast % 4 == 0, "tcow_layernorm_bwd: dx_cast stride must be a multiple of 4");
     const bool want_param_grads = dgamma != nullptr || dbeta != nullptr;
     TCOW_CHECK_ARG(!want_param_grads || (dgamma && dbeta && workspace && workspace_bytes >= tcow_layernorm_bwd_workspace_bytes(D)),
                    "tcow_layernorm_bwd: parameter gradients need dgamma, dbeta and a workspace of %ld bytes", tcow_layernorm_bwd_workspace_bytes(D));
+    TCOW_CHECK_ARG(!colsum_out || want_param_grads, "tcow_layernorm_bwd: colsum_out rides on the parameter-gradient pass (dgamma / dbeta needed)");
     int blocks = cdiv(rows, 4); if (blocks > kLnBwdBlocks) blocks = kLnBwdBlocks;
     float* part = want_param_grads ? (float*)workspace : nullptr;
-    const size_t lds = want_param_grads ? (size_t)8 * D * 4 : 0;
+    const bool csum = colsum_out != nullptr;
+    const size_t lds = want_param_grads ? (size_t)4 * (csum ? 3 : 2) * D * 4 : 0;
     if (dtype != TCOW_BF16 && dtype != TCOW_F32) { tcow_set_error("tcow_layernorm_bwd: unknown dtype %d", dtype); return TCOW_ERR_INVALID_ARG; }
     const int nvl = (D / 4 + 63) / 64;
 #define LN_BWD(NVV)                                                                                                                               \
     do {                                                                                                                                          \
-        if (dtype == TCOW_BF16) hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, NVV>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, rows, D, (const bf16_t*)dy, lddy, x, ldx, mean, rstd, gamma, dres, lddres, dx, lddx, part, (bf16_t*)dx_cast, lddx_cast, cast_row_scale); \
-        else hipLaunchKernelGGL((ln_bwd_kernel<float, NVV>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, rows, D, (const float*)dy, lddy, x, ldx, mean, rstd, gamma, dres, lddres, dx, lddx, part, (float*)dx_cast, lddx_cast, cast_row_scale); \
+        if (dtype == TCOW_BF16 && csum) hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, NVV, true>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, rows, D, (const bf16_t*)dy, lddy, x, ldx, mean, rstd, gamma, dres, lddres, dx, lddx, part, (bf16_t*)dx_cast, lddx_cast, cast_row_scale, colsum_row_scale); \
+        else if (dtype == TCOW_BF16) hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, NVV, false>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, rows, D, (const bf16_t*)dy, lddy, x, ldx, mean, rstd, gamma, dres, lddres, dx, lddx, part, (bf16_t*)dx_cast, lddx_cast, cast_row_scale, colsum_row_scale); \
+        else if (csum) hipLaunchKernelGGL((ln_bwd_kernel<float, NVV, true>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, rows, D, (const float*)dy, lddy, x, ldx, mean, rstd, gamma, dres, lddres, dx, lddx, part, (float*)dx_cast, lddx_cast, cast_row_scale, colsum_row_scale); \
+        else hipLaunchKernelGGL((ln_bwd_kernel<float, NVV, false>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, rows, D, (const float*)dy, lddy, x, ldx, mean, rstd, gamma, dres, lddres, dx, lddx, part, (float*)dx_cast, lddx_cast, cast_row_scale, colsum_row_scale); \
     } while (0)
     if (nvl <= 1) LN_BWD(1); else if (nvl == 2) LN_BWD(2); else if (nvl == 3) LN_BWD(3); else if (nvl == 4) LN_BWD(4); else LN_BWD(8);
 #undef LN_BWD
     TCOW_CHECK_LAUNCH();
     if (want_param_grads) {
-        // part is [blocks][2][D]: slab stride 2*D, dgamma partials first, dbeta partials at +D
+        // part is [blocks][2 or 3][D]: dgamma partials first, dbeta partials at +D, the fused bias gradient at +2D
+        if (csum) return tcow_launch_row_reduce3((hipStream_t)stream, part, blocks, 3L * D, D, dgamma, D, dbeta, D, colsum_out, accumulate);
         return tcow_launch_row_reduce2((hipStream_t)stream, part, blocks, 2L * D, D, dgamma, D, dbeta, accumulate);
     }
     return TCOW_OK;

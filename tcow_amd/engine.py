@@ -13,7 +13,19 @@ Layout: residual stream R [M, D] f32 with M = B*T*S rows, row(b,t,s) = (b*T+t)*S
     H   = GELU(LN_2(R2) W1^T + b1);  R3 = R2 + dp_m * (H W2^T + b2)           vit.py:216, 55-61
 
 The backward below is the hand-derived adjoint of exactly this schedule; nothing goes through torch autograd.
+
+16-bit modes FOLD the temporal projection: temporal_attn.proj -> DropPath -> temporal_fc (vit.py:111,172-176) are two Linear layers
+with only a per-row scale dp_t between them, so
+
+    R1 = R0 + [s>=1] * (dp_t * (O W'^T + b') + b_fc),      W' = Wfc Wproj,  b' = Wfc b_proj
+
+is ONE [M,768] x [768,768] GEMM instead of two (forward, input gradient and weight gradient: 36 of them per step at depth 12).  The
+state dict keeps both Linear layers: W', b' are recomputed from the f32 masters after every optimizer step (one batched launch of small
+f32 products, ops.sgemm_batched), and the backward turns dW' = dY'^T O, db' into dWfc = dW' Wproj^T, dWproj = Wfc^T dW',
+db_proj = Wfc^T db' the same way; b_fc's gradient is the row-masked column sum of dR1, taken in f32 inside the LayerNorm backward
+that produces dR1.  (The f32 parity modes keep the reference's op order.)
 """
+import os
 import torch
 
 from . import ops
@@ -75,6 +87,44 @@ def _get_weight(module, p, train):
     return Wc, Wt
 
 
+def _fold_on(module):
+    return ops.is16(module.mode) and module.attention_type == 'divided_space_time' and os.environ.get('TCOW_FOLD', '1') != '0'
+
+
+def _fold_products(ents):
+    """W' = Wfc Wproj and b' = Wfc b_proj for a list of fold entries: two batched launches (per 24 entries)."""
+    for c0 in range(0, len(ents), 24):
+        ops.sgemm_batched([(e['fc'].detach(), e['proj'].detach(), e['W32']) for e in ents[c0:c0 + 24]])
+        ops.sgemm_batched([(e['fc'].detach(), e['bproj'].detach().view(1, -1).t(), e['b32'].view(-1, 1)) for e in ents[c0:c0 + 24]])
+
+
+def _folded_weight(module, i, q, ix, train):
+    """Operands of block i's folded temporal projection: (Wc' [D,D], Wt' [D,D] or None, b' [D] f32), cached per parameter version."""
+    pfc, pproj, bproj = q[ix['tfc']], q[ix['tproj']], q[ix['tproj'] + 1]
+    key = ('fold', i)
+    ver = (pfc._version, pproj._version, bproj._version, getattr(module, '_wepoch', 0))
+    ent = module._wcache.get(key)
+    if ent is not None and ent['ver'] == ver and ent['mode'] == module.mode and (ent['Wt'] is not None or not train):
+        return ent['Wc'], ent['Wt'], ent['b32']
+    D = pfc.shape[0]
+    dev = pfc.device
+    dt = ops.tdtype(module.mode)
+    if ent is None or ent['mode'] != module.mode:
+        ent = dict(fc=pfc, proj=pproj, bproj=bproj, W32=torch.empty(D, D, dtype=torch.float32, device=dev), b32=torch.empty(D, dtype=torch.float32, device=dev),
+                   Wc=torch.empty(D, D, dtype=dt, device=dev), Wt=None, mode=module.mode)
+    if train and ent['Wt'] is None:
+        ent['Wt'] = torch.empty(D, D, dtype=dt, device=dev)
+    _fold_products([ent])
+    ops.cast_transpose(module.mode, ent['W32'], ent['Wc'], ent['Wt'])
+    ent['ver'] = ver
+    module._wcache[key] = ent
+    if train:
+        # registered like any GEMM weight: refresh_weights() recomputes W' (all blocks, one launch) and re-casts it with the others
+        module.__dict__.setdefault('_wreg', {})[key] = (ent['W32'], ent['Wc'], ent['Wt'], D, D)
+        module.__dict__.setdefault('_foldreg', {})[key] = ent
+    return ent['Wc'], ent['Wt'], ent['b32']
+
+
 def refresh_weights(module):
     """Re-cast every registered GEMM weight (bf16 copy + transposed copy) with ONE kernel launch instead of one per weight;
     called by QueryMaskTracker.invalidate_weight_cache() right after the optimizer has written the f32 master weights."""
@@ -83,6 +133,9 @@ def refresh_weights(module):
     if not reg:
         return False
     mode = module.mode
+    folds = module.__dict__.get('_foldreg')
+    if folds:
+        _fold_products(list(folds.values()))
     ents = list(reg.items())
     sig = tuple((k, p.data_ptr(), 0 if Wc is None else Wc.data_ptr(), 0 if Wt is None else Wt.data_ptr()) for k, (p, Wc, Wt, N, K) in ents) + (mode,)
     tab = module.__dict__.get('_wtab')
@@ -100,6 +153,10 @@ def refresh_weights(module):
     ops.cast_transpose_batched(mode, tab[1], tab[2], tab[3])
     epoch = getattr(module, '_wepoch', 0)
     for k, (p, Wc, Wt, N, K) in ents:
+        if folds and k in folds:
+            e = folds[k]
+            e['ver'] = (e['fc']._version, e['proj']._version, e['bproj']._version, epoch)
+            continue
         w = _w2d(p.detach())
         module._wcache[k] = ((p._version, epoch), mode, Wc if Wc is not None else w.contiguous(), Wt)
     return True
@@ -152,9 +209,10 @@ def _row_vectors(module, g, train):
         rt = rt.reshape(depth, -1)
         rsp = ks.expand(depth, B, T, S).reshape(depth, -1)
         rml = km.expand(depth, B, T * S).reshape(depth, -1)
+        rt0 = rt * mask0[None, :]               # mask0 * dp_t: row scale of the folded temporal projection
         for i in range(depth):
             live = rates[i] > 0.
-            scales.append({'t': rt[i] if live else None, 's': rsp[i] if live else None, 'm': rml[i] if live else None})
+            scales.append({'t': rt[i] if live else None, 's': rsp[i] if live else None, 'm': rml[i] if live else None, 't0': rt0[i] if live else mask0})
         return mask0, scales
     for i in range(depth):
         r = rates[i]
@@ -179,6 +237,7 @@ def _row_vectors(module, g, train):
             km = draw('mlp', (B,))
             if km is not None:
                 ent['m'] = km[:, None].expand(B, T * S).reshape(-1).contiguous()
+        ent['t0'] = mask0 if ent['t'] is None else ent['t'] * mask0
         scales.append(ent)
     return mask0, scales
 
@@ -259,6 +318,7 @@ def run_forward(module, rgb, qm, params, save):
 
     BP, ix = _layout(module)
     joint = module.attention_type != 'divided_space_time'
+    fold = _fold_on(module)
     shape_attn = ops.attn_shape(mode, B, T, S, D, heads, ca)
     if joint:
         jrows = _joint_rows(module, g, dev)
@@ -296,10 +356,15 @@ def run_forward(module, rgb, qm, params, save):
             ops.gemm_nt(gmode, U, W(q[ix['tqkv']]), QKV, bias=tqkv_b)
             O = E(M, D); lse_t = E(M, heads, dtype=f32) if save else None
             ops.attn_fwd(shape_attn, False, QKV, O, lse_t)
-            Pj = E(M, D)
-            ops.gemm_nt(gmode, O, W(q[ix['tproj']]), Pj, bias=tproj_b, row_scale=dp['t'])
             R1 = E(M, D, dtype=f32) if save else R0
-            ops.gemm_nt(gmode, Pj, W(q[ix['tfc']]), R1, bias=tfc_b, row_scale=mask0, resid=R0)
+            if fold:
+                Wf, _, bprime = _folded_weight(module, i, q, ix, train)
+                ops.gemm_nt(gmode, O, Wf, R1, bias=bprime, row_scale=dp['t0'], resid=R0, bias2=tfc_b, row_scale2=mask0)
+                Pj = None
+            else:
+                Pj = E(M, D)
+                ops.gemm_nt(gmode, O, W(q[ix['tproj']]), Pj, bias=tproj_b, row_scale=dp['t'])
+                ops.gemm_nt(gmode, Pj, W(q[ix['tfc']]), R1, bias=tfc_b, row_scale=mask0, resid=R0)
             if save:
                 st.update(R0=R0, mu0=mu0, rs0=rs0, U=U, QKV_t=QKV, O_t=O, lse_t=lse_t, Pj=Pj)
             # spatial
@@ -462,11 +527,58 @@ def run_backward(module, sv, params, d_mask, d_flags):
 
     BP, ix = _layout(module)
     joint = module.attention_type != 'divided_space_time'
-    nb = 5 + module.network_depth * BP
+    fold = _fold_on(module)
+    depth = module.network_depth
+    nb = 5 + depth * BP
     Co = module.output_channels
     have_flags = module.flag_channels > 0 and d_flags is not None and d_flags.numel() > 0
     head_idx = ([nb, nb + 1] if module.norm_embeddings else []) + [nb + 2, nb + 3] + ([nb + 4, nb + 5] if have_flags else [])
-    head_flat = bucket(head_idx)
+    # Gradient buckets = GROUPS of transformer blocks (TCOW_DDP_GROUP blocks each, default 3; the top group also carries the output heads, the
+    # bottom one the embeddings): 4 all-reduces of ~115-150 MB at depth 12 instead of 14 of ~38 MB -- each collective is a window in which
+    # resident RCCL workgroups push the one-workgroup-per-CU GEMMs into an extra round (profiles/r02_cu_contention.txt), so fewer, larger
+    # ones; and the folded projection's small products (below) run once per group.
+    gs = max(1, int(os.environ.get('TCOW_DDP_GROUP', '3')))
+    group_lo = {}                                   # block index -> first block of its group
+    for hi_ in range(depth, 0, -gs):
+        for j in range(max(0, hi_ - gs), hi_):
+            group_lo[j] = max(0, hi_ - gs)
+    top_lo = group_lo[depth - 1]
+    # The folded projection's three gradients per block (tproj.weight, tproj.bias, tfc.weight) come out of small products that are worth
+    # batching over ALL blocks (a launch of three 768^3 problems is pure latency: 35 us whether it carries 3 problems or 12), so they form one
+    # LATE bucket of their own (57 MB at ViT-B), finished and published once after the last block.
+    late = set()
+    if fold:
+        for j in range(depth):
+            late.update((5 + j * BP + ix['tproj'], 5 + j * BP + ix['tproj'] + 1, 5 + j * BP + ix['tfc']))
+    late_flat = bucket(sorted(late)) if late else None
+    blk_idx = lambda lo_, hi_: [j for j in range(5 + lo_ * BP, 5 + hi_ * BP) if j not in late]
+    flat_cur = bucket((list(range(0, 5)) if top_lo == 0 else []) + blk_idx(top_lo, depth) + head_idx)
+    fold_jobs = []          # (block, dW' [D,D], db' [D])
+
+    def fold_tmp(i):
+        t = module._gbufs.get(('foldtmp', i, str(dev)))
+        if t is None:
+            t = module._gbufs[('foldtmp', i, str(dev))] = (torch.empty(D, D, dtype=f32, device=dev), torch.empty(D, dtype=f32, device=dev))
+        return t
+
+    def finish_fold_group():
+        """Z = P Wfc^T + b_fc with P = dp_t (O Wproj^T + b_proj) and dY' = dp_t dZ:  dWfc = dZ^T P = dW' Wproj^T + db' b_proj^T,
+        dWproj = Wfc^T dW', db_proj = Wfc^T db' for all blocks: four batched launches (<= 24 problems each)."""
+        if not fold_jobs:
+            return
+        nt_, r1_, tn_, gv_ = [], [], [], []
+        for (i, tW, tb) in fold_jobs:
+            o_ = 5 + i * BP
+            wfc, wp, bp = params[o_ + ix['tfc']].detach(), params[o_ + ix['tproj']].detach(), params[o_ + ix['tproj'] + 1].detach()
+            nt_.append((tW, wp.t(), grads[o_ + ix['tfc']]))
+            r1_.append((tb.view(-1, 1), bp.view(1, -1), grads[o_ + ix['tfc']]))
+            tn_.append((wfc.t(), tW, grads[o_ + ix['tproj']]))
+            gv_.append((wfc.t(), tb.view(-1, 1), grads[o_ + ix['tproj'] + 1].view(-1, 1)))
+        for c0 in range(0, len(nt_), 24):
+            ops.sgemm_batched(nt_[c0:c0 + 24]); ops.sgemm_batched(r1_[c0:c0 + 24], accumulate=True)
+            ops.sgemm_batched(tn_[c0:c0 + 24]); ops.sgemm_batched(gv_[c0:c0 + 24])
+        fold_jobs.clear()
+
     # ---- mask head backward (mask_tracker.py:113-132)
     if d_mask is None:
         d_mask = torch.zeros(B, Co, T, module.frame_height, module.frame_width, dtype=f32, device=dev)
@@ -493,8 +605,6 @@ def run_backward(module, sv, params, d_mask, d_flags):
         ops.layernorm_bwd(ops.F32, dFeat, sv['X_final'], sv['muf'], sv['rsf'], params[nb].detach(), None, dX, galloc(nb), galloc(nb + 1))
     else:
         dX = dFeat     # model.norm takes no part when norm_embeddings is False (vision_tf.py:152): its grads stay None
-    publish('head', head_flat)
-
     shape_attn = ops.attn_shape(mode, B, T, S, D, heads, ca)
     if joint:
         jrows = _joint_rows(module, g, dev)
@@ -508,7 +618,9 @@ def run_backward(module, sv, params, d_mask, d_flags):
         st = sv['blocks'][i]
         dp = sv['dps'][i]
         Hd = q[ix['fc1']].shape[0]
-        blk_flat = bucket(range(o, o + BP))
+        if i != depth - 1 and group_lo[i] != group_lo[i + 1]:          # first (top) block of the next group: its bucket
+            lo_ = group_lo[i]
+            flat_cur = bucket((list(range(0, 5)) if lo_ == 0 else []) + blk_idx(lo_, i + 1))
         next_scale = (sv['dps'][i - 1]['m'] if i > 0 else mask0)      # row scale of the operand the block below (or the patch embedding) consumes
         # ---- mlp
         if G3_next is not None:
@@ -546,20 +658,31 @@ def run_backward(module, sv, params, d_mask, d_flags):
         linear_bwd(o + ix['qkv'], dQKV2, st['V'], defer=True)
         dR1 = E(M, D, dtype=f32)
         G1 = E(M, D)                           # bf16(dR1 * row scale), written by the same LayerNorm backward pass
-        ops.layernorm_bwd(mode, dV, st['R1'], st['mu1'], st['rs1'], q[ix['n1']].detach(), dR2, dR1, galloc(o + ix['n1']), galloc(o + ix['n1'] + 1), dx_cast=G1,
-                          cast_scale=(next_scale if joint else mask0))
+        if fold:
+            # G1 = bf16(dR1 * mask0 * dp_t) = dY' of the folded projection; its bias b_fc sees dR1 * mask0: summed here, in f32
+            ops.layernorm_bwd(mode, dV, st['R1'], st['mu1'], st['rs1'], q[ix['n1']].detach(), dR2, dR1, galloc(o + ix['n1']), galloc(o + ix['n1'] + 1), dx_cast=G1,
+                              cast_scale=dp['t0'], colsum_out=galloc(o + ix['tfc'] + 1), colsum_scale=mask0)
+        else:
+            ops.layernorm_bwd(mode, dV, st['R1'], st['mu1'], st['rs1'], q[ix['n1']].detach(), dR2, dR1, galloc(o + ix['n1']), galloc(o + ix['n1'] + 1), dx_cast=G1,
+                              cast_scale=(next_scale if joint else mask0))
         del G2, dO2, dQKV2, dV
         if joint:
             G3_next = G1                       # a joint block has no temporal half: its input gradient is complete here
             dR3 = dR1
         else:
             # ---- temporal
-            dPj = E(M, D)
-            ops.gemm_nt(gmode, G1, Wt(q[ix['tfc']]), dPj, row_scale=dp['t'])
-            linear_bwd(o + ix['tfc'], G1, st['Pj'], defer=True)
             dO = E(M, D)
-            ops.gemm_nt(gmode, dPj, Wt(q[ix['tproj']]), dO)
-            linear_bwd(o + ix['tproj'], dPj, st['O_t'], defer=True)
+            if fold:
+                ops.gemm_nt(gmode, G1, _folded_weight(module, i, q, ix, True)[1], dO)
+                tW, tb = fold_tmp(i)
+                pending.append((G1, st['O_t'], tW, tb))
+                fold_jobs.append((i, tW, tb))
+            else:
+                dPj = E(M, D)
+                ops.gemm_nt(gmode, G1, Wt(q[ix['tfc']]), dPj, row_scale=dp['t'])
+                linear_bwd(o + ix['tfc'], G1, st['Pj'], defer=True)
+                ops.gemm_nt(gmode, dPj, Wt(q[ix['tproj']]), dO)
+                linear_bwd(o + ix['tproj'], dPj, st['O_t'], defer=True)
             dQKV = E(M, 3 * D)
             ops.attn_bwd(shape_attn, False, st['QKV_t'], st['O_t'], dO, st['lse_t'], dQKV)
             dU = E(M, D)
@@ -570,13 +693,16 @@ def run_backward(module, sv, params, d_mask, d_flags):
             ops.layernorm_bwd(mode, dU, st['R0'], st['mu0'], st['rs0'], q[ix['tn']].detach(), dR1, dR0, galloc(o + ix['tn']), galloc(o + ix['tn'] + 1),
                               dx_cast=G3_next, cast_scale=next_scale)
             dR3 = dR0
-        flush_pending()          # the block's seven (joint: four) weight-gradient GEMMs as one grouped launch
+        flush_pending()          # the block's six or seven (joint: four) weight-gradient GEMMs as one grouped launch
         sv['blocks'][i] = None   # free this block's activations
-        publish(i, blk_flat)
+        if i > 0 and group_lo[i] == i:                                 # last (bottom) block of a group that is not the bottom group: done
+            publish('g%d' % i, flat_cur)
 
     # ---- embeddings + patch embed backward
     gX = dR3
-    emb_flat = bucket(range(0, 5))
+    finish_fold_group()
+    if late_flat is not None:
+        publish('fold', late_flat)
     resized = sv['pos_idx'] is not None or sv['time_idx'] is not None
     dpos_eff = grads[1][0] if sv['pos_idx'] is None else E(S, D, dtype=f32)
     dtime_eff = grads[2][0] if sv['time_idx'] is None else E(T, D, dtype=f32)
@@ -605,7 +731,7 @@ def run_backward(module, sv, params, d_mask, d_flags):
     else:
         ops.gemm_tn(gmode, Gpe, sv['A_pe'], dWpe)
     grads[4].copy_(dtime_eff.sum(0))       # bias gradient = sum over all patch rows
-    publish('embed', emb_flat)
+    publish('g0', flat_cur)
     if module.grad_hook is not None:
         # The collectives launched above were overlapped with the remaining backward compute; they must be complete (in
         # stream order) before autograd copies the bucket views into param.grad, so the hook is drained here.

@@ -45,7 +45,7 @@ def _need_cuda(*ts):
             raise L.TcowError('libtcow_hip kernels need CUDA/HIP tensors (no CPU fallback on this path)')
 
 
-def gemm_nt(mode, A, W, out, bias=None, row_scale=None, resid=None, act=ACT_NONE, aux=None, tile=0):
+def gemm_nt(mode, A, W, out, bias=None, row_scale=None, resid=None, act=ACT_NONE, aux=None, tile=0, bias2=None, row_scale2=None):
     """out[M,N] = epilogue(A[M,K] @ W[N,K]^T); see tcow_gemm_nt. `out` dtype f32 or the mode's dtype."""
     _need_cuda(A, W, out)
     M, K = A.shape
@@ -53,7 +53,7 @@ def gemm_nt(mode, A, W, out, bias=None, row_scale=None, resid=None, act=ACT_NONE
     lib, dm = _sel(mode)
     a = L.GemmArgs(M, N, K, dm, A.data_ptr(), A.stride(0), W.data_ptr(), W.stride(0), out.data_ptr(), out.stride(0),
                    1 if out.dtype == torch.float32 else 0, _p(bias), _p(row_scale), _p(resid),
-                   resid.stride(0) if resid is not None else 0, act, _p(aux), aux.stride(0) if aux is not None else 0, int(tile))
+                   resid.stride(0) if resid is not None else 0, act, _p(aux), aux.stride(0) if aux is not None else 0, int(tile), _p(bias2), _p(row_scale2))
     L.check(lib.tcow_gemm_nt(_stream(), ctypes.byref(a)), 'tcow_gemm_nt', lib)
     return out
 
@@ -97,6 +97,20 @@ def gemm_tn_grouped(mode, problems):
     L.check(lib.tcow_gemm_tn_grouped(_stream(), dm, n, arr, ws.data_ptr(), ws.numel()), 'tcow_gemm_tn_grouped', lib)
 
 
+def sgemm_batched(problems, accumulate=False):
+    """Small f32 products C (+)= A B, several per launch (tcow_sgemm_x3_batched).  problems = [(A, B, C), ...] with 2-D f32 tensors of ANY
+    strides: A [M,K], B [K,N] (pass `.t()` views for transposed operands), C [M,N] row-major with unit column stride."""
+    n = len(problems)
+    arr = (L.SGemm * n)()
+    for i, (A, B, C) in enumerate(problems):
+        _need_cuda(A, B, C)
+        M, K = A.shape
+        N = B.shape[1]
+        assert B.shape[0] == K and C.shape == (M, N) and C.stride(1) == 1 and A.dtype == B.dtype == C.dtype == torch.float32
+        arr[i] = L.SGemm(M, N, K, A.data_ptr(), A.stride(0), A.stride(1), B.data_ptr(), B.stride(1), B.stride(0), C.data_ptr(), C.stride(0), 1 if accumulate else 0)
+    L.check(L.lib().tcow_sgemm_x3_batched(_stream(), n, arr), 'tcow_sgemm_x3_batched')
+
+
 def layernorm_fwd(mode, x, gamma, beta, out, mean=None, rstd=None, eps=1e-6):
     rows, D = x.shape
     lib, dm = _sel(mode)
@@ -105,15 +119,17 @@ def layernorm_fwd(mode, x, gamma, beta, out, mean=None, rstd=None, eps=1e-6):
     return out
 
 
-def layernorm_bwd(mode, dy, x, mean, rstd, gamma, dres, dx, dgamma=None, dbeta=None, accumulate=False, dx_cast=None, cast_scale=None):
-    """dx = dres + dLN(dy); dx_cast (mode dtype, optional) = dx * cast_scale[row]: the next input-gradient GEMM's operand."""
+def layernorm_bwd(mode, dy, x, mean, rstd, gamma, dres, dx, dgamma=None, dbeta=None, accumulate=False, dx_cast=None, cast_scale=None,
+                  colsum_out=None, colsum_scale=None):
+    """dx = dres + dLN(dy); dx_cast (mode dtype, optional) = dx * cast_scale[row]: the next input-gradient GEMM's operand;
+    colsum_out [D] (optional) = sum over rows of colsum_scale[row] * dx[row]."""
     rows, D = x.shape
     lib, dm = _sel(mode)
     ws = workspace(lib.tcow_layernorm_bwd_workspace_bytes(D), x.device, 'ln')
     L.check(lib.tcow_layernorm_bwd(_stream(), dm, rows, D, dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), mean.data_ptr(),
                                    rstd.data_ptr(), gamma.data_ptr(), _p(dres), dres.stride(0) if dres is not None else 0, dx.data_ptr(),
                                    dx.stride(0), _p(dgamma), _p(dbeta), int(accumulate), ws.data_ptr(), ws.numel(),
-                                   _p(dx_cast), dx_cast.stride(0) if dx_cast is not None else 0, _p(cast_scale)), 'tcow_layernorm_bwd', lib)
+                                   _p(dx_cast), dx_cast.stride(0) if dx_cast is not None else 0, _p(cast_scale), _p(colsum_scale), _p(colsum_out)), 'tcow_layernorm_bwd', lib)
     return dx
 
 

@@ -70,7 +70,9 @@ def test_backward_drains_the_hook_before_returning_grads():
     import inspect
     from tcow_amd import engine
     src = inspect.getsource(engine.run_backward)
-    assert src.index("publish('embed', emb_flat)") < src.index('module.grad_hook.finish()') < src.rindex('return grads')
+    assert src.index("publish('g0', flat_cur)") < src.index('module.grad_hook.finish()') < src.rindex('return grads')
+    # the folded projection's gradients (dWfc, dWproj, db_proj) are finished BEFORE their group's bucket is published
+    assert src.index('finish_fold_group()\n    if late_flat is not None:\n        publish(') < src.index("publish('g0', flat_cur)")
     # every bucket goes through publish(): the loss scale of the fp16 mode is undone BEFORE the data-parallel hook sees the bucket
     assert src.index('flat.mul_(inv_gscale)') < src.index('module.grad_hook(tag, flat)')
 

@@ -46,6 +46,13 @@ def test_gemm_nt_epilogues(ops, cuda, mname, tol, M, K, N):
     inplace = resid.clone()                                                   # residual may alias the f32 output
     ops.gemm_nt(mode, A, W, inplace, bias=bias, resid=inplace)
     assert rel(inplace, ref0 + bias.double() + resid.double()) < tol
+    # second bias with its own row scale (the folded temporal projection: mask0 * (s (O W'^T + b') + b_fc))
+    b2 = torch.randn(N, device=cuda, generator=g); rs2 = (torch.rand(M, device=cuda, generator=g) > 0.3).float()
+    want2 = (ref0 + bias.double()) * rs.double()[:, None] + rs2.double()[:, None] * b2.double() + resid.double()
+    C = ops.gemm_nt(mode, A, W, torch.empty(M, N, device=cuda), bias=bias, row_scale=rs, resid=resid, bias2=b2, row_scale2=rs2)
+    assert rel(C, want2) < tol
+    C = ops.gemm_nt(mode, A, W, torch.empty(M, N, device=cuda, dtype=dt), bias=bias, bias2=b2)
+    assert rel(C, ref0 + bias.double() + b2.double()) < tol
     aux = torch.empty(M, N, device=cuda, dtype=dt)
     C = ops.gemm_nt(mode, A, W, torch.empty(M, N, device=cuda, dtype=dt), bias=bias, act=ops.ACT_GELU, aux=aux)
     assert rel(C, F.gelu(ref0 + bias.double())) < tol and rel(aux, ref0 + bias.double()) < tol
@@ -77,6 +84,7 @@ def test_gemm_nt_every_tile_kernel_at_bench_size(ops, cuda, N, K, fmt):
     A = torch.randn(M, K, device=cuda, generator=g).to(h16); W = (torch.randn(N, K, device=cuda, generator=g) * 0.05).to(h16)
     bias = torch.randn(N, device=cuda, generator=g); rs = torch.rand(M, device=cuda, generator=g) + 0.5; rs[::7] = 0.0
     resid = torch.randn(M, N, device=cuda, generator=g); pre = torch.randn(M, N, device=cuda, generator=g).to(h16)
+    b2 = torch.randn(N, device=cuda, generator=g); rs2 = (torch.rand(M, device=cuda, generator=g) > 0.3).float()
     ref0 = A.double() @ W.double().t()
     refb = ref0 + bias.double()
     xv = refb.clone().requires_grad_(True)
@@ -94,6 +102,12 @@ def test_gemm_nt_every_tile_kernel_at_bench_size(ops, cuda, N, K, fmt):
         inplace = resid.clone()
         ops.gemm_nt(H16, A, W, inplace, bias=bias, row_scale=rs, resid=inplace, **t)                                    # eval: residual aliases the output
         assert rel(inplace, refb * rs.double()[:, None] + resid.double()) < F32
+        if N == 768 and K == 768:                                                                                       # <NONE, 7>: the folded temporal projection
+            want7 = refb * rs.double()[:, None] + rs2.double()[:, None] * b2.double() + resid.double()
+            assert rel(ops.gemm_nt(H16, A, W, f32(), bias=bias, row_scale=rs, resid=resid, bias2=b2, row_scale2=rs2, **t), want7) < F32
+            inplace = resid.clone()
+            ops.gemm_nt(H16, A, W, inplace, bias=bias, row_scale=rs, resid=inplace, bias2=b2, row_scale2=rs2, **t)
+            assert rel(inplace, want7) < F32
         aux = bf()
         assert rel(ops.gemm_nt(H16, A, W, bf(), bias=bias, act=ops.ACT_GELU_DSAVE, aux=aux, **t), gel) < BF and rel(aux, dgel) < BF   # <GELU_DSAVE, 0>: fc1 (training)
         assert rel(ops.gemm_nt(H16, A, W, bf(), bias=bias, act=ops.ACT_GELU, **t), gel) < BF                            # <GELU, 0>: fc1 (inference)
@@ -167,6 +181,40 @@ def test_gemm_tn_grouped_block_weights(ops, cuda, M, fmt):
         assert rel(dW, dY.double().t() @ X.double()) < 2e-5
 
 
+@pytest.mark.parametrize('D', [768, 256, 100])
+def test_sgemm_batched_small_products(ops, cuda, D):
+    """The small f32 products of the folded temporal projection, every operand form the engine issues (plain, B transposed, A transposed,
+    matrix x vector both ways), several problems per launch; split-bf16 arithmetic: ~5e-6 relative."""
+    g = torch.Generator(device='cuda').manual_seed(D)
+    mats = [torch.randn(D, D, device=cuda, generator=g) * 0.05 for _ in range(6)]
+    vecs = [torch.randn(D, device=cuda, generator=g) for _ in range(3)]
+    out = lambda *sh: torch.full(sh, float('nan'), device=cuda)
+    # W' = Wfc Wproj (three problems in one launch)
+    C = [out(D, D) for _ in range(3)]
+    ops.sgemm_batched([(mats[i], mats[i + 3], C[i]) for i in range(3)])
+    for i in range(3):
+        assert rel(C[i], mats[i].double() @ mats[i + 3].double()) < 2e-5
+    # dWfc = dW' Wproj^T, dWproj = Wfc^T dW'
+    C = [out(D, D) for _ in range(2)]
+    ops.sgemm_batched([(mats[0], mats[1].t(), C[0]), (mats[2], mats[3].t(), C[1])])
+    assert rel(C[0], mats[0].double() @ mats[1].double().t()) < 2e-5 and rel(C[1], mats[2].double() @ mats[3].double().t()) < 2e-5
+    C = [out(D, D) for _ in range(2)]
+    ops.sgemm_batched([(mats[0].t(), mats[1], C[0]), (mats[2].t(), mats[3], C[1])])
+    assert rel(C[0], mats[0].double().t() @ mats[1].double()) < 2e-5 and rel(C[1], mats[2].double().t() @ mats[3].double()) < 2e-5
+    # b' = Wfc b_proj, db_proj = Wfc^T db'
+    c = [out(D) for _ in range(2)]
+    ops.sgemm_batched([(mats[0], vecs[0].view(1, -1).t(), c[0].view(-1, 1)), (mats[1], vecs[1].view(1, -1).t(), c[1].view(-1, 1))])
+    assert rel(c[0], mats[0].double() @ vecs[0].double()) < 2e-5 and rel(c[1], mats[1].double() @ vecs[1].double()) < 2e-5
+    c = [out(D) for _ in range(2)]
+    ops.sgemm_batched([(mats[0].t(), vecs[0].view(-1, 1), c[0].view(-1, 1)), (mats[1].t(), vecs[2].view(-1, 1), c[1].view(-1, 1))])
+    assert rel(c[0], mats[0].double().t() @ vecs[0].double()) < 2e-5 and rel(c[1], mats[1].double().t() @ vecs[2].double()) < 2e-5
+    # rank-1 update C += u v^T (dWfc's bias term)
+    C = [mats[4].clone(), mats[5].clone()]
+    ops.sgemm_batched([(vecs[0].view(-1, 1), vecs[1].view(1, -1), C[0]), (vecs[1].view(-1, 1), vecs[2].view(1, -1), C[1])], accumulate=True)
+    assert rel(C[0], mats[4].double() + torch.outer(vecs[0].double(), vecs[1].double())) < 2e-5
+    assert rel(C[1], mats[5].double() + torch.outer(vecs[1].double(), vecs[2].double())) < 2e-5
+
+
 def test_gemm_rejects_bad_arguments(ops, cuda):
     from tcow_amd._lib import TcowError
     A = torch.zeros(8, 72, device=cuda, dtype=torch.bfloat16); W = torch.zeros(8, 72, device=cuda, dtype=torch.bfloat16)
@@ -200,6 +248,12 @@ def test_layernorm_fwd_bwd(ops, cuda, mname, tol, rows, D):
         ops.layernorm_bwd(mode, dy, x, mu, rs, w, dres, dx2, dx_cast=dxc, cast_scale=scale)
         ops.scale_cast(mode, dx2, scale, want)
         assert torch.equal(dx2, dx) and torch.equal(dxc, want)
+    # fused row-weighted column sum of dx (the bias gradient of the Linear below the norm), with and without weights
+    for scale in (sc, None):
+        dx3 = torch.empty(rows, D, device=cuda); dg3 = torch.empty(D, device=cuda); db3 = torch.empty(D, device=cuda); cs = torch.full((D,), float('nan'), device=cuda)
+        ops.layernorm_bwd(mode, dy, x, mu, rs, w, dres, dx3, dg3, db3, colsum_out=cs, colsum_scale=scale)
+        want_cs = (dx.double() * (scale.double()[:, None] if scale is not None else 1.0)).sum(0)
+        assert torch.equal(dx3, dx) and rel(dg3, dg) < 1e-5 and rel(db3, db) < 1e-5 and rel(cs, want_cs) < 1e-5
 
 
 def _ref_attn(qkv, B, T, S, D, heads, ca, spatial):

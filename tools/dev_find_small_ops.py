@@ -25,10 +25,10 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stac
 import re
 cnt = collections.Counter()
 for ev in prof.events():
-    if ev.name in ('aten::fill_', 'aten::zero_', 'aten::copy_', 'aten::zeros', 'aten::full', 'aten::ones') and ev.device_time_total > 0 or ev.name in ('aten::fill_',):
+    if ev.name in ('aten::fill_', 'aten::zero_', 'aten::copy_', 'aten::zeros', 'aten::full', 'aten::ones', 'aten::sum', 'aten::any', 'aten::index', 'aten::eq', 'aten::ne', 'aten::gt', 'aten::lt', 'aten::mul', 'aten::add', 'aten::where', 'aten::cat', 'aten::stack', 'aten::clone', 'aten::contiguous', 'aten::index_put_', 'aten::_to_copy', 'aten::add_', 'aten::mul_', 'aten::div', 'aten::rand', 'aten::floor_', 'aten::expand'):
         fr = [f for f in (ev.stack or []) if '/tcow_amd/' in f or 'bench' in f]
         cnt[(ev.name, fr[0] if fr else (ev.stack[0] if ev.stack else '?'))] += 1
-for (n, f), c in cnt.most_common(30):
+for (n, f), c in cnt.most_common(70):
     print(f'{c:4d} {n:14s} {f[:130]}')
 ka = prof.key_averages()
 rows = sorted(ka, key=lambda e: -e.count)
