@@ -70,9 +70,19 @@ def pretrained_surgery(state_dict, in_chans, num_patches, num_frames, patch_size
     return out
 
 
-def _torch_load(path):
-    """Reference checkpoints are ordinary pickles: train.py:269-283 stores `train_args` as an argparse.Namespace next to the
-    tensors, and the image-ViT files are plain dicts.  torch >= 2.6 defaults to weights_only=True, which rejects both."""
+def _torch_load(path, trusted=False):
+    """Tensor-only loading first (torch.load(weights_only=True) with argparse.Namespace allow-listed: train.py:269-283 stores `train_args` as
+    one next to the tensors); only a file the caller declares TRUSTED -- a TCOW checkpoint.pth written by train.py or save_tcow_checkpoint,
+    which may hold further plain-Python objects -- falls back to the full unpickler, which executes code from the file.  Downloaded image-ViT
+    weights (`tracker_pretrained=<path>`) are never loaded that way."""
+    import argparse
+    import pickle
+    try:
+        with torch.serialization.safe_globals([argparse.Namespace]):
+            return torch.load(path, map_location='cpu', weights_only=True)
+    except (pickle.UnpicklingError, RuntimeError, AttributeError):
+        if not trusted:
+            raise
     return torch.load(path, map_location='cpu', weights_only=False)
 
 
@@ -121,7 +131,7 @@ def load_tcow_checkpoint(path, logger=None, device='cuda', precision='bf16'):
     the part that matters -- keeps the (rgb - 0.45) / 0.225 input normalisation of vision_tf.py:81-89 switched on.  Here the module is
     constructed without the (offline-impossible, redundant) download and the parsed flag is restored afterwards."""
     from .seeker import Seeker
-    ck = _torch_load(path)
+    ck = _torch_load(path, trusted=True)
     args = dict(ck['seeker_args'])
     flag, _ = parse_tracker_pretrained(args.get('tracker_pretrained', False))
     args['tracker_pretrained'] = False
@@ -131,16 +141,28 @@ def load_tcow_checkpoint(path, logger=None, device='cuda', precision='bf16'):
     return net.to(device)
 
 
-def save_tcow_checkpoint(directory, epoch, net, optimizer=None, lr_scheduler=None, seeker_args=None, train_args=None, dset_args=None, name='tcow_amd'):
+def save_tcow_checkpoint(directory, epoch, net, optimizer=None, lr_scheduler=None, seeker_args=None, train_args=None, dset_args=None, name='tcow_amd',
+                         checkpoint_every=0):
     """train.py:269-304 (`save_model_checkpoint`): the reference's checkpoint dictionary and side files, so that its own `--resume`
     (train.py:246-257) and eval/inference.py:38-54 read what this framework trained.  `net` is the Seeker (un-wrapped: the reference
-    saves `networks_nodp`); optimizer / lr_scheduler state dicts use torch's layout (FusedAdamWClip keeps torch.optim.AdamW's)."""
+    saves `networks_nodp`); optimizer / lr_scheduler state dicts use torch's layout (FusedAdamWClip keeps torch.optim.AdamW's).
+    seeker_args defaults to the constructor keywords the Seeker recorded; train_args (the reference's argparse.Namespace: eval/inference.py
+    deep-copies it and reads .num_queries etc.) must be supplied by the caller for checkpoints the reference's tools are to read.
+    checkpoint_every > 0 also writes the periodic copy model_{epoch}.pth of train.py:297-300, which inference.py reads for epoch >= 0."""
     import os
+    import shutil
     import numpy as np
     os.makedirs(directory, exist_ok=True)
+    if seeker_args is None:
+        seeker_args = getattr(net, 'seeker_args', None)
+        if not seeker_args:
+            raise TcowError('save_tcow_checkpoint: no seeker_args (the module did not record its constructor keywords): pass seeker_args=')
+    tracker = getattr(net, 'seeker', None)
     checkpoint = {'epoch': epoch, 'train_args': train_args, 'dset_args': dset_args if dset_args is not None else {},
-                  'seeker_args': dict(seeker_args) if seeker_args is not None else dict(getattr(net, 'seeker_args', {})),
+                  'seeker_args': dict(seeker_args),
                   'net_seeker': {k: v.detach().cpu() for k, v in net.state_dict().items()}}
+    if tracker is not None and getattr(tracker, 'precision', None) == 'fp16':
+        checkpoint['tcow_amd_loss_scale_log2'] = float(tracker.ls_log2)          # (extra key: ignored by the reference's readers)
     if optimizer is not None:
         checkpoint['optim_seeker'] = optimizer.state_dict()
     if lr_scheduler is not None:
@@ -149,16 +171,21 @@ def save_tcow_checkpoint(directory, epoch, net, optimizer=None, lr_scheduler=Non
     torch.save(checkpoint, path)
     np.savetxt(os.path.join(directory, 'checkpoint_epoch.txt'), np.array([epoch], dtype=np.int32), fmt='%d')       # train.py:292-295
     np.savetxt(os.path.join(directory, 'checkpoint_name.txt'), np.array([name]), fmt='%s')
+    if checkpoint_every > 0 and epoch % checkpoint_every == 0:                                                      # train.py:297-300
+        shutil.copy(path, os.path.join(directory, f'model_{epoch}.pth'))
     return path
 
 
 def resume_tcow_checkpoint(path, net, optimizer=None, lr_scheduler=None):
     """train.py:246-257: weights, optimizer and scheduler state of a checkpoint.pth into live objects; returns the epoch to start from."""
-    ck = _torch_load(path)
+    ck = _torch_load(path, trusted=True)
     net.load_state_dict(ck['net_seeker'], strict=True)
     tracker = getattr(net, 'seeker', None)
     if tracker is not None and hasattr(tracker, 'invalidate_weight_cache'):
         tracker.invalidate_weight_cache()
+    if tracker is not None and 'tcow_amd_loss_scale_log2' in ck and 'ls_log2' in tracker._buffers:
+        with torch.no_grad():
+            tracker.ls_log2.fill_(float(ck['tcow_amd_loss_scale_log2']))
     if optimizer is not None and ck.get('optim_seeker'):
         optimizer.load_state_dict(ck['optim_seeker'])
     if lr_scheduler is not None and ck.get('lr_sched_seeker'):

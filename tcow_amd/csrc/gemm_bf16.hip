@@ -443,7 +443,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_320_kernel(NtParams p) {
     const int pid = xcd_remap(blockIdx.x, nblk);
     const int pm = pid / p.tiles_n, pn = pid - pm * p.tiles_n;
     const int m0 = pm * C_BM, n0 = pn * C_BN;
-
     // wave w issues wave-loads 5w..5w+4 of A (8 rows x 128 B each) and 4w..4w+3 of W per stage; 32-bit element offsets from the
     // tile's first row keep the nine addresses in nine registers
     const bf16_t* a_base = p.A + (size_t)m0 * p.lda;

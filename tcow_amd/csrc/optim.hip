@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const Chunk* __restrict__ ch
     if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-__global__ __launch_bounds__(256) void clipcoef_kernel(const float* __restrict__ partial, int n, float max_norm, float* __restrict__ out /* [0]=coef, [1]=norm */) {
+__global__ __launch_bounds__(256) void clipcoef_kernel(const float* __restrict__ partial, int n, float max_norm, float* __restrict__ out /* [0]=coef, [1]=norm, [2]+=skipped */) {
     __shared__ float red[4];
     float s = 0.f;
     for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
@@ -36,16 +36,22 @@ __global__ __launch_bounds__(256) void clipcoef_kernel(const float* __restrict__
         const float norm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
         float coef = max_norm > 0.f ? max_norm / (norm + 1e-6f) : 1.0f;
         // a non-finite gradient norm (an overflow in a 16-bit backward) marks the step as skipped: coefficient -1
-        out[0] = !(norm <= 3.0e38f) ? -1.0f : (coef < 1.0f ? coef : 1.0f);
+        const bool skip = !(norm <= 3.0e38f);
+        out[0] = skip ? -1.0f : (coef < 1.0f ? coef : 1.0f);
         out[1] = norm;
+        if (skip) out[2] += 1.0f;                  // steps skipped so far (every precision): the update kernel counts them out of its bias correction
     }
 }
 
 __global__ __launch_bounds__(256) void adamw_kernel(const Chunk* __restrict__ chunks, const float* __restrict__ coef_ptr, float lr, float beta1, float beta2, float eps,
-                                                    float weight_decay, float bc1, float bc2_sqrt) {
+                                                    float weight_decay, int step) {
     const Chunk c = chunks[blockIdx.x];
     const float coef = coef_ptr[0];
     if (coef < 0.f) return;                        // non-finite gradients: parameters and moments stay as they are (like a GradScaler skip)
+    // bias correction with the number of updates actually APPLIED: the caller counts calls, skipped ones are subtracted here, so the moments
+    // and their correction stay in step after an overflow (torch's GradScaler does not advance the optimizer on a skipped step either)
+    const float eff = fmaxf((float)step - coef_ptr[2], 1.0f);
+    const float bc1 = 1.0f - powf(beta1, eff), bc2_sqrt = sqrtf(1.0f - powf(beta2, eff));
     const float decay = 1.0f - lr * weight_decay, step_size = lr / bc1;
     const long n4 = c.n >> 2;
     auto upd = [&](float& p, float g, float& m, float& v) {
@@ -70,8 +76,10 @@ extern "C" {
 
 long tcow_adamw_chunk_bytes(void) { return (long)sizeof(Chunk); }
 
-// chunks: device array of n_chunks {p, g, m, v, n} records (all f32, 16-byte aligned starts); scratch: f32 [n_chunks + 2];
-// on return scratch[n_chunks] = clip coefficient, scratch[n_chunks + 1] = total gradient norm (device side, no sync).
+// chunks: device array of n_chunks {p, g, m, v, n} records (all f32, 16-byte aligned starts); scratch: f32 [n_chunks + 3];
+// on return scratch[n_chunks] = clip coefficient (-1 = step skipped), scratch[n_chunks + 1] = total gradient norm,
+// scratch[n_chunks + 2] += 1 if the step was skipped (the caller zeroes it once; device side, no sync).  `step` = number of calls so far
+// (>= 1); the bias correction uses step - scratch[n_chunks + 2].
 int tcow_adamw_clip_step(void* stream, const void* chunks, int n_chunks, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                          float max_norm, float* scratch) {
     TCOW_CHECK_ARG(chunks && scratch && n_chunks > 0 && step >= 1, "tcow_adamw_clip_step: bad arguments");
@@ -80,8 +88,7 @@ int tcow_adamw_clip_step(void* stream, const void* chunks, int n_chunks, float l
     TCOW_CHECK_LAUNCH();
     hipLaunchKernelGGL(clipcoef_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, scratch, n_chunks, max_norm, scratch + n_chunks);
     TCOW_CHECK_LAUNCH();
-    const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
-    hipLaunchKernelGGL(adamw_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, c, scratch + n_chunks, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2));
+    hipLaunchKernelGGL(adamw_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, c, scratch + n_chunks, lr, beta1, beta2, eps, weight_decay, step);
     TCOW_CHECK_LAUNCH();
     return TCOW_OK;
 }

@@ -62,6 +62,8 @@ class GradSync:
         self.deferred = []
         self.bytes = 0
         self.launched = []
+        self.steps = 0                  # finish() calls
+        self._exposed = []              # per finish(): (start event, end event) on the compute stream, or seconds on the CPU path
 
     def _launch(self, flat):
         op = dist.ReduceOp.AVG if self.native_avg else dist.ReduceOp.SUM
@@ -79,9 +81,43 @@ class GradSync:
             self.deferred.append(flat)
 
     def finish(self):
+        """Drain: the compute stream waits for every collective of this backward.  The wait is bracketed by two events on that stream, so
+        `stats()` can report how long the stream actually stood still for communication (the EXPOSED part of the all-reduce) without any
+        synchronisation inside the step."""
         for flat in self.deferred:
             self._launch(flat)
         self.deferred = []
+        self.steps += 1
+        if not self.pending:
+            return
+        on_gpu = self.pending[0][1].is_cuda
+        if on_gpu:
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e0.record()
+        else:
+            import time
+            t0 = time.perf_counter()
+        self._drain()
+        if on_gpu:
+            e1.record(); self._exposed.append((e0, e1))
+        else:
+            self._exposed.append(time.perf_counter() - t0)
+
+    def reset_stats(self):
+        self.bytes = 0; self.launched = []; self.steps = 0; self._exposed = []
+
+    def stats(self):
+        """Since the last reset_stats(): all-reduce bytes and buckets per step and the mean exposed wait per step in ms (synchronises)."""
+        n = max(self.steps, 1)
+        ms = 0.0
+        for e in self._exposed:
+            if isinstance(e, tuple):
+                e[1].synchronize(); ms += e[0].elapsed_time(e[1])
+            else:
+                ms += e * 1e3
+        return dict(allreduce_exposed_ms=ms / n, allreduce_bytes=self.bytes // n, buckets=len(self.launched) // n, bucket_dtype=self.bucket_dtype,
+                    overlap=self.overlap, native_avg=self.native_avg)
+
+    def _drain(self):
         for work, flat, wire in self.pending:
             work.wait()                      # makes the current stream wait for the collective
             if wire is not flat:

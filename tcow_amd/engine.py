@@ -464,8 +464,11 @@ def run_backward(module, sv, params, d_mask, d_flags):
             for t in (d_mask, d_flags):
                 if t is not None and t.numel():
                     amax = torch.maximum(amax, t.detach().abs().amax().to(f32))
-            if getattr(module, 'ls_log2', None) is None or module.ls_log2.device != dev:
-                module.ls_log2 = torch.full((), -2.0, dtype=f32, device=dev)
+            if not module.__dict__.get('_optim_attached') and not module.__dict__.get('_warned_ls'):
+                import warnings
+                module.__dict__['_warned_ls'] = True
+                warnings.warn("precision='fp16' with the dynamic loss scale but no FusedAdamWClip(..., module=net) attached: nothing lowers the scale "
+                              "after an overflow or skips the poisoned step -- pass module= to the optimizer or set net.seeker.loss_scale to a number")
             gscale = torch.exp2(torch.floor(module.ls_log2 - torch.log2(amax.clamp_min(1e-37)))).clamp(2.0 ** -20, 2.0 ** 60)     # no host sync
         elif float(ls) != 1.0:
             gscale = torch.tensor(float(ls), dtype=f32, device=dev)
@@ -593,12 +596,13 @@ def run_backward(module, sv, params, d_mask, d_flags):
     ops.gemm_nt(gmode, dPm, Wt(params[nb + 2]), dFeat)
     if module.flag_channels > 0 and have_flags:
         # flags head adjoint (F x D, once per step; only the plugin path ever asks for it, pipeline.py:238)
-        df = d_flags.to(f32).reshape(B * T, -1)
+        df = d_flags.to(f32).reshape(B * T, -1).contiguous()
         meanf = sv['feat32'].reshape(B * T, S, D)[:, 1:, :].float().mean(dim=1)
-        grads[nb + 4].copy_(df.t() @ meanf)
+        dmean = torch.empty(B * T, D, dtype=f32, device=dev)
+        ops.sgemm_batched([(df.t(), meanf, grads[nb + 4])])                       # dWf = df^T mean(features)   (library kernel: no vendor BLAS on the path)
+        ops.sgemm_batched([(df, params[nb + 4].detach(), dmean)])
         grads[nb + 5].copy_(df.sum(0))
-        dmean = (df @ params[nb + 4].detach()) / float(S - 1)
-        dFeat.reshape(B * T, S, D)[:, 1:, :] += dmean[:, None, :]
+        dFeat.reshape(B * T, S, D)[:, 1:, :] += (dmean / float(S - 1))[:, None, :]
     # (without a flags gradient flag_post_linear.* keep grad None, like the reference where pipeline.py:157 drops them)
     if module.norm_embeddings:
         dX = E(M, D, dtype=f32)

@@ -17,7 +17,10 @@ re-casts all GEMM operands in ONE launch) are an optimisation on top of that, no
 
 One extension over torch's pair: a step whose total gradient norm is NaN / infinite is SKIPPED (parameters and moments untouched) instead
 of poisoning the weights -- the overflow guard of the binary16 mode (precision='fp16'), whose loss-scale exponent is lowered in the same
-step (device side, no synchronisation)."""
+step (device side, no synchronisation).  Skips are COUNTED on the device in every precision (`skipped_steps`, a device scalar; read it
+-- one sync -- whenever you log: a NaN gradient in bf16 / fp32 training shows up there instead of silently freezing the weights), and the
+update kernel subtracts them from the step number of its bias correction, so moments and correction stay in step; `state_dict()`
+stores the applied-update count, i.e. what torch.optim.AdamW would have counted behind a GradScaler."""
 import numpy as np
 import torch
 
@@ -37,12 +40,13 @@ class FusedAdamWClip(torch.optim.Optimizer):
         self.scratch = None
         self.on_step = []          # callables run after every step
         self._tracker = None
-        self.skipped_steps = None      # precision='fp16': how many steps the overflow guard has skipped (device int32 tensor once a step has run)
+        self._skip_carry = 0.0         # skipped steps of earlier pointer tables (the device counter lives in the scratch buffer)
         if module is not None:     # a Seeker / QueryMaskTracker: batch re-cast of its GEMM operand copies right after the update
             tracker = getattr(module, 'seeker', module)
             self._tracker = tracker
             if hasattr(tracker, 'invalidate_weight_cache'):
                 self.on_step.append(tracker.invalidate_weight_cache)
+            tracker.__dict__['_optim_attached'] = True      # (engine.run_backward warns when precision='fp16' trains without one: its loss scale could never recover)
         assert L.lib().tcow_adamw_chunk_bytes() == 40
 
     @property
@@ -77,8 +81,11 @@ class FusedAdamWClip(torch.optim.Optimizer):
             n = p.numel()
             for off in range(0, n, CHUNK):
                 rows.append((p.data_ptr() + 4 * off, g.data_ptr() + 4 * off, m.data_ptr() + 4 * off, v.data_ptr() + 4 * off, min(CHUNK, n - off)))
+        if self.scratch is not None:
+            self._skip_carry += float(self.scratch[-1])      # (rebuilds are rare: first step, re-allocated gradients, load_state_dict)
         self._table = torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(live[0].device)
-        self.scratch = torch.empty(len(rows) + 2, dtype=torch.float32, device=live[0].device)
+        self.scratch = torch.zeros(len(rows) + 3, dtype=torch.float32, device=live[0].device)      # [chunk partials | coef, norm, skipped]
+        self.scratch[-1] = self._skip_carry
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -102,9 +109,8 @@ class FusedAdamWClip(torch.optim.Optimizer):
         # (clip coefficient -1); lower the module's loss-scale exponent by 4, otherwise let it creep back towards -2.  All on the device.
         ls = getattr(self._tracker, 'ls_log2', None) if self._tracker is not None else None
         if ls is not None and ls.device == self.scratch.device:
-            ok = torch.isfinite(self.scratch[-1])
+            ok = self.scratch[-3] >= 0                       # clip coefficient -1 = skipped
             ls.copy_(torch.minimum(ls + torch.where(ok, 1.0 / 256.0, -4.0), torch.full_like(ls, -2.0)))
-            self.skipped_steps = (~ok).to(torch.int32) + (self.skipped_steps if self.skipped_steps is not None else 0)     # device counter, no sync
         torch._foreach_add_([self.state[p]['step'] for p in live], 1)   # CPU scalars, like torch.optim.AdamW keeps them (one call, not 247)
         torch.autograd.graph.increment_version(live)   # the kernels wrote through raw pointers: make the update visible to version checks
         for cb in self.on_step:
@@ -113,8 +119,25 @@ class FusedAdamWClip(torch.optim.Optimizer):
 
     def grad_norm(self):
         """Total gradient norm of the last step (device tensor, no sync)."""
-        return self.scratch[-1]
+        return self.scratch[-2]
+
+    @property
+    def skipped_steps(self):
+        """Steps skipped so far because their gradient norm was not finite (device f32 scalar, no sync; None before the first step)."""
+        return None if self.scratch is None else self.scratch[-1]
+
+    def state_dict(self):
+        """torch.optim.AdamW's layout; 'step' = updates actually applied (calls minus skipped steps; one device read here, none per step)."""
+        sd = super().state_dict()
+        skipped = float(self.scratch[-1]) if self.scratch is not None else 0.0
+        if skipped:
+            for st in sd['state'].values():
+                if 'step' in st:
+                    st['step'] = st['step'] - skipped
+        return sd
 
     def load_state_dict(self, sd):
         super().load_state_dict(sd)
         self._key = None
+        self._skip_carry = 0.0            # the loaded 'step' already counts applied updates only
+        self.scratch = None

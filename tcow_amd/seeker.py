@@ -184,6 +184,10 @@ class QueryMaskTracker(nn.Module):
             load_pretrained_vit(self, self.pretrained_path, logger)
         self._wcache = {}
         self._gbufs = {}
+        # dynamic loss scale of precision='fp16' (engine.run_backward): log2 of the target magnitude of the largest gradient seed element.  A
+        # NON-persistent buffer: it follows .to() / DataParallel replication like any buffer, stays out of the 251-key state dict, and
+        # save_tcow_checkpoint / resume_tcow_checkpoint carry it beside the optimizer state.
+        self.register_buffer('ls_log2', torch.full((), -2.0, dtype=torch.float32), persistent=False)
         # persistent_grads=True: the backward writes parameter gradients into flat per-bucket buffers that live across steps and
         # hands them to p.grad directly (same pointers every step: no autograd copies, the fused optimizer's pointer table stays
         # valid).  Gradients are then OVERWRITTEN, not accumulated, by each backward -- use only with one backward per step.
@@ -197,7 +201,9 @@ class QueryMaskTracker(nn.Module):
             raise ValueError("precision must be 'bf16', 'fp16', 'fp32' or 'bf16x3'")
         self.precision = precision
         self.mode = ops.BF16 if precision == 'bf16' else ops.FP16 if precision == 'fp16' else ops.F32
-        self.ls_log2 = None                                                     # device scalar of the dynamic loss scale (created by the first fp16 backward)
+        if 'ls_log2' in self._buffers:
+            with torch.no_grad():
+                self.ls_log2.fill_(-2.0)
         self.loss_scale = 'dynamic'                                             # fp16 only: power-of-two factor on the backward's gradients (engine.run_backward); a number = static
         self.gemm_mode = ops.F32X3 if precision == 'bf16x3' else self.mode     # GEMM arithmetic; storage / every other kernel follow `mode`
         self._wcache = {}
@@ -283,6 +289,7 @@ class Seeker(nn.Module):
     def __init__(self, logger, **kwargs):
         super().__init__()
         self.logger = logger
+        self.seeker_args = {k: v for k, v in kwargs.items() if k != 'precision'}     # what train.py:186-205 stores as checkpoint['seeker_args']
         self.seeker = QueryMaskTracker(logger, **kwargs)
 
     def forward(self, *args):

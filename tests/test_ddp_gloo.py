@@ -41,6 +41,8 @@ def _worker(rank, world, port, q):
     ok = ok and torch.equal(gathered[0], gathered[1])
     clip_a = synth.make_clip(1, 2, 16, 16, seed=ddp.shard_seed(900, rank))['rgb']
     ok = ok and sync.launched == ['head', 1, 0, 'embed'] and sync.bytes == (7 + 2000 + 33) * 4
+    st = sync.stats()                              # the fields bench.py puts into its N > 1 line
+    ok = ok and st['buckets'] == 4 and st['allreduce_bytes'] == (7 + 2000 + 33) * 4 and st['allreduce_exposed_ms'] >= 0.0 and st['bucket_dtype'] == 'f32' 
     q.put((rank, bool(ok), float(clip_a.sum())))
     dist.destroy_process_group()
 
