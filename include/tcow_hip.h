@@ -208,6 +208,10 @@ int tcow_embed_fwd(void* stream, int B, int T, int S, int D, float* x, const flo
 int tcow_embed_bwd(void* stream, int B, int T, int S, int D, const float* g, float* dpos, float* dtime,
                    int accumulate);
 int tcow_cls_merge(void* stream, int B, int T, int S, int D, float* x, int mode, int backward);
+/* the adjoint (backward != 0) that also refreshes the `dtype` operand copy of the gradient for the slot-0 rows it rewrites:
+ * cast_out[row] = dtype(cast_scale[row] * x[row]) (scale NULL = 1) -- the copy the LayerNorm backward wrote for all rows (dx_cast). */
+int tcow_cls_merge_bwd_cast(void* stream, int dtype, int B, int T, int S, int D, float* x, int mode, void* cast_out, long ldc,
+                            const float* cast_scale);
 
 /* ------------------------------------------------------------------------------------------- mask head
  * tcow_unpatchify_pool_fwd: head output pm [B*T*S, C*P*P] (`dtype`, (c,py,px) order, mask_tracker.py:113-115)

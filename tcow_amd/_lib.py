@@ -87,6 +87,7 @@ SIGNATURES = {
     'tcow_embed_fwd': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'tcow_embed_bwd': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _i]),
     'tcow_cls_merge': (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i]),
+    'tcow_cls_merge_bwd_cast': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _l, _vp]),
     'tcow_unpatchify_pool_fwd': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'tcow_unpatchify_pool_bwd': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'tcow_upsample_fwd': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),

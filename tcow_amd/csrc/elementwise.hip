@@ -105,7 +105,11 @@ __global__ __launch_bounds__(256) void embed_bwd_time_kernel(int B, int T_, int 
 // clip: frame 0's row for causal_attention == 1, the mean over frames for 0 (vit.py:189-198,215).  Write that row
 // back to every frame's slot 0.  mode: 1 -> frame 0, 0 -> mean.  Backward: sum of the replicas' gradients goes to
 // frame 0 (mode 1, others get zero) or is spread as mean (mode 0).
-__global__ void cls_merge_kernel(int B, int T_, int S, int D, float* __restrict__ x, int mode, int backward) {
+// CT* cast_out (backward only, may be NULL): the 16-bit operand copy of the gradient (cast_scale[row] * x[row], what the LayerNorm backward
+// in front of this call wrote for every row) is refreshed for the slot-0 rows this kernel changes, so no separate cast pass is needed.
+template <typename CT>
+__global__ void cls_merge_kernel(int B, int T_, int S, int D, float* __restrict__ x, int mode, int backward, CT* __restrict__ cast_out, long ldc,
+                                 const float* __restrict__ cast_scale) {
     const int d4 = D / 4;
     const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
     if (i >= (long)B * d4) return;
@@ -131,6 +135,14 @@ __global__ void cls_merge_kernel(int B, int T_, int S, int D, float* __restrict_
         } else {
             const float inv = 1.0f / (float)T_; a.x *= inv; a.y *= inv; a.z *= inv; a.w *= inv;
             for (int t = 0; t < T_; ++t) st4(base + t * fs, a);
+        }
+        if (cast_out) {
+            for (int t = 0; t < T_; ++t) {
+                const long row = ((long)b * T_ + t) * S;
+                const float cs = cast_scale ? cast_scale[row] : 1.0f;
+                const float4 v = (mode == 1 && t > 0) ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(a.x * cs, a.y * cs, a.z * cs, a.w * cs);
+                st4(cast_out + row * ldc + c, v);
+            }
         }
     }
 }
@@ -452,7 +464,17 @@ int tcow_embed_bwd(void* stream, int B, int T_, int S, int D, const float* g, fl
 
 int tcow_cls_merge(void* stream, int B, int T_, int S, int D, float* x, int mode, int backward) {
     TCOW_CHECK_ARG(B > 0 && T_ > 0 && S > 1 && D % 4 == 0 && x && (mode == 0 || mode == 1), "tcow_cls_merge: bad arguments");
-    hipLaunchKernelGGL(cls_merge_kernel, dim3(cdiv((long)B * D / 4, 256)), dim3(256), 0, (hipStream_t)stream, B, T_, S, D, x, mode, backward);
+    hipLaunchKernelGGL(cls_merge_kernel<float>, dim3(cdiv((long)B * D / 4, 256)), dim3(256), 0, (hipStream_t)stream, B, T_, S, D, x, mode, backward, (float*)nullptr, 0L, (const float*)nullptr);
+    TCOW_CHECK_LAUNCH();
+    return TCOW_OK;
+}
+
+int tcow_cls_merge_bwd_cast(void* stream, int dtype, int B, int T_, int S, int D, float* x, int mode, void* cast_out, long ldc, const float* cast_scale) {
+    TCOW_CHECK_ARG(B > 0 && T_ > 0 && S > 1 && D % 4 == 0 && x && (mode == 0 || mode == 1) && cast_out && ldc % 4 == 0, "tcow_cls_merge_bwd_cast: bad arguments");
+    const dim3 grid(cdiv((long)B * D / 4, 256));
+    if (dtype == TCOW_BF16) hipLaunchKernelGGL(cls_merge_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, B, T_, S, D, x, mode, 1, (bf16_t*)cast_out, ldc, cast_scale);
+    else if (dtype == TCOW_F32) hipLaunchKernelGGL(cls_merge_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, B, T_, S, D, x, mode, 1, (float*)cast_out, ldc, cast_scale);
+    else { tcow_set_error("tcow_cls_merge_bwd_cast: unknown dtype %d", dtype); return TCOW_ERR_INVALID_ARG; }
     TCOW_CHECK_LAUNCH();
     return TCOW_OK;
 }

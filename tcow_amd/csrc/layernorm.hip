@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int D, const T* _
     // CSUM: a third column sum rides along, sum_rows sumscale[row] * dx[row] -- the bias gradient of the Linear layer BELOW this norm when
     // that layer's output was row-masked (temporal_fc: vit.py:174-176 with the cls rows excluded), in f32 instead of from the bf16 operand
     constexpr int NP = CSUM ? 3 : 2;
-    extern __shared__ __attribute__((aligned(16))) float red[];  // [4][NP*D]
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [4][D]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = D >> 2;
     float4 gsum[NV], bsum[NV], gam[NV], csum[CSUM ? NV : 1];
@@ -154,18 +154,19 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int D, const T* _
         }
     }
     if (!part) return;
+    // fold the four waves' column partials through ONE [4][D] LDS image, one quantity after the other (12 KiB at D = 768 instead of 24 / 36:
+    // the image is held for the whole kernel, and this streaming kernel wants its 6 workgroups per CU)
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c = lane + i * 64;
-        if (c < nv) {
-            *reinterpret_cast<float4*>(red + (size_t)wave * NP * D + c * 4) = gsum[i];
-            *reinterpret_cast<float4*>(red + (size_t)wave * NP * D + D + c * 4) = bsum[i];
-            if (CSUM) *reinterpret_cast<float4*>(red + (size_t)wave * NP * D + 2 * D + c * 4) = csum[i];
+    for (int qn = 0; qn < NP; ++qn) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + i * 64;
+            if (c < nv) *reinterpret_cast<float4*>(red + (size_t)wave * D + c * 4) = qn == 0 ? gsum[i] : (qn == 1 ? bsum[i] : csum[CSUM ? i : 0]);
         }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < NP * D; i += 256) {
-        part[(size_t)blockIdx.x * NP * D + i] = (red[i] + red[NP * D + i]) + (red[2 * NP * D + i] + red[3 * NP * D + i]);
+        __syncthreads();
+        for (int i = threadIdx.x; i < D; i += 256)
+            part[((size_t)blockIdx.x * NP + qn) * D + i] = (red[i] + red[D + i]) + (red[2 * D + i] + red[3 * D + i]);
+        __syncthreads();
     }
 }
 
@@ -214,7 +215,7 @@ int tcow_layernorm_bwd(void* stream, int dtype, int rows, int D, const void* dy,
     int blocks = cdiv(rows, 4); if (blocks > kLnBwdBlocks) blocks = kLnBwdBlocks;
     float* part = want_param_grads ? (float*)workspace : nullptr;
     const bool csum = colsum_out != nullptr;
-    const size_t lds = want_param_grads ? (size_t)4 * (csum ? 3 : 2) * D * 4 : 0;
+    const size_t lds = want_param_grads ? (size_t)4 * D * 4 : 0;
     if (dtype != TCOW_BF16 && dtype != TCOW_F32) { tcow_set_error("tcow_layernorm_bwd: unknown dtype %d", dtype); return TCOW_ERR_INVALID_ARG; }
     const int nvl = (D / 4 + 63) / 64;
 #define LN_BWD(NVV)                                                                                                                               \

@@ -639,13 +639,13 @@ def run_backward(module, sv, params, d_mask, d_flags):
         ops.gemm_nt(gmode, dpre, Wt(q[ix['fc1']]), dWn)
         linear_bwd(o + ix['fc1'], dpre, st['Wn'], defer=True)
         dR2 = E(M, D, dtype=f32)
-        ops.layernorm_bwd(mode, dWn, st['R2'], st['mu2'], st['rs2'], q[ix['n2']].detach(), dR3, dR2, galloc(o + ix['n2']), galloc(o + ix['n2'] + 1))
+        G2 = E(M, D)                           # operand copy of dR2 * row scale: written by the LayerNorm backward, its slot-0 rows redone by the cls adjoint
+        ops.layernorm_bwd(mode, dWn, st['R2'], st['mu2'], st['rs2'], q[ix['n2']].detach(), dR3, dR2, galloc(o + ix['n2']), galloc(o + ix['n2'] + 1),
+                          dx_cast=G2, cast_scale=st['rs_s'])
         del G3, dpre, dWn
         # ---- spatial / joint attention
         if use_cls and not joint:
-            ops.cls_merge(dR2, B, T, S, 1 if ca == 1 else 0, backward=True)
-        G2 = E(M, D)
-        ops.scale_cast(mode, dR2, st['rs_s'], G2)
+            ops.cls_merge(dR2, B, T, S, 1 if ca == 1 else 0, backward=True, cast_mode=mode, cast_out=G2, cast_scale=st['rs_s'])
         dO2 = E(M, D)
         ops.gemm_nt(gmode, G2, Wt(q[ix['proj']]), dO2)
         linear_bwd(o + ix['proj'], G2, st['O_s'], defer=True)

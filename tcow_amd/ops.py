@@ -193,7 +193,12 @@ def embed_bwd(g, B, T, S, dpos, dtime, accumulate=False):
     L.check(L.lib().tcow_embed_bwd(_stream(), B, T, S, g.shape[1], g.data_ptr(), dpos.data_ptr(), dtime.data_ptr(), int(accumulate)), 'tcow_embed_bwd')
 
 
-def cls_merge(x, B, T, S, mode, backward=False):
+def cls_merge(x, B, T, S, mode, backward=False, cast_mode=None, cast_out=None, cast_scale=None):
+    """cast_out (backward only): the 16-bit / f32 operand copy of x to refresh for the rewritten slot-0 rows (tcow_cls_merge_bwd_cast)."""
+    if cast_out is not None:
+        lib, dm = _sel(cast_mode)
+        L.check(lib.tcow_cls_merge_bwd_cast(_stream(), dm, B, T, S, x.shape[1], x.data_ptr(), mode, cast_out.data_ptr(), cast_out.stride(0), _p(cast_scale)), 'tcow_cls_merge_bwd_cast', lib)
+        return x
     L.check(L.lib().tcow_cls_merge(_stream(), B, T, S, x.shape[1], x.data_ptr(), mode, int(backward)), 'tcow_cls_merge')
     return x
 

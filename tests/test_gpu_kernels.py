@@ -348,6 +348,15 @@ def test_cls_merge_and_adjoint(ops, cuda):
         gy = torch.randn_like(x); gx = gy.clone(); ops.cls_merge(gx, B, T, S, mode, backward=True)
         # adjoint identity <merge(x), gy> == <x, merge^T(gy)>
         assert abs(float((y.double() * gy.double()).sum() - (x.double() * gx.double()).sum())) < 1e-3
+        # the adjoint that also refreshes the operand copy of the rows it rewrites == adjoint followed by a full scale + cast
+        sc = torch.rand(B * T * S, device=cuda) + 0.5
+        for cmode, dt in ((ops.BF16, torch.bfloat16), (ops.FP16, torch.float16), (ops.F32, torch.float32)):
+            for scale in (sc, None):
+                g2 = gy.clone(); cast = torch.empty(B * T * S, D, device=cuda, dtype=dt); want_c = torch.empty_like(cast)
+                ops.scale_cast(cmode, g2, scale, cast)                               # what the LayerNorm backward leaves: the copy of the un-merged gradient
+                ops.cls_merge(g2, B, T, S, mode, backward=True, cast_mode=cmode, cast_out=cast, cast_scale=scale)
+                ops.scale_cast(cmode, gx, scale, want_c)
+                assert torch.equal(g2, gx) and torch.equal(cast, want_c)
 
 
 @pytest.mark.parametrize('st,bilinear', [(4, True), (4, False), (2, True), (1, False)])
