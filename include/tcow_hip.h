@@ -203,6 +203,14 @@ int tcow_im2col_channels(void* stream, int dtype, int B, int T, int H, int W, in
  * elem_bytes = 1 (uint8 segmentation / masks) or 4 (f32 frames); index tables are device int32 arrays with in-range entries. */
 int tcow_gather_frames(void* stream, int elem_bytes, int C, int Tv, int H, int W, int Tc, int h, int w, const void* src,
                        const int* frame_idx, const int* src_y, const int* src_x, void* out);
+/* tcow_resize_aa: the float modalities of the same pipeline (rgb / depth / coordinates: augs.py:40-43,199-201 -- torchvision Resize(BILINEAR,
+ *   antialias=True) == torch.nn.functional.interpolate(mode='bilinear', antialias=True, align_corners=False) on tensors):
+ *   out[c,t,Y,X] = sum_j wy[Y][j] * sum_i wx[X][i] * src[c, frame_idx[t], ys[ymin[Y]+j], xs[xmin[X]+i]].  ys [hc] / xs [wc] = source row /
+ *   column of each row / column of the cropped (and flipped) image; (ymin, ysize, wy [oh, ky]) and (xmin, xsize, wx [ow, kx]) = first tap,
+ *   tap count and normalised triangle-filter weights per output row / column (tcow_amd/augs.py::aa_tables restates ATen's tables). */
+int tcow_resize_aa(void* stream, int C, int Tv, int H, int W, int Tc, int hc, int wc, int oh, int ow, const float* src, const int* frame_idx,
+                   const int* ys, const int* xs, const int* ymin, const int* ysize, const float* wy, int ky, const int* xmin, const int* xsize,
+                   const float* wx, int kx, float* out);
 int tcow_embed_fwd(void* stream, int B, int T, int S, int D, float* x, const float* cls, const float* pos,
                    const float* time_embed);
 int tcow_embed_bwd(void* stream, int B, int T, int S, int D, const float* g, float* dpos, float* dtime,

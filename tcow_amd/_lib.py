@@ -83,6 +83,7 @@ SIGNATURES = {
     'tcow_attn_spatial_bwd': (_i, [_vp, _ash, _vp, _vp, _vp, _vp, _vp, _vp, _l]),
     'tcow_im2col': (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     'tcow_gather_frames': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    'tcow_resize_aa': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp]),
     'tcow_im2col_channels': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     'tcow_embed_fwd': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'tcow_embed_bwd': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _i]),

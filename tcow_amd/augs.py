@@ -1,68 +1,87 @@
-"""Index half of the reference's clip augmentation pipeline (data/augs.py:50-210, data/data_kubric.py:341-434):
-temporal sub-sampling (palindrome / reverse / stride factor / offset), centre crop, horizontal flip, random crop and NEAREST resize.
-All of it is integer index arithmetic, so it composes into three small index tables (source frame per clip frame, source row per output
-row, source column per output column) and ONE gather pass on the GPU (`tcow_gather_frames`) for every modality at once, bit-exact --
-the reference runs slicing + torch.flip + slicing + torchvision Resize as four full-tensor passes per modality on the CPU loader
-workers.  Applies to the integer / mask modalities ('segm', 'div_segm', query / target masks: augs.py:196-198) at any size and to rgb
-whenever no smooth resize is involved (same size after cropping, i.e. the test-time path of a pre-sized dataset).
+"""The reference's clip augmentation pipeline on the GPU (data/augs.py:50-210, data/data_kubric.py:341-434):
+temporal sub-sampling (palindrome / reverse / stride factor / offset), centre crop, horizontal flip, random crop and the final resize.
 
-Out of scope: the photometric half (ColorJitter / GaussianBlur / Grayscale, augs.py:175-181) and the antialiased bilinear resize of rgb
-(augs.py:199-201) are torchvision operators; torchvision is not installed here, so no golden vectors can pin them ("parity unpinned").
+The index part is integer arithmetic and composes into three small tables (source frame per clip frame, source row / column per row /
+column of the cropped image); with them
+  * integer / mask modalities ('segm', 'div_segm', query / target masks: augs.py:196-198, NEAREST) are ONE gather pass
+    (`tcow_gather_frames`), bit-exact;
+  * rgb / depth / coordinate modalities (augs.py:199-201: BILINEAR with antialias=True) are ONE pass of `tcow_resize_aa`: the separable
+    triangle filter of torch.nn.functional.interpolate(mode='bilinear', antialias=True, align_corners=False) -- the ATen operator
+    torchvision's tensor Resize dispatches to -- with its index / weight tables computed on the host (`aa_tables`, a restatement of
+    ATen's _compute_indices_weights_aa in float32) and the crop / flip / frame selection folded into the source addressing.
+The reference runs slicing + torch.flip + slicing + torchvision Resize as four full-tensor passes per modality on the CPU loader workers.
+
+Out of scope: the photometric operators (ColorJitter / GaussianBlur / Grayscale, augs.py:33-35,175-181) are torchvision's own random
+transforms (their parameters come from torchvision's internal torch-RNG draws); torchvision is not installed here, so no vector of the
+reference's can pin them.  `apply_augs` raises when a parameter set asks for one.
 
 `sample_augs_params` draws from numpy's GLOBAL generator in exactly the reference's order, so `np.random.seed(s)` reproduces the
 reference's parameters draw for draw (pinned by tests/golden/g13_augs.npz).
 """
 import numpy as np
 
+# The reference's draw sequence (data/augs.py:66-133) as DATA: (name, kind, argument, condition on the values drawn so far).
+#   'lt'   value = rand() < arg          'unit' value = rand() * 0.2 + arg          'offset' value = randint(0, avail - clip + 1)
+# Conditions see the dict of earlier draws; a draw whose condition is false is NOT made (the generator does not advance) and takes `default`.
+_TEMPORAL_DRAWS = [
+    ('palindrome', 'lt', 'palindrome_prob', None, False),
+    ('reverse_p', 'lt', 0.35, lambda d: d['palindrome'], False),
+    ('stride2', 'lt', 0.35, lambda d: d['palindrome'], False),
+    ('reverse_n', 'lt', 'reverse_prob', lambda d: not d['palindrome'], False),
+]
+_SPATIAL_DRAWS = [
+    ('color_jitter', 'lt', 0.9, None, False),
+    ('rgb_blur', 'lt', 0.2, None, False),
+    ('rgb_grayscale', 'lt', 0.05, None, False),
+    ('horz_flip', 'lt', 0.5, lambda d: d['augs_2d'], False),
+    ('crop_y1', 'unit', 0.0, lambda d: d['augs_2d'], -1.0),
+    ('crop_y2', 'unit', 0.8, lambda d: d['augs_2d'], -1.0),
+    ('crop_x1', 'unit', 0.0, lambda d: d['augs_2d'], -1.0),
+    ('crop_x2', 'unit', 0.8, lambda d: d['augs_2d'], -1.0),
+]
+
+
+def _draw(table, d, probs):
+    for name, kind, arg, cond, default in table:
+        if cond is not None and not cond(d):
+            d[name] = default
+            continue
+        u = np.random.rand()
+        a = probs[arg] if isinstance(arg, str) else arg
+        d[name] = bool(u < a) if kind == 'lt' else u * 0.2 + a
+
 
 def sample_augs_params(num_frames_load, num_frames_clip, frame_stride, do_random_augs, augs_2d, reverse_prob, palindrome_prob):
-    """data/augs.py:50-135."""
-    palindrome = False
-    reverse = False
-    frame_stride_factor = 1
+    """data/augs.py:50-135: same keys, same values, same consumption of numpy's global generator."""
+    d = dict(augs_2d=bool(augs_2d), palindrome=False, reverse_p=False, stride2=False, reverse_n=False)
+    probs = dict(palindrome_prob=palindrome_prob, reverse_prob=reverse_prob)
+    clip = list(range(num_frames_clip))
     offset = (num_frames_load - num_frames_clip) // 2
-    frame_inds_load = list(range(0, num_frames_load * frame_stride, frame_stride))
-    frame_inds_clip = list(range(0, num_frames_clip))
     if do_random_augs:
-        palindrome = (np.random.rand() < palindrome_prob)
-        if palindrome:
-            reverse = (np.random.rand() < 0.35)
-            frame_stride_factor = (2 if np.random.rand() < 0.35 else 1)
-        else:
-            reverse = (np.random.rand() < reverse_prob)
-            frame_stride_factor = 1
-        if palindrome:
-            frame_inds_clip = frame_inds_clip + frame_inds_clip[::-1][1:]
-        if reverse:
-            frame_inds_clip = frame_inds_clip[::-1]
-        if frame_stride_factor > 1:
-            frame_inds_clip = frame_inds_clip[::frame_stride_factor]
-        avail = len(frame_inds_clip)
-        assert avail >= num_frames_clip
-        offset = np.random.randint(0, avail - num_frames_clip + 1)
-        frame_inds_clip = frame_inds_clip[offset:offset + num_frames_clip]
-    p = dict(palindrome=palindrome, reverse=reverse, frame_stride_factor=frame_stride_factor, offset=offset,
-             frame_inds_load=np.array(frame_inds_load), frame_inds_clip=np.array(frame_inds_clip))
-    color_jitter = rgb_blur = rgb_grayscale = horz_flip = False
-    crop_rect = -np.ones(4)
-    if do_random_augs:
-        color_jitter = (np.random.rand() < 0.9)
-        rgb_blur = (np.random.rand() < 0.2)
-        rgb_grayscale = (np.random.rand() < 0.05)
-        if augs_2d:
-            horz_flip = (np.random.rand() < 0.5)
-            y1 = np.random.rand() * 0.2; y2 = np.random.rand() * 0.2 + 0.8
-            x1 = np.random.rand() * 0.2; x2 = np.random.rand() * 0.2 + 0.8
-            crop_rect = np.array([y1, y2, x1, x2])
-    p.update(color_jitter=color_jitter, rgb_blur=rgb_blur, rgb_grayscale=rgb_grayscale, horz_flip=horz_flip, crop_rect=crop_rect)
-    return p
+        _draw(_TEMPORAL_DRAWS, d, probs)
+        if d['palindrome']:
+            clip = clip + clip[::-1][1:]
+        if d['reverse_p'] or d['reverse_n']:
+            clip = clip[::-1]
+        if d['stride2']:
+            clip = clip[::2]
+        assert len(clip) >= num_frames_clip
+        offset = np.random.randint(0, len(clip) - num_frames_clip + 1)
+        clip = clip[offset:offset + num_frames_clip]
+        _draw(_SPATIAL_DRAWS, d, probs)
+    else:
+        for name, _, _, _, default in _SPATIAL_DRAWS:
+            d[name] = default
+    return dict(palindrome=d['palindrome'], reverse=bool(d['reverse_p'] or d['reverse_n']), frame_stride_factor=2 if d['stride2'] else 1, offset=offset,
+                frame_inds_load=np.arange(0, num_frames_load * frame_stride, frame_stride), frame_inds_clip=np.array(clip),
+                color_jitter=d['color_jitter'], rgb_blur=d['rgb_blur'], rgb_grayscale=d['rgb_grayscale'], horz_flip=d['horz_flip'],
+                crop_rect=np.array([d['crop_y1'], d['crop_y2'], d['crop_x1'], d['crop_x2']]) if (do_random_augs and augs_2d) else -np.ones(4))
 
 
-def index_maps(augs_params, H, W, out_h, out_w, center_crop=False, return_resized=False):
-    """Source (frame, row, column) of every output (frame, row, column) for the spatial chain of augs.py:150-203 with NEAREST resize:
-    centre crop to the output aspect ratio (torchvision CenterCrop: top = round((H - h) / 2)), horizontal flip, fractional crop rectangle
-    (int(y1 * H) : int(y2 * H) on the post-flip image), nearest resize (source = floor(dst * in / out), torch's 'nearest').
-    Returns int32 arrays (frame_idx [Tc], src_y [out_h], src_x [out_w]) (+ whether the last step changes the size)."""
+def crop_maps(augs_params, H, W, out_h, out_w, center_crop=False):
+    """Source (frame, row, column) of every (frame, row, column) of the image the final resize sees: centre crop to the output aspect
+    ratio (torchvision CenterCrop: top = round((H - h) / 2)), horizontal flip, fractional crop rectangle (int(y1 * H) : int(y2 * H) on the
+    post-flip image) -- augs.py:150-194.  Returns (frame_idx [Tc] int32, ys [h] int64, xs [w] int64)."""
     frame_idx = np.asarray(augs_params['frame_inds_clip'], dtype=np.int32)
     y0, x0, h, w = 0, 0, H, W
     if center_crop:                                                        # augs.py:163-171
@@ -82,6 +101,36 @@ def index_maps(augs_params, H, W, out_h, out_w, center_crop=False, return_resize
         y1, y2, x1, x2 = [float(v) for v in cr]
         ys = ys[int(y1 * H):int(y2 * H)]
         xs = xs[int(x1 * W):int(x2 * W)]
+    return frame_idx, ys, xs
+
+
+def aa_tables(n_in, n_out):
+    """Index / weight table of the antialiased bilinear resize along one axis: ATen's _compute_indices_weights_aa (UpSampleKernel.cpp) for
+    the triangle filter, align_corners=False, in float32.  Returns (first source index [n_out] int32, tap count [n_out] int32,
+    weights [n_out, K] float32 zero-padded, K)."""
+    f = np.float32
+    scale = f(n_in) / f(n_out)
+    support = f(scale) if scale >= 1.0 else f(1.0)
+    invscale = f(1.0) / scale if scale >= 1.0 else f(1.0)
+    K = int(np.ceil(support)) * 2 + 1
+    i = np.arange(n_out, dtype=np.float32)
+    center = scale * (i + f(0.5))
+    xmin = np.maximum((center - support + f(0.5)).astype(np.int64), 0)
+    xsize = np.minimum((center + support + f(0.5)).astype(np.int64), n_in) - xmin
+    j = np.arange(K, dtype=np.float32)[None, :]
+    arg = (j + xmin[:, None].astype(np.float32) - center[:, None] + f(0.5)) * invscale
+    w = np.maximum(f(1.0) - np.abs(arg), f(0.0)).astype(np.float32)
+    w[np.arange(K)[None, :] >= xsize[:, None]] = 0.0
+    tot = w.sum(axis=1, dtype=np.float32)
+    w = (w / tot[:, None]).astype(np.float32)
+    return xmin.astype(np.int32), xsize.astype(np.int32), np.ascontiguousarray(w), K
+
+
+def index_maps(augs_params, H, W, out_h, out_w, center_crop=False, return_resized=False):
+    """Source (frame, row, column) of every output (frame, row, column) for the spatial chain of augs.py:150-203 with NEAREST resize
+    (source = floor(dst * in / out), torch's 'nearest') on top of `crop_maps`.
+    Returns int32 arrays (frame_idx [Tc], src_y [out_h], src_x [out_w]) (+ whether the last step changes the size)."""
+    frame_idx, ys, xs = crop_maps(augs_params, H, W, out_h, out_w, center_crop)
     # nearest resize: torch.nn.functional.interpolate(mode='nearest'): src = floor(dst * (in / out)) with the scale in float32
     def nearest(n_in, n_out):
         scale = np.float32(n_in) / np.float32(n_out)
@@ -103,6 +152,42 @@ def gather_clip(frames, frame_idx, src_y, src_x):
     return ops.gather_frames(frames, fi, sy, sx)
 
 
+def resize_clip_aa(frames, frame_idx, ys, xs, out_h, out_w):
+    """frames (C, Tv, H, W) f32 CUDA tensor -> (C, Tc, out_h, out_w): frame selection + crop / flip (ys, xs = source row / column of each
+    row / column of the cropped image) + antialiased bilinear resize, one HIP pass (tcow_resize_aa)."""
+    import torch
+    from . import ops
+    dev = frames.device
+    ymin, ysz, wy, ky = aa_tables(len(ys), out_h)
+    xmin, xsz, wx, kx = aa_tables(len(xs), out_w)
+    t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt).to(dev)
+    return ops.resize_aa(frames, t(frame_idx, torch.int32), t(ys, torch.int32), t(xs, torch.int32), t(ymin, torch.int32), t(ysz, torch.int32), t(wy, torch.float32), ky,
+                         t(xmin, torch.int32), t(xsz, torch.int32), t(wx, torch.float32), kx, out_h, out_w)
+
+
+def apply_augs(modalities, augs_params, out_h, out_w, center_crop=False):
+    """augs.py:137-207: dict name -> (C, Tv, H, W) CUDA tensor (uint8 / float32); tensors with fewer than 4 dimensions pass through."""
+    if augs_params.get('color_jitter') or augs_params.get('rgb_blur') or augs_params.get('rgb_grayscale'):
+        if any('rgb' in name for name in modalities):
+            raise NotImplementedError('ColorJitter / GaussianBlur / Grayscale (augs.py:175-181) are torchvision operators: out of scope (see module docstring)')
+    out = {}
+    for name, fr in modalities.items():
+        if fr.dim() < 4:
+            out[name] = fr.clone()
+            continue
+        C, Tv, H, W = fr.shape
+        if 'segm' in name or 'mask' in name:                                # integer valued: NEAREST (augs.py:196-198)
+            fi, sy, sx = index_maps(augs_params, H, W, out_h, out_w, center_crop)
+            out[name] = gather_clip(fr.contiguous(), fi, sy, sx)
+        else:                                                               # rgb, depth, coordinates: BILINEAR, antialias=True (augs.py:199-201)
+            fi, ys, xs = crop_maps(augs_params, H, W, out_h, out_w, center_crop)
+            if len(ys) == out_h and len(xs) == out_w:
+                out[name] = gather_clip(fr.contiguous(), fi, ys.astype(np.int32), xs.astype(np.int32))      # (the filter is the identity at scale 1)
+            else:
+                out[name] = resize_clip_aa(fr.float().contiguous(), fi, ys, xs, out_h, out_w)
+    return out
+
+
 def apply_augs_index(modalities, augs_params, out_h, out_w, center_crop=False):
     """augs.py:137-207 for the modalities the index path covers (see module docstring): dict name -> (C, Tv, H, W) CUDA tensor."""
     out = {}
@@ -114,6 +199,6 @@ def apply_augs_index(modalities, augs_params, out_h, out_w, center_crop=False):
         fi, sy, sx, resized = index_maps(augs_params, H, W, out_h, out_w, center_crop, return_resized=True)
         smooth = not ('segm' in name or 'mask' in name)
         if smooth and resized:
-            raise NotImplementedError(f"'{name}' needs the antialiased bilinear resize of augs.py:199-201 (torchvision): out of scope of the index path")
+            raise NotImplementedError(f"'{name}' needs the antialiased bilinear resize of augs.py:199-201: use apply_augs")
         out[name] = gather_clip(fr.contiguous(), fi, sy, sx)
     return out

@@ -47,6 +47,31 @@ __global__ void gather_frames_kernel(int C, int Tv, int H, int W, int Tc, int h,
     }
 }
 
+// Antialiased bilinear resize of a clip with the crop / flip / frame selection folded into the source addressing (data/augs.py:150-201 for
+// the float modalities): out[c,t,Y,X] = sum_j wy[Y][j] * (sum_i wx[X][i] * src[c, frame_idx[t], ys[ymin[Y] + j], xs[xmin[X] + i]]) -- the
+// separable triangle filter of F.interpolate(mode='bilinear', antialias=True, align_corners=False), horizontal pass inside, vertical
+// outside (ATen's order), tables from tcow_amd/augs.py::aa_tables.  One thread per output pixel: 2 x 2 taps when enlarging, ~(2 s + 1)^2
+// when shrinking by s; the source rows of a pixel's taps are shared by the neighbouring threads of its row (L1 / L2 hits).
+__global__ void resize_aa_kernel(int C, int Tv, int H, int W, int Tc, int oh, int ow, const float* __restrict__ src, const int* __restrict__ frame_idx,
+                                 const int* __restrict__ ys, const int* __restrict__ xs, const int* __restrict__ ymin, const int* __restrict__ ysize,
+                                 const float* __restrict__ wy, int ky, const int* __restrict__ xmin, const int* __restrict__ xsize, const float* __restrict__ wx, int kx,
+                                 float* __restrict__ out) {
+    const long total = (long)C * Tc * oh * ow;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int X = (int)(i % ow); long r = i / ow; const int Y = (int)(r % oh); r /= oh; const int t = (int)(r % Tc); const int c = (int)(r / Tc);
+        const float* plane = src + ((size_t)c * Tv + frame_idx[t]) * H * W;
+        const int x0 = xmin[X], nx = xsize[X], y0 = ymin[Y], ny = ysize[Y];
+        float acc = 0.f;
+        for (int j = 0; j < ny; ++j) {
+            const float* row = plane + (size_t)ys[y0 + j] * W;
+            float h = 0.f;
+            for (int k = 0; k < nx; ++k) h += wx[(size_t)X * kx + k] * row[xs[x0 + k]];
+            acc += wy[(size_t)Y * ky + j] * h;
+        }
+        out[i] = acc;
+    }
+}
+
 // ------------------------------------------------------------------------------------------ embeddings
 // x[b,t,s,:] = (s == 0) ? cls + pos[0] : x + pos[s] + time[t]      (vision_tf.py:99-138; f32 residual stream)
 __global__ void embed_fwd_kernel(int B, int T_, int S, int D, float* __restrict__ x, const float* __restrict__ cls, const float* __restrict__ pos,
@@ -431,6 +456,17 @@ int tcow_gather_frames(void* stream, int elem_bytes, int C, int Tv, int H, int W
     const long total = (long)C * Tc * h * w;
     if (elem_bytes == 1) hipLaunchKernelGGL(gather_frames_kernel<uint8_t>, dim3(gs_blocks(total)), dim3(256), 0, (hipStream_t)stream, C, Tv, H, W, Tc, h, w, (const uint8_t*)src, frame_idx, src_y, src_x, (uint8_t*)out);
     else hipLaunchKernelGGL(gather_frames_kernel<uint32_t>, dim3(gs_blocks(total)), dim3(256), 0, (hipStream_t)stream, C, Tv, H, W, Tc, h, w, (const uint32_t*)src, frame_idx, src_y, src_x, (uint32_t*)out);
+    TCOW_CHECK_LAUNCH();
+    return TCOW_OK;
+}
+
+int tcow_resize_aa(void* stream, int C, int Tv, int H, int W, int Tc, int hc, int wc, int oh, int ow, const float* src, const int* frame_idx, const int* ys, const int* xs,
+                   const int* ymin, const int* ysize, const float* wy, int ky, const int* xmin, const int* xsize, const float* wx, int kx, float* out) {
+    TCOW_CHECK_ARG(C > 0 && Tv > 0 && H > 0 && W > 0 && Tc > 0 && hc > 0 && wc > 0 && oh > 0 && ow > 0 && ky > 0 && kx > 0, "tcow_resize_aa: bad geometry");
+    TCOW_CHECK_ARG(src && frame_idx && ys && xs && ymin && ysize && wy && xmin && xsize && wx && out, "tcow_resize_aa: null pointer");
+    const long total = (long)C * Tc * oh * ow;
+    hipLaunchKernelGGL(resize_aa_kernel, dim3(gs_blocks(total)), dim3(256), 0, (hipStream_t)stream, C, Tv, H, W, Tc, oh, ow, src, frame_idx, ys, xs, ymin, ysize, wy, ky, xmin, xsize,
+                       wx, kx, out);
     TCOW_CHECK_LAUNCH();
     return TCOW_OK;
 }

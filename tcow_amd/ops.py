@@ -177,6 +177,24 @@ def gather_frames(frames, frame_idx, src_y, src_x):
     return out
 
 
+def resize_aa(frames, frame_idx, ys, xs, ymin, ysize, wy, ky, xmin, xsize, wx, kx, out_h, out_w):
+    """frames (C,Tv,H,W) f32 CUDA tensor + the index / weight tables of tcow_amd.augs (int32 / f32 CUDA tensors) -> (C,Tc,out_h,out_w) f32
+    (see tcow_resize_aa)."""
+    _need_cuda(frames, frame_idx, ys, xs, ymin, ysize, wy, xmin, xsize, wx)
+    if frames.dtype != torch.float32 or not frames.is_contiguous():
+        raise L.TcowError('resize_aa: contiguous f32 frames expected')
+    for t, dt in ((frame_idx, torch.int32), (ys, torch.int32), (xs, torch.int32), (ymin, torch.int32), (ysize, torch.int32), (xmin, torch.int32), (xsize, torch.int32),
+                  (wy, torch.float32), (wx, torch.float32)):
+        if t.dtype != dt or not t.is_contiguous():
+            raise L.TcowError('resize_aa: tables must be contiguous int32 / float32 tensors')
+    C, Tv, H, W = frames.shape
+    out = torch.empty(C, frame_idx.numel(), out_h, out_w, dtype=torch.float32, device=frames.device)
+    L.check(L.lib().tcow_resize_aa(_stream(), C, Tv, H, W, frame_idx.numel(), ys.numel(), xs.numel(), out_h, out_w, frames.data_ptr(), frame_idx.data_ptr(), ys.data_ptr(),
+                                   xs.data_ptr(), ymin.data_ptr(), ysize.data_ptr(), wy.data_ptr(), int(ky), xmin.data_ptr(), xsize.data_ptr(), wx.data_ptr(), int(kx),
+                                   out.data_ptr()), 'tcow_resize_aa')
+    return out
+
+
 def im2col_channels(mode, src, P, normalise, out):
     """src (B,C,T,H,W) f32 -> out [B*T*S, C*P*P] (see tcow_im2col_channels)."""
     B, C, T, H, W = src.shape

@@ -123,9 +123,14 @@ class TcowLosses:
                 lo = logits.reshape(-1); tg = target.reshape(-1); fw = weights.reshape(-1)
             else:
                 lo = logits[which]; tg = target[which]; fw = weights[which]
-            if self.args.focal_loss:
-                raise NotImplementedError('focal_loss needs torchvision.ops.sigmoid_focal_loss (loss.py:49-51); default is BCE')
             bce = F.binary_cross_entropy_with_logits(lo, tg, reduction='none')
+            if self.args.focal_loss:
+                # loss.py:49-51: torchvision.ops.sigmoid_focal_loss(x, y, reduction='none') with its defaults alpha = 0.25, gamma = 2 -- restated
+                # from torchvision's published definition (torchvision is not installed here: no vector of the reference's pins this branch;
+                # args.py:198 defaults it to False).  Tensor path only (the fused kernels implement the BCE objective).
+                p = torch.sigmoid(lo)
+                p_t = p * tg + (1.0 - p) * (1.0 - tg)
+                bce = (0.25 * tg + 0.75 * (1.0 - tg)) * bce * (1.0 - p_t) ** 2
             custom = (bce * fw).mean()
             if self.args.aot_loss > 0.0:
                 for_aot = bce * fw if apply_weights_for_aot else bce

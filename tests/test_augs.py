@@ -6,6 +6,7 @@ import torch
 
 from conftest import load_golden
 from oracle.make_golden_r2 import augs_inputs
+from oracle.make_golden_r3 import smooth_inputs
 from tcow_amd import augs
 
 KEYS = ['palindrome', 'reverse', 'frame_stride_factor', 'offset', 'color_jitter', 'rgb_blur', 'rgb_grayscale', 'horz_flip']
@@ -77,4 +78,60 @@ def test_gather_frames_kernel_bit_exact(cuda):
     got = augs.apply_augs_index({'rgb': rgb}, p, 48, 64)['rgb']
     assert torch.equal(got, torch.flip(rgb[:, torch.arange(11, 1, -1, device=cuda)], dims=[-1]))
     with pytest.raises(NotImplementedError):
-        augs.apply_augs_index({'rgb': rgb}, p, 24, 32)                      # would need the antialiased bilinear resize (torchvision): out of scope
+        augs.apply_augs_index({'rgb': rgb}, p, 24, 32)                      # the index path alone cannot resize a float modality: apply_augs does
+
+
+def _smooth_cases(g):
+    for k in g:
+        if k.endswith('::cfg') and k.startswith('sm'):
+            yield k[:-5], [int(v) for v in g[k]]
+
+
+def _smooth_params(cfg):
+    H, W, oh, ow, cc, rnd, a2d, seed = cfg
+    np.random.seed(seed)
+    p = augs.sample_augs_params(14, 10, 1, bool(rnd), bool(a2d), 0.3, 0.4)
+    p['color_jitter'] = False; p['rgb_blur'] = False; p['rgb_grayscale'] = False       # (the fixture ran the reference with the photometric flags off)
+    return p
+
+
+def test_antialias_tables_equal_aten_interpolate():
+    """aa_tables (host side of tcow_resize_aa) against torch.nn.functional.interpolate(mode='bilinear', antialias=True) -- the operator
+    torchvision's tensor Resize dispatches to (data/augs.py:40-43) -- applied as ATen applies it (width pass, then height pass)."""
+    g = torch.Generator().manual_seed(3)
+    for (H, W, oh, ow) in [(96, 128, 60, 80), (77, 131, 40, 56), (64, 64, 120, 160), (100, 99, 33, 200), (37, 53, 37, 20), (9, 7, 2, 3)]:
+        x = torch.rand(2, 3, H, W, generator=g)
+        want = torch.nn.functional.interpolate(x, size=(oh, ow), mode='bilinear', antialias=True, align_corners=False).numpy()
+        ymin, ysz, wy, ky = augs.aa_tables(H, oh); xmin, xsz, wx, kx = augs.aa_tables(W, ow)
+        xn = x.numpy()
+        tmp = np.stack([sum(wx[X, i] * xn[..., xmin[X] + i] for i in range(xsz[X])) for X in range(ow)], axis=-1).astype(np.float32)
+        got = np.stack([sum(wy[Y, j] * tmp[..., ymin[Y] + j, :] for j in range(ysz[Y])) for Y in range(oh)], axis=-2).astype(np.float32)
+        assert np.abs(got - want).max() < 1e-6, (H, W, oh, ow)
+        assert np.allclose(wy.sum(1), 1.0, atol=1e-6) and np.allclose(wx.sum(1), 1.0, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_resize_aa_kernel_vs_reference_pipeline(cuda):
+    """G15: rgb / depth clips through the REFERENCE's apply_augs_2d_frames (frame selection, centre crop, flip, crop, antialiased bilinear
+    resize) against ONE pass of tcow_resize_aa.  Floating point: 1e-5 absolute on values in [0, 1) (depth: [0, 20) -> 2e-4), the
+    difference being the summation order of <= 7 x 7 taps."""
+    _, g = load_golden('g15_augs_smooth')
+    n = 0
+    for tag, cfg in _smooth_cases(g):
+        H, W, oh, ow, cc = cfg[:5]
+        p = _smooth_params(cfg)
+        rgb, depth = smooth_inputs(tag, H, W)
+        out = augs.apply_augs({'rgb': rgb.cuda(), 'depth': depth.cuda(), 'scalar_thing': torch.zeros(3).cuda()}, p, oh, ow, center_crop=bool(cc))
+        o = out['rgb'].cpu().numpy(); dd = out['depth'].cpu().numpy()
+        assert o.shape == (3, 10, oh, ow) and dd.shape == (1, 10, oh, ow)
+        big = H >= 400
+        assert np.abs((o[:, ::3, ::7, ::5] if big else o[:, ::3]) - g[f'{tag}::rgb_frames']).max() < 1e-5, tag
+        assert np.abs((dd[:, 4, ::7, ::5] if big else dd[:, 4]) - g[f'{tag}::depth_frame']).max() < 2e-4, tag
+        assert np.abs(o.astype(np.float64).sum(axis=(2, 3)) - g[f'{tag}::rgb_sum']).max() < 1e-5 * oh * ow
+        assert np.abs(dd.astype(np.float64).sum(axis=(2, 3)) - g[f'{tag}::depth_sum']).max() < 2e-4 * oh * ow
+        n += 1
+    assert n == 14
+    # the photometric operators are torchvision's: asking for one is an error, not a silent skip
+    p = _smooth_params([96, 128, 60, 80, 0, 1, 1, 3000]); p['color_jitter'] = True
+    with pytest.raises(NotImplementedError):
+        augs.apply_augs({'rgb': torch.rand(3, 14, 96, 128, device=cuda)}, p, 60, 80)

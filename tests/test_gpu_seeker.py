@@ -87,10 +87,11 @@ def test_gradients_vs_reference_golden(cuda, precision, tol):
             assert abs(float(named[k].grad.norm()) - n) <= tol * n + 1e-7, k
 
 
-@pytest.mark.parametrize('name', ['g3_mid_T8_96x128', 'g4_cfg2_T30_240x320'])
+@pytest.mark.parametrize('name', ['g3_mid_T8_96x128', 'g4_cfg2_T30_240x320', 'g4b_cfg2_seed2'])
 @pytest.mark.parametrize('precision', ['fp32', 'bf16', 'bf16x3', 'fp16'])
 def test_large_geometries_vs_reference_golden(cuda, name, precision):
-    """Native 12-layer ViT-B Seeker at T=8 96x128 and at the full BASELINE configs[1] size (T=30, 240x320)."""
+    """Native 12-layer ViT-B Seeker at T=8 96x128 and at the full BASELINE configs[1] size (T=30, 240x320) -- the latter with two
+    independent weight / clip seeds (g4, g4b): the binary16 mode must stay inside the north-star bound of 1e-3 on both."""
     meta, g, net, om, fl = _run(name, precision)
     pooled, fsum, fmax = summarise(om.cpu())
     d = np.abs(pooled - g['pooled']).max(); df = np.abs(fl.cpu().numpy() - g['output_flags']).max()

@@ -61,6 +61,22 @@ def test_metrics_edge_cases():
     assert abs(float(mp['mean_snitch_iou']) - 0.5) < 1e-6
 
 
+def test_focal_loss_follows_the_published_definition():
+    """loss.py:49-51 switches the per-pixel term to torchvision.ops.sigmoid_focal_loss (alpha 0.25, gamma 2); torchvision is not installed,
+    so this pins the restatement against the formula written out independently in float64 (aot_loss = 0: the term enters the loss directly)."""
+    import argparse
+    from tcow_amd.tcow_loss import TcowLosses, default_args
+    a = argparse.Namespace(**{**vars(default_args()), 'focal_loss': True, 'aot_loss': 0.0})
+    g = torch.Generator().manual_seed(1)
+    lo = torch.randn(2, 3, 4, 8, 8, generator=g) * 2; tg = (torch.rand(2, 3, 4, 8, 8, generator=g) > 0.6).float(); w = torch.rand(2, 3, 4, 8, 8, generator=g) + 0.1
+    got = TcowLosses(a, fused=False).mask_loss(lo, tg, w, 0.0, False)
+    x, y = lo.double(), tg.double()
+    p = 1.0 / (1.0 + torch.exp(-x))
+    ce = torch.clamp(x, min=0) - x * y + torch.log1p(torch.exp(-x.abs()))
+    fl = (0.25 * y + 0.75 * (1 - y)) * ce * (1 - (p * y + (1 - p) * (1 - y))) ** 2
+    assert abs(float(got) - float((fl * w.double()).mean())) < 1e-6
+
+
 def test_hard_negative_band_matches_reference_blur():
     from tcow_amd.tcow_loss import hard_negative_band
     _, g = load_golden('g5_pipeline_cfg1')
