@@ -172,6 +172,57 @@ __device__ __forceinline__ void fwd_store(const SeqDesc& sd, long base, int head
     }
 }
 
+// A 32 x 64 tile held as two TRANSPOSED accumulators (lane (row l31, hi): channels 32 dt + 8 g + 4 hi + 0..3 of register quad g) -> global
+// rows, through a wave-private 4 KiB LDS tile: after the round trip 8 lanes hold one row's 128 bytes, i.e. every store instruction
+// writes 8 whole cache lines instead of 32 rows x 8 (or 32) bytes.  The row-per-lane stores kept the memory pipe busy for thousands of
+// cycles per tile (timeline in profiles/r03_ubench_valu.txt part D) and the next loads queued behind them.  One v_permlane32_swap per
+// dword first pairs the half-waves' 8-byte pieces into 16-byte ones (guide T21); LDS chunk c of row r sits at c ^ (r & 7); inline-asm
+// LDS accesses (hipcc would wait vmcnt(0) for direct-to-LDS loads that may still be in flight elsewhere in the kernel).
+typedef uint32_t stg_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_tile_staged(uint32_t stage, int lane, float mul, const f32x16& a0, const f32x16& a1, bf16_t* __restrict__ dst, long row_stride,
+                                                  int rows_valid) {
+    const int l31 = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+        const f32x16& o = dt ? a1 : a0;
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {
+            const int g = 2 * gp;
+            uint32_t x0 = pack_bf2(o[4 * g] * mul, o[4 * g + 1] * mul), x1 = pack_bf2(o[4 * g + 2] * mul, o[4 * g + 3] * mul);
+            uint32_t y0 = pack_bf2(o[4 * g + 4] * mul, o[4 * g + 5] * mul), y1 = pack_bf2(o[4 * g + 6] * mul, o[4 * g + 7] * mul);
+            asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x0), "+v"(y0));
+            asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x1), "+v"(y1));
+            const stg_u32x4 w = {x0, x1, y0, y1};                    // channels 32 dt + 16 gp + 8 hi + 0..7 of row l31
+            const uint32_t a = stage + l31 * 128 + (((4 * dt + 2 * gp + hi) ^ (l31 & 7)) << 4);
+            asm volatile("ds_write_b128 %0, %1" :: "v"(a), "v"(w) : "memory");
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    stg_u32x4 rd[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = 8 * i + (lane >> 3);
+        const uint32_t a = stage + r * 128 + (((lane & 7) ^ (r & 7)) << 4);
+        asm volatile("ds_read_b128 %0, %1" : "=v"(rd[i]) : "v"(a) : "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rd[0]), "+v"(rd[1]), "+v"(rd[2]), "+v"(rd[3]) :: "memory");
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = 8 * i + (lane >> 3);
+        if (r < rows_valid) *reinterpret_cast<stg_u32x4*>(dst + (long)r * row_stride + (lane & 7) * 8) = rd[i];
+    }
+}
+
+// normalise + store one query tile (+ log-sum-exp) as whole rows through the wave-private LDS tile `stage`
+__device__ __forceinline__ void fwd_store_rows(const SeqDesc& sd, long base, int head, int q0, int lane, float m, float l, const f32x16& o0, const f32x16& o1,
+                                               uint32_t stage, bf16_t* __restrict__ out, float* __restrict__ lse) {
+    const int l31 = lane & 31, hi = lane >> 5;
+    l = half_sum(l);
+    store_tile_staged(stage, lane, 1.0f / l, o0, o1, out + (base + (long)q0 * sd.pos_stride) * sd.D + head * ATT_HD, sd.pos_stride * (long)sd.D, sd.L - q0);
+    const int q = q0 + l31;
+    if (lse && hi == 0 && q < sd.L) lse[(base + (long)q * sd.pos_stride) * sd.heads + head] = (m + log2f(l)) * 0.6931471805599453f;
+}
+
 // ------------------------------------------------------------------------------------------------ forward
 template <bool SHARED>
 __global__ __launch_bounds__(256, 2) void attn_fwd_mfma(SeqDesc sd, int nt, const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse) {
@@ -184,8 +235,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma(SeqDesc sd, int nt, cons
     const long base = seq_base(sd, w.item);
     const long ld3 = 3L * sd.D, pse = sd.pos_stride * ld3;
     const bf16_t* qh = qkv + base * ld3 + w.head * ATT_HD;
-    char* kt = SHARED ? smem : smem + wave * (2 * nt * TILE_B);
+    // wave-private variant (temporal): K, V AND Q tiles of the sequence in LDS.  Q used to be fetched as MFMA fragments straight from
+    // global memory -- 16 bytes per lane from 32 different rows per instruction, a quarter of every cache line per request -- and the
+    // result went out as 8-byte pieces per lane; both now move as whole 128-byte rows (direct-to-LDS loads in, store_tile_staged out
+    // through the Q tile's space once its fragments are in registers).
+    char* kt = SHARED ? smem : smem + wave * (3 * nt * TILE_B);
     char* vt = kt + nt * TILE_B;
+    char* qt_ = vt + nt * TILE_B;
     if (SHARED) {
         for (int t = wave; t < nt; t += 4) {
             load_tile(qh + sd.D, pse, 32 * t, sd.L, kt + t * TILE_B, lane);
@@ -195,18 +251,18 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma(SeqDesc sd, int nt, cons
         __syncthreads();
     } else {
         for (int t = 0; t < nt; ++t) {
+            load_tile(qh, pse, 32 * t, sd.L, qt_ + t * TILE_B, lane);
             load_tile(qh + sd.D, pse, 32 * t, sd.L, kt + t * TILE_B, lane);
             load_tile(qh + 2 * sd.D, pse, 32 * t, sd.L, vt + t * TILE_B, lane);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    const float sc = kScale * kLog2e;
     for (int qt = SHARED ? wave : 0; qt < nt; qt += SHARED ? 4 : 1) {
         const int q = 32 * qt + l31;
         const int qc = q < sd.L ? q : sd.L - 1;
         bf16x8 qf[4];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qf[ks] = frag_row_global(qh, pse, qc, ks, hi);
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = SHARED ? frag_row_global(qh, pse, qc, ks, hi) : frag_row(qt_ + qt * TILE_B, l31, ks, hi);
         f32x16 o0, o1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
@@ -214,7 +270,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma(SeqDesc sd, int nt, cons
         const long klim = (long)32 * qt + 31 + sd.diag;            // last key any query of this tile may see
         const int kt_end = klim >= (long)sd.L - 1 ? nt : (int)(klim / 32) + 1;
         for (int j = 0; j < kt_end; ++j) fwd_tile(sd, kt + j * TILE_B, vt + j * TILE_B, qf, j, qt, q, l31, hi, lane, m, l, o0, o1);
-        fwd_store(sd, base, w.head, q, hi, m, l, o0, o1, out, lse);
+        if (SHARED) fwd_store(sd, base, w.head, q, hi, m, l, o0, o1, out, lse);
+        else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            fwd_store_rows(sd, base, w.head, 32 * qt, lane, m, l, o0, o1, (uint32_t)(uintptr_t)(LDS_PTR(char))(qt_ + qt * TILE_B), out, lse);
+        }
     }
 }
 
@@ -706,49 +766,6 @@ __device__ __forceinline__ void fwd_store16(const SeqDesc& sd, long base, int he
     if (lse && hi == 0 && q < sd.L) lse[row * sd.heads + head] = (m + log2f(l)) * 0.6931471805599453f;
 }
 
-// The same through a wave-private 4 KiB LDS tile, so that the global stores are whole 128-byte rows (8 lanes x 16 bytes per row, 8 rows
-// per instruction) instead of 32 rows x 32 bytes per instruction: in the persistent kernel the row-per-lane stores of all ten waves kept
-// the memory pipe busy for ~5000 cycles after every pair, and the next pair's loads queued behind them.  `stage` is the wave's own V tile
-// of the image that has just been used up (nobody else touches it before this wave's next V wave-load); LDS accesses in inline asm (see
-// res_step2), chunk c of row r at c ^ (r & 7).
-__device__ __forceinline__ void fwd_store_rows(const SeqDesc& sd, long base, int head, int q0, int lane, float m, float l, const f32x16& o0, const f32x16& o1,
-                                               uint32_t stage, bf16_t* __restrict__ out, float* __restrict__ lse) {
-    const int l31 = lane & 31, hi = lane >> 5;
-    l = half_sum(l);
-    const float inv = 1.0f / l;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt) {
-        const f32x16& o = dt ? o1 : o0;
-#pragma unroll
-        for (int gp = 0; gp < 2; ++gp) {
-            const int g = 2 * gp;
-            uint32_t x0 = pack_bf2(o[4 * g] * inv, o[4 * g + 1] * inv), x1 = pack_bf2(o[4 * g + 2] * inv, o[4 * g + 3] * inv);
-            uint32_t y0 = pack_bf2(o[4 * g + 4] * inv, o[4 * g + 5] * inv), y1 = pack_bf2(o[4 * g + 6] * inv, o[4 * g + 7] * inv);
-            asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x0), "+v"(y0));
-            asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x1), "+v"(y1));
-            const u32x4_t w = {x0, x1, y0, y1};                      // channels 32 dt + 16 gp + 8 hi + 0..7 of row l31
-            const uint32_t a = stage + l31 * 128 + (((4 * dt + 2 * gp + hi) ^ (l31 & 7)) << 4);
-            asm volatile("ds_write_b128 %0, %1" :: "v"(a), "v"(w) : "memory");
-        }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    u32x4_t rd[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = 8 * i + (lane >> 3);
-        const uint32_t a = stage + r * 128 + (((lane & 7) ^ (r & 7)) << 4);
-        asm volatile("ds_read_b128 %0, %1" : "=v"(rd[i]) : "v"(a) : "memory");
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rd[0]), "+v"(rd[1]), "+v"(rd[2]), "+v"(rd[3]) :: "memory");
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int qq = q0 + 8 * i + (lane >> 3);
-        if (qq < sd.L) *reinterpret_cast<u32x4_t*>(out + (base + (long)qq * sd.pos_stride) * sd.D + head * ATT_HD + (lane & 7) * 8) = rd[i];
-    }
-    const int q = q0 + l31;
-    if (lse && hi == 0 && q < sd.L) lse[(base + (long)q * sd.pos_stride) * sd.heads + head] = (m + log2f(l)) * 0.6931471805599453f;
-}
-
 #define P10_STEP(J, FIRST, PRE_) p10_step<(J) * TILE_B, FIRST, PRE_, PRE>(L, 32 * (J), kad, vad, kf, q, hi, m, l, negm, o0, o1, (J) == nt - 1 ? qnext : nullptr)
 // One wave-load of the NEXT pair per key step: K chunks 0..3 of tile `wave` before steps 0..3, V chunks before steps 4..7.  Inline asm with a
 // scalar base (the pair's K / V column, uniform) + a 32-bit per-lane offset that is the same for every pair (4 registers for the whole
@@ -1093,9 +1110,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma(SeqDesc sd, int nt, c
 
 // ------------------------------------------------------------------------------------------------ backward, one tile (L <= 32)
 // Temporal attention at T <= 32: the whole sequence of a (site, head) is one 32-position tile, so one wave produces dQ, dK and dV
-// from a single visit of Q, K, V, dO (wave-private LDS tiles) and computes delta = rowsum(dO * O) itself: one launch and one
-// read of every operand instead of prep + dK/dV + dQ kernels (three launches, Q/K/V/dO read twice).
-__global__ __launch_bounds__(256, 2) void attn_bwd_one_tile(SeqDesc sd, const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
+// from a single visit of Q, K, V, dO (wave-private LDS tiles): one launch and one read of every operand instead of prep + dK/dV + dQ
+// kernels (three launches, Q/K/V/dO read twice).  delta = rowsum(dO * O) is NOT read from O: with the whole row of P in one tile,
+// rowsum(dO * O) = sum_j P_ij (dO_i . V_j) = sum_j P_ij dP_ij comes out of the accumulators the dQ pass holds anyway (lane = query: 16
+// multiply-adds + one half-wave exchange, in f32) -- the O tensor (a sixth of the kernel's bytes, read as 8-byte pieces per lane) is not touched.
+__global__ __launch_bounds__(256, 2) void attn_bwd_one_tile(SeqDesc sd, const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                          const float* __restrict__ lse, bf16_t* __restrict__ dqkv) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1107,7 +1126,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_one_tile(SeqDesc sd, const bf
     const long ld3 = 3L * sd.D, pse = sd.pos_stride * ld3, pso = sd.pos_stride * sd.D;
     const bf16_t* qh = qkv + base * ld3 + w.head * ATT_HD;
     const bf16_t* doh = dout + base * sd.D + w.head * ATT_HD;
-    const bf16_t* oh = o + base * sd.D + w.head * ATT_HD;
     char* qt_ = smem + wave * (4 * TILE_B + 256);
     char* kt = qt_ + TILE_B; char* vt = kt + TILE_B; char* dot_ = vt + TILE_B;
     float2* ldw = reinterpret_cast<float2*>(dot_ + TILE_B);
@@ -1115,39 +1133,61 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_one_tile(SeqDesc sd, const bf
     load_tile(qh + sd.D, pse, 0, sd.L, kt, lane);
     load_tile(qh + 2 * sd.D, pse, 0, sd.L, vt, lane);
     load_tile(doh, pso, 0, sd.L, dot_, lane);
-    // delta for row l31: each half-wave covers 32 of the 64 channels
     const int qc = l31 < sd.L ? l31 : sd.L - 1;
-    float part = 0.f;
-#pragma unroll
-    for (int d = 0; d < 32; d += 4) {
-        const float4 x = ld4(oh + (size_t)qc * pso + 32 * hi + d), y = ld4(doh + (size_t)qc * pso + 32 * hi + d);
-        part += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
-    }
-    const float dl = half_sum(part);
-    const float lsv = lse[(base + (long)qc * sd.pos_stride) * sd.heads + w.head];
-    if (hi == 0) ldw[l31] = l31 < sd.L ? make_float2(lsv * kLog2e, dl) : make_float2(0.f, 0.f);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    // ---- dK, dV (this wave's keys against its queries)
-    {
-        bf16x8 kf[4], vf[4];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) { kf[ks] = frag_row(kt, l31, ks, hi); vf[ks] = frag_row(vt, l31, ks, hi); }
-        f32x16 dk0, dk1, dv0, dv1;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { dk0[r] = 0.f; dk1[r] = 0.f; dv0[r] = 0.f; dv1[r] = 0.f; }
-        dkv_tile(sd, qt_, dot_, ldw, 0, l31, kf, vf, l31, hi, lane, dk0, dk1, dv0, dv1);
-        dkv_store(sd, base, ld3, w.head, 0, l31, hi, dk0, dk1, dv0, dv1, dqkv);
-    }
-    // ---- dQ
+    const float ls = lse[(base + (long)qc * sd.pos_stride) * sd.heads + w.head] * kLog2e;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ---- dQ (this wave's queries against its keys), which also yields delta
     {
         bf16x8 qf[4], dof[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) { qf[ks] = frag_row(qt_, l31, ks, hi); dof[ks] = frag_row(dot_, l31, ks, hi); }
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            s = TCOW_MFMA_32x32x16_H16(frag_row(kt, l31, ks, hi), qf[ks], s, 0, 0, 0);
+            dp = TCOW_MFMA_32x32x16_H16(frag_row(vt, l31, ks, hi), dof[ks], dp, 0, 0, 0);
+        }
+        // (one tile = the whole sequence: always a boundary tile.  Lane (q = l31, hi) holds the keys crow32(r, hi).)
+        float pv[16];
+        float part = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = crow32(r, hi);
+            const bool ok = l31 < sd.L && key < sd.L && (long)key <= (long)l31 + sd.diag;
+            const float p = ok ? __builtin_amdgcn_exp2f(fmaf(s[r], kScale * kLog2e, -ls)) : 0.f;
+            pv[r] = p;
+            part = fmaf(p, dp[r], part);
+        }
+        const float dl = half_sum(part);                     // delta_q = sum over ALL keys of P dP
+        if (hi == 0) ldw[l31] = l31 < sd.L ? make_float2(ls, dl) : make_float2(0.f, 0.f);
+        float dsv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dsv[r] = pv[r] * (dp[r] - dl);
+        const bf16x8 da0 = pack8(dsv), da1 = pack8(dsv + 8);
         f32x16 dq0, dq1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dq0[r] = 0.f; dq1[r] = 0.f; }
-        dq_tile(sd, kt, vt, 0, l31, qf, dof, lsv * kLog2e, dl, l31, hi, lane, dq0, dq1);
-        dq_store(sd, base, ld3, w.head, 0, l31, hi, dq0, dq1, dqkv);
+        dq0 = TCOW_MFMA_32x32x16_H16(frag_tr(kt, 0, 0, lane), da0, dq0, 0, 0, 0);
+        dq0 = TCOW_MFMA_32x32x16_H16(frag_tr(kt, 1, 0, lane), da1, dq0, 0, 0, 0);
+        dq1 = TCOW_MFMA_32x32x16_H16(frag_tr(kt, 0, 1, lane), da0, dq1, 0, 0, 0);
+        dq1 = TCOW_MFMA_32x32x16_H16(frag_tr(kt, 1, 1, lane), da1, dq1, 0, 0, 0);
+        // K and V fragments of the second pass are taken BEFORE the gradient tiles go out through the K / V tiles' LDS space (whole-row stores)
+        bf16x8 kf[4], vf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { kf[ks] = frag_row(kt, l31, ks, hi); vf[ks] = frag_row(vt, l31, ks, hi); }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (also: the (lse, delta) table is in LDS; wave-private, no barrier)
+        bf16_t* drow0 = dqkv + base * ld3 + w.head * ATT_HD;
+        const uint32_t lds_k = (uint32_t)(uintptr_t)(LDS_PTR(char))kt, lds_v = (uint32_t)(uintptr_t)(LDS_PTR(char))vt;
+        store_tile_staged(lds_k, lane, kScale, dq0, dq1, drow0, pse, sd.L);
+        // ---- dK, dV (this wave's keys against its queries)
+        f32x16 dk0, dk1, dv0, dv1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk0[r] = 0.f; dk1[r] = 0.f; dv0[r] = 0.f; dv1[r] = 0.f; }
+        dkv_tile(sd, qt_, dot_, ldw, 0, l31, kf, vf, l31, hi, lane, dk0, dk1, dv0, dv1);
+        store_tile_staged(lds_k, lane, kScale, dk0, dk1, drow0 + sd.D, pse, sd.L);        // dS was accumulated without its 1/sqrt(d) factor
+        store_tile_staged(lds_v, lane, 1.0f, dv0, dv1, drow0 + 2 * sd.D, pse, sd.L);
     }
 }
 
@@ -1299,7 +1339,7 @@ int tcow_attn_mfma_fwd(hipStream_t st, const SeqDesc& d, bool shared, const void
         set_lds_attr(attn_fwd_mfma<true>, lds);
         hipLaunchKernelGGL(attn_fwd_mfma<true>, dim3(pairs), dim3(256), lds, st, d, nt, (const bf16_t*)qkv, (bf16_t*)out, lse);
     } else {
-        const int lds = 4 * 2 * nt * TILE_B;
+        const int lds = 4 * 3 * nt * TILE_B;
         set_lds_attr(attn_fwd_mfma<false>, lds);
         hipLaunchKernelGGL(attn_fwd_mfma<false>, dim3(cdiv(pairs, 4)), dim3(256), lds, st, d, nt, (const bf16_t*)qkv, (bf16_t*)out, lse);
     }
@@ -1319,7 +1359,7 @@ int tcow_attn_mfma_bwd(hipStream_t st, const SeqDesc& d, bool shared, const void
     if (!shared && nt == 1) {
         const int lds = 4 * (4 * TILE_B + 256);
         set_lds_attr(attn_bwd_one_tile, lds);
-        hipLaunchKernelGGL(attn_bwd_one_tile, dim3(cdiv(pairs, 4)), dim3(256), lds, st, d, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv);
+        hipLaunchKernelGGL(attn_bwd_one_tile, dim3(cdiv(pairs, 4)), dim3(256), lds, st, d, (const bf16_t*)qkv, (const bf16_t*)dout, lse, (bf16_t*)dqkv);
         TCOW_CHECK_LAUNCH();
         return TCOW_OK;
     }
