@@ -111,18 +111,19 @@ def cpu_baseline(cfg, budget_s):
 
 def pmc_traffic():
     """roofline.traffic: HBM bytes per launch of the dominant kernel family from the rocprofv3 --pmc passes of this command (FETCH_SIZE
-    with the gfx950 x2 correction + WRITE_SIZE, tools/pmc_gemm_traffic.sh -> profiles/r02_pmc_gemm_nt.json).  Counters cannot be read
+    with the gfx950 x2 correction + WRITE_SIZE, tools/pmc_bench.sh -> profiles/rNN_pmc_gemm_nt.json).  Counters cannot be read
     inside the timed run, so the committed measurement is used ONLY while it still describes the kernel source that is running: the JSON
     records the sha256 of gemm_bf16.hip it was taken with; any difference reports null rather than a stale number."""
+    import glob
     import hashlib
     root = os.path.dirname(os.path.abspath(__file__))
-    path = os.path.join(root, 'profiles', 'r02_pmc_gemm_nt.json')
-    if not os.path.exists(path):
-        return None
-    rec = json.load(open(path))
     src = os.path.join(root, 'tcow_amd', 'csrc', 'gemm_bf16.hip')
     sha = hashlib.sha256(open(src, 'rb').read()).hexdigest() if os.path.exists(src) else None
-    return rec.get('traffic_bytes_per_launch') if sha is not None and rec.get('gemm_bf16_sha256') == sha else None
+    for path in sorted(glob.glob(os.path.join(root, 'profiles', 'r*_pmc_gemm_nt.json')), reverse=True):     # newest round first
+        rec = json.load(open(path))
+        if sha is not None and rec.get('gemm_bf16_sha256') == sha:
+            return rec.get('traffic_bytes_per_launch')
+    return None
 
 
 def parity_leg(make_trainer, bf16_net, ref_mask, args, bf16_rate=None):

@@ -175,7 +175,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int D, const T* _
 int tcow_launch_row_reduce2(hipStream_t stream, const float* part, int nrows, long ld, int N1, float* out1, int N2, float* out2, int accumulate);
 int tcow_launch_row_reduce3(hipStream_t stream, const float* part, int nrows, long ld, int N1, float* out1, int N2, float* out2, int N3, float* out3, int accumulate);
 
-static const int kLnBwdBlocks = 512;
+static const int kLnBwdBlocks = [] { const char* e = getenv("TCOW_LN_BWD_BLOCKS"); const int v = e ? atoi(e) : 768; return v >= 1 ? v : 768; }();
+// (grid-stride blocks of the backward: 768 = three 4-wave workgroups per CU in ONE round -- the kernel needs 154 VGPRs at D = 768, i.e. three
+// waves per SIMD; 512 -> 768: 78 -> 73.5 us, 1024 (1.33 rounds) 84 us.  The colsum variant needs 180 VGPRs = two waves per SIMD: 512 blocks.)
+static const int kLnBwdBlocksCsum = [] { const char* e = getenv("TCOW_LN_BWD_BLOCKS_CSUM"); const int v = e ? atoi(e) : 512; return v >= 1 && v <= kLnBwdBlocks ? v : (kLnBwdBlocks < 512 ? kLnBwdBlocks : 512); }();
 static const int kLnFwdBlocks = [] { const char* e = getenv("TCOW_LN_FWD_BLOCKS"); const int v = e ? atoi(e) : 4096; return v >= 1 ? v : 4096; }();     // grid-stride blocks of the forward (512 ... 8192 measured within 6 %: tools/dev_ln_time.py)
 
 extern "C" {
@@ -212,9 +215,10 @@ int tcow_layernorm_bwd(void* stream, int dtype, int rows, int D, const void* dy,
     TCOW_CHECK_ARG(!want_param_grads || (dgamma && dbeta && workspace && workspace_bytes >= tcow_layernorm_bwd_workspace_bytes(D)),
                    "tcow_layernorm_bwd: parameter gradients need dgamma, dbeta and a workspace of %ld bytes", tcow_layernorm_bwd_workspace_bytes(D));
     TCOW_CHECK_ARG(!colsum_out || want_param_grads, "tcow_layernorm_bwd: colsum_out rides on the parameter-gradient pass (dgamma / dbeta needed)");
-    int blocks = cdiv(rows, 4); if (blocks > kLnBwdBlocks) blocks = kLnBwdBlocks;
-    float* part = want_param_grads ? (float*)workspace : nullptr;
     const bool csum = colsum_out != nullptr;
+    const int max_blocks = csum ? kLnBwdBlocksCsum : kLnBwdBlocks;
+    int blocks = cdiv(rows, 4); if (blocks > max_blocks) blocks = max_blocks;
+    float* part = want_param_grads ? (float*)workspace : nullptr;
     const size_t lds = want_param_grads ? (size_t)4 * D * 4 : 0;
     if (dtype != TCOW_BF16 && dtype != TCOW_F32) { tcow_set_error("tcow_layernorm_bwd: unknown dtype %d", dtype); return TCOW_ERR_INVALID_ARG; }
     const int nvl = (D / 4 + 63) / 64;

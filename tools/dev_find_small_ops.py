@@ -30,6 +30,13 @@ for ev in prof.events():
         cnt[(ev.name, fr[0] if fr else (ev.stack[0] if ev.stack else '?'))] += 1
 for (n, f), c in cnt.most_common(70):
     print(f'{c:4d} {n:14s} {f[:130]}')
+print('---- fill / zero launches by innermost frames')
+fc = collections.Counter()
+for ev in prof.events():
+    if ev.name in ('aten::fill_', 'aten::zero_'):
+        fc[(ev.name, tuple((ev.stack or ['?'])[:5]))] += 1
+for (n, st), c in fc.most_common(25):
+    print(f'{c:4d} {n}'); [print('        ', f[:150]) for f in st]
 ka = prof.key_averages()
 rows = sorted(ka, key=lambda e: -e.count)
 for e in rows[:45]:

@@ -16,4 +16,8 @@ def bench(f, n=30, w_=8):
 ops.layernorm_fwd(ops.BF16, x, w, b, y, mu, rs)
 tf = bench(lambda: ops.layernorm_fwd(ops.BF16, x, w, b, y, mu, rs))
 tb = bench(lambda: ops.layernorm_bwd(ops.BF16, dy, x, mu, rs, w, dres, dx, dg, db, dx_cast=dxc, cast_scale=cs))
+cso = torch.empty(D, device=dev); ss = torch.rand(M, device=dev)
+tc = bench(lambda: ops.layernorm_bwd(ops.BF16, dy, x, mu, rs, w, dres, dx, dg, db, dx_cast=dxc, cast_scale=cs, colsum_out=cso, colsum_scale=ss))
+tn = bench(lambda: ops.layernorm_bwd(ops.BF16, dy, x, mu, rs, w, dres, dx, dg, db))
+print(f'ln bwd csum {tc:.1f} us, ln bwd no cast {tn:.1f} us ({M*D*14/tn/1e6:.2f} TB/s)')
 print(f'ln fwd {tf:.1f} us ({M*D*6/tf/1e6:.2f} TB/s)   ln bwd + cast + param-grad fold {tb:.1f} us ({M*D*16/tb/1e6:.2f} TB/s)')
