@@ -63,6 +63,28 @@ __device__ __forceinline__ void load_tile(const bf16_t* src, long pse, int p0, i
     }
 }
 
+// rows 8c .. 8c+7 of such a tile (a quarter: one direct-to-LDS instruction)
+__device__ __forceinline__ void load_tile_chunk(const bf16_t* src, long pse, int p0, int L, char* tile, int c, int lane) {
+    const int r = 8 * c + (lane >> 3);
+    const int ch = (lane & 7) ^ swz_g(r);
+    int pos = p0 + r; pos = pos < L ? pos : L - 1;
+    glds16(src + (size_t)pos * pse + ch * 8, tile + c * 1024);
+}
+
+// Streaming kernels: tiles c0 .. c0+CH-1 of two row sources into the LDS tile arrays ta / tb.  Wave w of the 4-wave workgroup brings tile c0+w;
+// with CH = 5 the fifth tile comes in quarters, one per wave (nt = 10 -- S = 301 -- then needs two chunk rounds instead of three).
+template <int CH>
+__device__ __forceinline__ void load_chunk2(const bf16_t* a, long psa, const bf16_t* b, long psb, int c0, int nt, int L, char* ta, char* tb, int wave, int lane) {
+    if (c0 + wave < nt) {
+        load_tile(a, psa, 32 * (c0 + wave), L, ta + wave * TILE_B, lane);
+        load_tile(b, psb, 32 * (c0 + wave), L, tb + wave * TILE_B, lane);
+    }
+    if (CH == 5 && c0 + 4 < nt) {
+        load_tile_chunk(a, psa, 32 * (c0 + 4), L, ta + 4 * TILE_B, wave, lane);
+        load_tile_chunk(b, psb, 32 * (c0 + 4), L, tb + 4 * TILE_B, wave, lane);
+    }
+}
+
 // A/B fragment of a row-major tile for a contraction over d: lane (row = lane&31, hi) gets d = 16*ks + 8*hi .. +7
 __device__ __forceinline__ bf16x8 frag_row(const char* tile, int row, int ks, int hi) {
     const int c = (2 * ks + hi) ^ swz_g(row);
@@ -294,8 +316,9 @@ __device__ __forceinline__ StreamWork stream_work(int pairs, int nchunk) {
 }
 static inline int stream_grid(int pairs, int nchunk) { return 8 * ((pairs + 7) / 8) * nchunk; }
 
+template <int CH>
 __global__ __launch_bounds__(256, 2) void attn_fwd_stream(SeqDesc sd, int nt, const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse) {
-    __shared__ __attribute__((aligned(16))) char smem[8 * TILE_B];
+    __shared__ __attribute__((aligned(16))) char smem[2 * CH * TILE_B];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
@@ -306,7 +329,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_stream(SeqDesc sd, int nt, co
     const long ld3 = 3L * sd.D, pse = sd.pos_stride * ld3;
     const bf16_t* qh = qkv + base * ld3 + head * ATT_HD;
     char* kt = smem;
-    char* vt = smem + 4 * TILE_B;
+    char* vt = smem + CH * TILE_B;
+    // the first K / V chunk is requested before anything else: its flight covers the query-fragment loads below
+    load_chunk2<CH>(qh + sd.D, pse, qh + 2 * sd.D, pse, 0, nt, sd.L, kt, vt, wave, lane);
     const int qt = sw_.chunk * 4 + wave;
     const bool active = qt < nt;
     const int q = 32 * qt + l31;
@@ -322,15 +347,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_stream(SeqDesc sd, int nt, co
     const int kt_end = (!active) ? 0 : (klim >= (long)sd.L - 1 ? nt : (int)(klim / 32) + 1);
     const long klim_wg = (long)32 * (sw_.chunk * 4 + 3) + 31 + sd.diag;          // last key tile any wave of this workgroup needs
     const int kt_end_wg = klim_wg >= (long)sd.L - 1 ? nt : (int)(klim_wg / 32) + 1;
-    for (int c0 = 0; c0 < kt_end_wg; c0 += 4) {
-        __syncthreads();                                   // previous chunk fully consumed
-        if (c0 + wave < nt) {
-            load_tile(qh + sd.D, pse, 32 * (c0 + wave), sd.L, kt + wave * TILE_B, lane);
-            load_tile(qh + 2 * sd.D, pse, 32 * (c0 + wave), sd.L, vt + wave * TILE_B, lane);
+    for (int c0 = 0; c0 < kt_end_wg; c0 += CH) {
+        if (c0) {
+            __syncthreads();                               // previous chunk fully consumed
+            load_chunk2<CH>(qh + sd.D, pse, qh + 2 * sd.D, pse, c0, nt, sd.L, kt, vt, wave, lane);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        const int jend = (c0 + 4 < kt_end) ? c0 + 4 : kt_end;
+        const int jend = (c0 + CH < kt_end) ? c0 + CH : kt_end;
         for (int j = c0; j < jend; ++j) fwd_tile(sd, kt + (j - c0) * TILE_B, vt + (j - c0) * TILE_B, qf, j, qt, q, l31, hi, lane, m, l, o0, o1);
     }
     if (active) fwd_store(sd, base, head, q, hi, m, l, o0, o1, out, lse);
@@ -648,13 +672,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_res(SeqDesc sd, int nt, const
 // running maximum enters through the C operand of the first score MFMA (a 16-register tuple holding -m) and the exponent argument needs
 // no VALU instruction at all.
 constexpr int P10_WAVES = 10;
-
-__device__ __forceinline__ void load_tile_chunk(const bf16_t* src, long pse, int p0, int L, char* tile, int c, int lane) {
-    const int r = 8 * c + (lane >> 3);
-    const int ch = (lane & 7) ^ swz_g(r);
-    int pos = p0 + r; pos = pos < L ? pos : L - 1;
-    glds16(src + (size_t)pos * pse + ch * 8, tile + c * 1024);
-}
 
 // qnext != nullptr: this is the pair's last key step -- once its score MFMAs have issued (i.e. read their operands) the query fragment
 // registers are free, and the NEXT pair's fragments are requested into them (inline-asm loads; the end-of-pair vmcnt(0) covers them).
@@ -1193,14 +1210,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_one_tile(SeqDesc sd, const bf
 
 // ---- streaming backward kernels (any sequence length): a workgroup owns 4 key tiles (dK/dV) or 4 query tiles (dQ), one per
 // wave, and walks the other side in chunks of 4 tiles staged in 32 KiB of LDS (wave w loads tile 4c+w of the chunk).
+template <int CH>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_stream(SeqDesc sd, int nt, const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
-                                                           const float2* __restrict__ ld, bf16_t* __restrict__ dqkv) {
-    __shared__ __attribute__((aligned(16))) char smem[8 * TILE_B];
+                                                           const float2* __restrict__ ld, bf16_t* __restrict__ dqkv, long long* __restrict__ dbg) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * CH * TILE_B];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
+#define STREAM_STAMP(i) do { if (dbg && lane == 0) dbg[(blockIdx.x * 4 + wave) * 24 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
     const StreamWork sw_ = stream_work(sd.n_outer * sd.n_inner * sd.heads, (nt + 3) / 4);
     if (!sw_.valid) return;
+    STREAM_STAMP(0);
     const int item = sw_.pair / sd.heads, head = sw_.pair - item * sd.heads;
     const long base = seq_base(sd, item);
     const long ld3 = 3L * sd.D, pse = sd.pos_stride * ld3, pso = sd.pos_stride * sd.D;
@@ -1208,9 +1228,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_stream(SeqDesc sd, int nt
     const bf16_t* doh = dout + base * sd.D + head * ATT_HD;
     const float2* ldh = ld + ((size_t)item * sd.heads + head) * (nt * 32);
     char* qt_ = smem;
-    char* dot_ = smem + 4 * TILE_B;
+    char* dot_ = smem + CH * TILE_B;
     const int j = sw_.chunk * 4 + wave;
     const bool active = j < nt;
+    const long qlo = (long)32 * j - sd.diag;                       // first query tile that can see this wave's keys
+    const int i0 = qlo > 0 ? (int)(qlo / 32) : 0;
+    const long qlo_wg = (long)32 * (sw_.chunk * 4) - sd.diag;     // ... and any key of this workgroup
+    const int c_start = qlo_wg > 0 ? ((int)(qlo_wg / 32) / CH) * CH : 0;
+    // the first Q / dO chunk is requested before the K / V fragment loads: both latencies run together
+    load_chunk2<CH>(qh, pse, doh, pso, c_start, nt, sd.L, qt_, dot_, wave, lane);
+    STREAM_STAMP(1);
     const int key = 32 * j + l31;
     const int kc = key < sd.L ? key : sd.L - 1;
     bf16x8 kf[4], vf[4];
@@ -1219,36 +1246,41 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_stream(SeqDesc sd, int nt
     f32x16 dk0, dk1, dv0, dv1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dk0[r] = 0.f; dk1[r] = 0.f; dv0[r] = 0.f; dv1[r] = 0.f; }
-    const long qlo = (long)32 * j - sd.diag;                       // first query tile that can see this wave's keys
-    const int i0 = qlo > 0 ? (int)(qlo / 32) : 0;
-    const long qlo_wg = (long)32 * (sw_.chunk * 4) - sd.diag;     // ... and any key of this workgroup
-    const int c_start = qlo_wg > 0 ? (int)(qlo_wg / 32) & ~3 : 0;
-    for (int c0 = c_start; c0 < nt; c0 += 4) {
-        __syncthreads();
-        if (c0 + wave < nt) {
-            load_tile(qh, pse, 32 * (c0 + wave), sd.L, qt_ + wave * TILE_B, lane);
-            load_tile(doh, pso, 32 * (c0 + wave), sd.L, dot_ + wave * TILE_B, lane);
+    for (int c0 = c_start; c0 < nt; c0 += CH) {
+        const int cidx = (c0 - c_start) / CH;
+        const int ck = 1 + 5 * (cidx < 3 ? cidx : 3);
+        if (c0 != c_start) {
+            __syncthreads();
+            STREAM_STAMP(ck);
+            load_chunk2<CH>(qh, pse, doh, pso, c0, nt, sd.L, qt_, dot_, wave, lane);
         }
+        STREAM_STAMP(ck + 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        STREAM_STAMP(ck + 2);
         __syncthreads();
+        STREAM_STAMP(ck + 3);
         if (active) {
-            const int ib = c0 > i0 ? c0 : i0, ie = c0 + 4 < nt ? c0 + 4 : nt;
+            const int ib = c0 > i0 ? c0 : i0, ie = c0 + CH < nt ? c0 + CH : nt;
             for (int i = ib; i < ie; ++i) dkv_tile(sd, qt_ + (i - c0) * TILE_B, dot_ + (i - c0) * TILE_B, ldh, i, key, kf, vf, l31, hi, lane, dk0, dk1, dv0, dv1);
         }
+        STREAM_STAMP(ck + 4);
     }
     if (active) dkv_store(sd, base, ld3, head, j, l31, hi, dk0, dk1, dv0, dv1, dqkv);
+    STREAM_STAMP(21);
 }
 
 // (This kernel runs FIRST in the streaming backward: every wave owns a query tile, so it also computes delta = rowsum(dO * O) of
 // its queries and publishes the packed (lse, delta) table that the dK / dV kernel reads -- no separate preparation launch.)
+template <int CH>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_stream(SeqDesc sd, int nt, const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
-                                                          const float* __restrict__ lse, float2* __restrict__ ld, bf16_t* __restrict__ dqkv) {
-    __shared__ __attribute__((aligned(16))) char smem[8 * TILE_B];
+                                                          const float* __restrict__ lse, float2* __restrict__ ld, bf16_t* __restrict__ dqkv, long long* __restrict__ dbg) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * CH * TILE_B];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
     const StreamWork sw_ = stream_work(sd.n_outer * sd.n_inner * sd.heads, (nt + 3) / 4);
     if (!sw_.valid) return;
+    STREAM_STAMP(0);
     const int item = sw_.pair / sd.heads, head = sw_.pair - item * sd.heads;
     const long base = seq_base(sd, item);
     const long ld3 = 3L * sd.D, pse = sd.pos_stride * ld3, pso = sd.pos_stride * sd.D;
@@ -1256,7 +1288,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_stream(SeqDesc sd, int nt,
     const bf16_t* doh = dout + base * sd.D + head * ATT_HD;
     float2* ldh = ld + ((size_t)item * sd.heads + head) * (nt * 32);
     char* kt = smem;
-    char* vt = smem + 4 * TILE_B;
+    char* vt = smem + CH * TILE_B;
+    // the first K / V chunk is requested before the Q / dO / O fragment loads and the delta sums: both latencies run together
+    load_chunk2<CH>(qh + sd.D, pse, qh + 2 * sd.D, pse, 0, nt, sd.L, kt, vt, wave, lane);
+    STREAM_STAMP(1);
     const int qt = sw_.chunk * 4 + wave;
     const bool active = qt < nt;
     const int q = 32 * qt + l31;
@@ -1285,18 +1320,25 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_stream(SeqDesc sd, int nt,
     const int kt_end = (!active) ? 0 : (klim >= (long)sd.L - 1 ? nt : (int)(klim / 32) + 1);
     const long klim_wg = (long)32 * (sw_.chunk * 4 + 3) + 31 + sd.diag;
     const int kt_end_wg = klim_wg >= (long)sd.L - 1 ? nt : (int)(klim_wg / 32) + 1;
-    for (int c0 = 0; c0 < kt_end_wg; c0 += 4) {
-        __syncthreads();
-        if (c0 + wave < nt) {
-            load_tile(qh + sd.D, pse, 32 * (c0 + wave), sd.L, kt + wave * TILE_B, lane);
-            load_tile(qh + 2 * sd.D, pse, 32 * (c0 + wave), sd.L, vt + wave * TILE_B, lane);
+    for (int c0 = 0; c0 < kt_end_wg; c0 += CH) {
+        const int ck = 1 + 5 * ((c0 / CH) < 3 ? (c0 / CH) : 3);
+        if (c0) {
+            __syncthreads();
+            STREAM_STAMP(ck);
+            load_chunk2<CH>(qh + sd.D, pse, qh + 2 * sd.D, pse, c0, nt, sd.L, kt, vt, wave, lane);
         }
+        STREAM_STAMP(ck + 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        STREAM_STAMP(ck + 2);
         __syncthreads();
-        const int jend = (c0 + 4 < kt_end) ? c0 + 4 : kt_end;
+        STREAM_STAMP(ck + 3);
+        const int jend = (c0 + CH < kt_end) ? c0 + CH : kt_end;
         for (int j = c0; j < jend; ++j) dq_tile(sd, kt + (j - c0) * TILE_B, vt + (j - c0) * TILE_B, j, q, qf, dof, ls, dl, l31, hi, lane, dq0, dq1);
+        STREAM_STAMP(ck + 4);
     }
     if (active) dq_store(sd, base, ld3, head, qt, l31, hi, dq0, dq1, dqkv);
+    STREAM_STAMP(21);
+#undef STREAM_STAMP
 }
 
 template <typename K>
@@ -1311,6 +1353,11 @@ static void set_lds_attr(K kernel, int bytes) {
 static int shared_variant() { static const int v = [] { const char* e = getenv("TCOW_ATTN_SHARED"); return e ? atoi(e) : 2; }(); return v; }
 // spatial sequences of <= 10 tiles without a causal mask: TCOW_ATTN_RES=1 the resident kernel (2 workgroups per CU), =2 the persistent
 // 10-wave kernel, 0 (default) the streaming kernels -- see profiles/r03_attention.md for the measurements behind the default
+// streaming kernels: tiles per LDS chunk -- 5 when that saves a chunk round (nt = 10: two rounds instead of three), else 4; TCOW_ATTN_CH=4|5 forces
+static bool stream_ch5(int nt) {
+    static const int v = [] { const char* e = getenv("TCOW_ATTN_CH"); return e ? atoi(e) : 0; }();
+    return v == 5 || (v != 4 && (nt + 4) / 5 < (nt + 3) / 4);
+}
 static int res_variant() { static const int v = [] { const char* e = getenv("TCOW_ATTN_RES"); return e ? atoi(e) : 0; }(); return v; }
 static bool use_res(const SeqDesc& d, bool shared, int nt) { return shared && res_variant() != 0 && nt <= RES_MAX_NT && d.diag >= (1 << 27) && d.L >= 2; }
 
@@ -1333,7 +1380,8 @@ int tcow_attn_mfma_fwd(hipStream_t st, const SeqDesc& d, bool shared, const void
         set_lds_attr(attn_fwd_res, lds);
         hipLaunchKernelGGL(attn_fwd_res, dim3(pairs), dim3(256), lds, st, d, nt, (const bf16_t*)qkv, (bf16_t*)out, lse, (long long*)nullptr);
     } else if ((shared && shared_variant() == 2) || (!shared && nt > 2)) {
-        hipLaunchKernelGGL(attn_fwd_stream, dim3(stream_grid(pairs, cdiv(nt, 4))), dim3(256), 0, st, d, nt, (const bf16_t*)qkv, (bf16_t*)out, lse);
+        // (forward: four tiles per chunk -- with five, 40 KiB per workgroup, the fourth workgroup of a CU no longer fits and 56 us become 60)
+        hipLaunchKernelGGL(attn_fwd_stream<4>, dim3(stream_grid(pairs, cdiv(nt, 4))), dim3(256), 0, st, d, nt, (const bf16_t*)qkv, (bf16_t*)out, lse);
     } else if (shared) {
         const int lds = 2 * nt * TILE_B;
         set_lds_attr(attn_fwd_mfma<true>, lds);
@@ -1367,10 +1415,16 @@ int tcow_attn_mfma_bwd(hipStream_t st, const SeqDesc& d, bool shared, const void
     const long total = (long)pairs * nt * 32;
     int blocks = cdiv(total, 256); if (blocks > 8192) blocks = 8192;
     if ((shared && shared_variant() == 2) || (!shared && nt > 2)) {
-        hipLaunchKernelGGL(attn_bwd_dq_stream, dim3(stream_grid(pairs, cdiv(nt, 4))), dim3(256), 0, st, d, nt, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, ld,
-                           (bf16_t*)dqkv);
-        TCOW_CHECK_LAUNCH();
-        hipLaunchKernelGGL(attn_bwd_dkv_stream, dim3(stream_grid(pairs, cdiv(nt, 4))), dim3(256), 0, st, d, nt, (const bf16_t*)qkv, (const bf16_t*)dout, ld, (bf16_t*)dqkv);
+        const dim3 sg(stream_grid(pairs, cdiv(nt, 4)));
+        if (stream_ch5(nt)) {
+            hipLaunchKernelGGL(attn_bwd_dq_stream<5>, sg, dim3(256), 0, st, d, nt, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, ld, (bf16_t*)dqkv, (long long*)nullptr);
+            TCOW_CHECK_LAUNCH();
+            hipLaunchKernelGGL(attn_bwd_dkv_stream<5>, sg, dim3(256), 0, st, d, nt, (const bf16_t*)qkv, (const bf16_t*)dout, ld, (bf16_t*)dqkv, (long long*)nullptr);
+        } else {
+            hipLaunchKernelGGL(attn_bwd_dq_stream<4>, sg, dim3(256), 0, st, d, nt, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, ld, (bf16_t*)dqkv, (long long*)nullptr);
+            TCOW_CHECK_LAUNCH();
+            hipLaunchKernelGGL(attn_bwd_dkv_stream<4>, sg, dim3(256), 0, st, d, nt, (const bf16_t*)qkv, (const bf16_t*)dout, ld, (bf16_t*)dqkv, (long long*)nullptr);
+        }
         TCOW_CHECK_LAUNCH();
         return TCOW_OK;
     }

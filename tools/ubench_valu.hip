@@ -439,6 +439,47 @@ int main(int argc, char** argv) {
                 fprintf(f, "\n");
             }
         }
+        // E: phase timeline of the shipped streaming backward kernels (wave 0..3 of every workgroup that owns four live tiles)
+        {
+            bf16_t *dout, *dqkv; float2* ldt; long long* dbg3;
+            CK(hipMalloc(&dout, M * D * 2)); CK(hipMalloc(&dqkv, M * 3 * D * 2)); CK(hipMalloc(&ldt, (size_t)pairs * 320 * 8));
+            CK(hipMemcpy(dout, qkv, M * D * 2, hipMemcpyDeviceToDevice));
+            const int nchunk = 3, grid = stream_grid(pairs, nchunk);
+            CK(hipMalloc(&dbg3, (size_t)grid * 4 * 24 * 8));
+            hipLaunchKernelGGL(attn_fwd_stream<5>, dim3(grid), dim3(256), 0, 0, sd, 10, qkv, o, lse); CK(hipDeviceSynchronize());
+            for (int which = 0; which < 4; ++which) {
+                auto launch = [&](long long* d) {
+                    if (which == 0) hipLaunchKernelGGL(attn_bwd_dq_stream<4>, dim3(grid), dim3(256), 0, 0, sd, 10, qkv, o, dout, lse, ldt, dqkv, d);
+                    else if (which == 1) hipLaunchKernelGGL(attn_bwd_dkv_stream<4>, dim3(grid), dim3(256), 0, 0, sd, 10, qkv, dout, ldt, dqkv, d);
+                    else if (which == 2) hipLaunchKernelGGL(attn_bwd_dq_stream<5>, dim3(grid), dim3(256), 0, 0, sd, 10, qkv, o, dout, lse, ldt, dqkv, d);
+                    else hipLaunchKernelGGL(attn_bwd_dkv_stream<5>, dim3(grid), dim3(256), 0, 0, sd, 10, qkv, dout, ldt, dqkv, d);
+                };
+                for (int rep = 0; rep < 3; ++rep) launch(nullptr);
+                CK(hipEventRecord(e0)); for (int rep = 0; rep < 20; ++rep) launch(nullptr);
+                CK(hipEventRecord(e1)); CK(hipDeviceSynchronize()); CK(hipEventElapsedTime(&ms, e0, e1));
+                fprintf(f, "E  %s at B*Qs=3 T=30 S=301 h=12: %.1f us per launch\n", (which & 1) ? (which > 1 ? "attn_bwd_dkv_stream<5>" : "attn_bwd_dkv_stream<4>") : (which > 1 ? "attn_bwd_dq_stream<5>" : "attn_bwd_dq_stream<4>"), ms * 1000 / 20);
+                CK(hipMemset(dbg3, 0, (size_t)grid * 4 * 24 * 8));
+                launch(dbg3); CK(hipDeviceSynchronize());
+                std::vector<long long> h3((size_t)grid * 4 * 24); CK(hipMemcpy(h3.data(), dbg3, h3.size() * 8, hipMemcpyDeviceToHost));
+                const char* ph[5] = {"barrier in", "issue loads", "loads land", "barrier", "tile steps"};
+                const int nch = which > 1 ? 2 : 3;
+                for (int w = 0; w < 4; w += 3) {
+                    double acc[3][5] = {{0}}; double store = 0, total = 0; int n = 0;
+                    for (int b = 0; b < grid; ++b) {
+                        const int k = b >> 3, ch = k % nchunk; if (ch == 2) continue;            // (the workgroup of tiles 8, 9 has two idle waves)
+                        const long long* t = &h3[(size_t)(b * 4 + w) * 24]; if (!t[21]) continue;
+                        ++n; store += (double)(t[21] - t[5 * nch]); total += (double)(t[21] - t[0]);
+                        for (int c = 0; c < nch; ++c) for (int i = 0; i < 5; ++i) { const int a = 1 + 5 * c + i; acc[c][i] += (double)(t[a] - t[a - 1]); }
+                    }
+                    fprintf(f, "E    wave %d (%d workgroups): total %.0f cycles; issue of the first chunk's loads %.0f, fragment loads (+ delta) %.0f; store %.0f\n", w, n, total / n, acc[0][0] / n, acc[0][1] / n, store / n);
+                    for (int c = 0; c < nch; ++c) {
+                        fprintf(f, "E      chunk %d:", c);
+                        for (int i = (c ? 0 : 2); i < 5; ++i) fprintf(f, "  %s %.0f", ph[i], acc[c][i] / n);
+                        fprintf(f, "\n");
+                    }
+                }
+            }
+        }
         hipLaunchKernelGGL(attn_fwd_res, dim3(pairs), dim3(256), RES_LDS, 0, sd, 10, qkv, o, lse, dbg); CK(hipDeviceSynchronize());
         std::vector<long long> h((size_t)pairs * 16); CK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
         const char* nm[12] = {"issue loads", "wait group 0 (Q + tiles 0-3)", "steps 0-3", "wait group 1", "steps 4-7", "issue qx", "wait group 2", "steps 8-9", "store 2 tiles", "5 single steps", "barrier", "merge + store"};
