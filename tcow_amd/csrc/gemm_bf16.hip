@@ -37,7 +37,6 @@ struct NtParams {
     bf16_t* aux; long ldaux;
     int tiles_m, tiles_n;
     const float* bias2; const float* row_scale2;      // second bias with its own row scale (the folded temporal projection), or NULL
-    int epi_prefetch;                                  // 320 tile: pull the epilogue's row operands into L2 under the last K slices
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
@@ -505,35 +504,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_320_kernel(NtParams p) {
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                    \
             acc[i][j] = TCOW_MFMA_32x32x16_H16(__builtin_bit_cast(bf16x8, fw[buf][j]), __builtin_bit_cast(bf16x8, fa[buf][i]), acc[i][j], 0, 0, 0)
 
-    // Epilogue operands ([320 x 256] residual f32 / GELU' bf16 of this tile) are pulled into L2 while the last K slices are multiplied:
-    // one 4-byte direct-to-LDS load per 64-byte sector into a scratch LDS word behind the operand stages (no register, no result).  All
-    // tiles of a round finish together, so without this the whole round's operand reads hit HBM as one burst after the last MFMA.
-    const int pf_mode = p.epi_prefetch;
-    const int pf_at = pf_mode ? (nk > 6 ? nk - 6 : 0) : -1;
-    char* sink = smem + C_LDS + wave * 256;
-    auto prefetch_epi = [&](int i) {          // i-th of 5 passes: one 4-byte load per 128-byte line
-        if (E::res(p)) {
-            if (pf_mode == 1) {
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int id = tid + 512 * (2 * i + h), r = id >> 4, c = (id & 15) * 16;
-                    if (m0 + r < p.M && n0 + c < p.N) __builtin_amdgcn_global_load_lds((GLB_PTR(const uint32_t))(p.resid + (size_t)(m0 + r) * p.ldr + n0 + c), (LDS_PTR(uint32_t))sink, 4, 0, 0);
-                }
-            } else {
-                const int id = tid + 512 * i, r = id >> 3, c = (id & 7) * 32;
-                if (m0 + r < p.M && n0 + c < p.N) __builtin_amdgcn_global_load_lds((GLB_PTR(const uint32_t))(p.resid + (size_t)(m0 + r) * p.ldr + n0 + c), (LDS_PTR(uint32_t))sink, 4, 0, 0);
-            }
-        }
-        if (E::act(p) == TCOW_ACT_MUL_AUX || E::act(p) == TCOW_ACT_DGELU) {
-            if (pf_mode == 1) {
-                const int id = tid + 512 * i, r = id >> 3, c = (id & 7) * 32;
-                if (m0 + r < p.M && n0 + c < p.N) __builtin_amdgcn_global_load_lds((GLB_PTR(const uint32_t))(p.aux + (size_t)(m0 + r) * p.ldaux + n0 + c), (LDS_PTR(uint32_t))sink, 4, 0, 0);
-            } else if (i < 3) {
-                const int id = tid + 512 * i, r = id >> 2, c = (id & 3) * 64;
-                if (id < 1280 && m0 + r < p.M && n0 + c < p.N) __builtin_amdgcn_global_load_lds((GLB_PTR(const uint32_t))(p.aux + (size_t)(m0 + r) * p.ldaux + n0 + c), (LDS_PTR(uint32_t))sink, 4, 0, 0);
-            }
-        }
-    };
     issue(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -541,8 +511,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_320_kernel(NtParams p) {
     for (int kt = 0; kt < nk; ++kt) {
         const uint32_t so = (uint32_t)(kt & 1) * C_STAGE;
         if (kt + 1 < nk) issue(kt + 1, (kt & 1) ^ 1);
-        if (pf_mode == 3) { if (kt >= pf_at && kt < pf_at + 5) prefetch_epi(kt - pf_at); }
-        else if (kt == pf_at + 2) { for (int i = 0; i < 5; ++i) prefetch_epi(i); }
         TCOW_READ_FRAGS(1, 1, so);
         asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
@@ -826,7 +794,7 @@ int tcow_gemm_nt_bf16(hipStream_t stream, const tcow_gemm_args* a) {
     p.A = (const bf16_t*)a->A; p.lda = a->lda; p.W = (const bf16_t*)a->W; p.ldw = a->ldw;
     p.C = a->C; p.ldc = a->ldc; p.out_f32 = a->out_f32; p.bias = a->bias; p.row_scale = a->row_scale;
     p.resid = a->resid; p.ldr = a->ldr; p.act = a->act; p.aux = (bf16_t*)a->aux; p.ldaux = a->ldaux;
-    p.bias2 = a->bias2; p.row_scale2 = a->row_scale2; p.epi_prefetch = 0;
+    p.bias2 = a->bias2; p.row_scale2 = a->row_scale2;
     p.tiles_m = cdiv(a->M, BM); p.tiles_n = cdiv(a->N, BN);
     TCOW_CHECK_ARG(a->tile == 0 || a->tile == 128 || a->tile == 256 || a->tile == 320, "tcow_gemm_nt(bf16): tile must be 0, 128, 256 or 320 (got %d)", a->tile);
     static const int big = [] { const char* e = getenv("TCOW_GEMM_BIG"); return e ? atoi(e) : 1; }();
@@ -852,10 +820,8 @@ int tcow_gemm_nt_bf16(hipStream_t stream, const tcow_gemm_args* a) {
             else if (a->act == TCOW_ACT_GELU_DSAVE && rows == 0) k = gemm_nt_bf16_320_kernel<EpiCfg<TCOW_ACT_GELU_DSAVE, 0>>;
             else if (a->act == TCOW_ACT_MUL_AUX && rows == 0) k = gemm_nt_bf16_320_kernel<EpiCfg<TCOW_ACT_MUL_AUX, 0>>;
             else if (a->act == TCOW_ACT_GELU && rows == 0) k = gemm_nt_bf16_320_kernel<EpiCfg<TCOW_ACT_GELU, 0>>;
-            static const int epf = [] { const char* e = getenv("TCOW_GEMM_EPF"); return e ? atoi(e) : 3; }();
-            p.epi_prefetch = epf;
-            tcow_ensure_lds(reinterpret_cast<const void*>(k), C_LDS + 2048);
-            hipLaunchKernelGGL(k, dim3(p.tiles_m * p.tiles_n), dim3(512), C_LDS + 2048, stream, p);
+            tcow_ensure_lds(reinterpret_cast<const void*>(k), C_LDS);
+            hipLaunchKernelGGL(k, dim3(p.tiles_m * p.tiles_n), dim3(512), C_LDS, stream, p);
             TCOW_CHECK_LAUNCH();
             return TCOW_OK;
         }

@@ -1,6 +1,6 @@
 """Turn the two rocprofv3 --pmc passes of `bench.py` (FETCH_SIZE, WRITE_SIZE; one counter group per pass, MI355X_MICROARCH.md) into
-profiles/r02_pmc_gemm_nt.json: HBM bytes per launch of the NT-GEMM family, dispatch-weighted over a training step, with the gfx950 x2
-correction on FETCH_SIZE calibrated in the same run on two streaming kernels of known byte count (scale_cast_kernel, ln_fwd_kernel)."""
+profiles/rNN_pmc_gemm_nt.json: HBM bytes per launch of the NT-GEMM family, dispatch-weighted over a training step, with the gfx950 x2
+correction on FETCH_SIZE calibrated in the same run on a streaming kernel of known byte count (ln_fwd_kernel: one f32 [M, D] read)."""
 import collections, csv, glob, hashlib, json, os, re, sys
 
 def load(path, counter):
@@ -24,7 +24,7 @@ def mean(acc, pat):
 # calibration: known streams (f32 [M, D] read = 83.2 MB; bf16 [M, D] write = 41.6 MB)
 sc_f, _ = mean(fetch, r'scale_cast_kernel'); ln_f, _ = mean(fetch, r'ln_fwd_kernel'); sc_w, _ = mean(write, r'scale_cast_kernel')
 known_read = M * D * 4 / 1024.0; known_write = M * D * 2 / 1024.0
-corr_f = [known_read / x for x in (sc_f, ln_f) if x]
+corr_f = [known_read / x for x in (ln_f,) if x]        # (ln_fwd reads exactly one f32 [M, D] matrix; scale_cast runs on other shapes since round 3)
 corr = sum(corr_f) / len(corr_f) if corr_f else 2.0
 f_nt, n_f = mean(fetch, r'gemm_nt_bf16'); w_nt, n_w = mean(write, r'gemm_nt_bf16')
 per = {}

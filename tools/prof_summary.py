@@ -9,3 +9,4 @@ print(f'{"kernel":112s} {"calls":>6s} {"total_us":>12s} {"avg_us":>10s} {"pct":>
 for n, c, t, a, p in rows[: int(sys.argv[2]) if len(sys.argv) > 2 else 25]:
     print(f'{short(n):112s} {c:6d} {t:12.1f} {a:10.2f} {p:6.2f}')
 print('total_us', sum(r[2] for r in rows))
+print('total_launches', sum(r[1] for r in rows), '(all kernels of the traced process, warm-up steps and one-time initialisation included)')
