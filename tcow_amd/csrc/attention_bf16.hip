@@ -661,7 +661,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_res(SeqDesc sd, int nt, const
 }
 
 // ------------------------------------------------------------------------------------------------ persistent forward (spatial, S <= 320)
-// What the timeline of the resident kernel showed (tools/ubench_valu.hip part D, profiles/r03_attn_fwd_timeline.txt): a wave that issues its
+// What the timeline of the resident kernel showed (tools/ubench_valu.hip part D, profiles/r03_ubench_valu.txt): a wave that issues its
 // 24 tile loads up front sits in the ISSUE of those loads for 11 500 cycles (the memory pipe takes ~12 B/clk per CU, all CUs pulling at once),
 // a quarter of the workgroup's life, and 1080 workgroups on 512 slots run as three rounds.  So: ONE persistent 640-thread workgroup per CU
 // walks its (frame, head) pairs; LDS holds TWO K / V images (2 x 80 KiB = all of it) and while pair p is multiplied out of one, every wave

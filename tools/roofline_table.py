@@ -15,7 +15,7 @@ def fam(*pats):
             c += cc; t += tt
     return c, t
 M, D, L, heads, T, S, BQ = 27090, 768, 12, 12, 30, 301, 3
-gemm_fwd = 2.0 * M * (17 * D * D) * L                       # qkv x2, proj x2, temporal_fc, fc1, fc2 per block
+gemm_fwd = 2.0 * M * (16 * D * D) * L                       # qkv x2, folded temporal proj . temporal_fc, spatial proj, fc1, fc2 per block
 head = 2.0 * M * D * D
 nt_flops = 2 * gemm_fwd + 2 * head                           # forward + input gradients (+ mask head both ways)
 tn_flops = gemm_fwd + head
@@ -29,12 +29,12 @@ def row(name, launches, us, flops=None, bytes_=None, note=''):
                (f'{tf:.0f} TFLOP/s = {tf / PF:.3f}' if tf else '-') + ' | ' + (f'{tb:.2f} TB/s = {tb / TB:.2f}' if tb else '-') + f' | {note} |')
 c, t = fam('gemm_nt_bf16'); row('NT GEMM (forward + input gradients, fused epilogues)', c, t, nt_flops, None, 'MFMA-bound main loop, HBM-bound epilogues at K = 768')
 c, t = fam('gemm_tn_bf16'); c2, t2 = fam('slab_reduce4'); row('weight-gradient GEMM (grouped) + folds', c + c2, t + t2, tn_flops, None, 'LDS-bound on the transpose reads')
-c, t = fam('attn_fwd_stream'); row('spatial attention forward', c, t, sp_f, L * (qkv_b + o_b), 'VALU-bound (d = 64: 16 v_exp_f32 per 8 MFMAs)')
-c, t = fam('attn_bwd_dq_stream', 'attn_bwd_dkv_stream'); row('spatial attention backward (dQ + dK/dV)', c, t, 2.5 * sp_f, L * (2 * qkv_b + 2 * o_b + qkv_b), 'VALU / latency-bound (d = 64)')
-c, t = fam('attn_fwd_mfma<false>'); row('temporal attention forward', c, t, tp_f, L * (qkv_b + o_b), 'HBM-bound; the strided row pattern itself streams at 3.9 TB/s (tools/dev_stride_copy.py)')
-c, t = fam('attn_bwd_one_tile'); row('temporal attention backward', c, t, 2.5 * tp_f, L * (2 * qkv_b + 2 * o_b), 'HBM-bound')
+c, t = fam('attn_fwd_stream'); row('spatial attention forward', c, t, sp_f, L * (qkv_b + o_b), 'latency-bound: 2.0 x its HBM floor, traffic at the algorithmic minimum (profiles/r03_attention.md)')
+c, t = fam('attn_bwd_dq_stream', 'attn_bwd_dkv_stream'); row('spatial attention backward (dQ + dK/dV)', c, t, 3.5 * sp_f, L * (3 * qkv_b + 3 * o_b), 'latency-bound (2 - 3 waves per SIMD, dependent chains): 2.1 / 3.1 x the HBM floors')
+c, t = fam('attn_fwd_mfma<false>'); row('temporal attention forward', c, t, tp_f, L * (qkv_b + o_b), 'HBM-bound (81 % of a float4 copy)')
+c, t = fam('attn_bwd_one_tile'); row('temporal attention backward', c, t, 2.5 * tp_f, L * (2 * qkv_b + o_b), 'HBM-bound (84 % of a float4 copy)')
 c, t = fam('ln_fwd_kernel'); row('LayerNorm forward', c, t, None, c * M * D * 6.0, 'HBM-bound')
-c, t = fam('ln_bwd_kernel'); row('LayerNorm backward (+ residual add, + cast of dx on 2 of 3)', c, t, None, c * M * D * (2 + 4 + 4 + 4 + 2 * 2 / 3.0), 'HBM-bound')
+c, t = fam('ln_bwd_kernel'); row('LayerNorm backward (+ residual add, + 16-bit copy of dx for the next GEMM)', c, t, None, c * M * D * (2 + 4 + 4 + 4 + 2.0), 'HBM-bound')
 c, t = fam('adamw_kernel', 'sumsq_kernel'); row('clip + AdamW', c, t, None, 122.1e6 * 32.0, 'HBM-bound')
 c, t = fam('cast_transpose_batched'); row('weight re-cast (bf16 W and W^T)', c, t, None, 120.3e6 * 8.0, 'HBM-bound (transposes)')
 total = sum(tt for _, tt in rows.values())
