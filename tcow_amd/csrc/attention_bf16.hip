@@ -245,9 +245,23 @@ __device__ __forceinline__ void fwd_store_rows(const SeqDesc& sd, long base, int
     if (lse && hi == 0 && q < sd.L) lse[(base + (long)q * sd.pos_stride) * sd.heads + head] = (m + log2f(l)) * 0.6931471805599453f;
 }
 
+// Temporal sequences skip slot 0 of every frame (the cls replica: SeqDesc.offset = 1, inner_stride = 1), but the GEMMs that consume the attention
+// output / produce dqkv read all rows: the wave that owns slot 1 of a clip also defines the slot-0 rows of its head as zero (`sections` blocks of
+// 64 columns, D apart) -- this used to be a separate launch per attention call.
+__device__ __forceinline__ void zero_prev_slot(const SeqDesc& sd, const WorkId& w, long base, bf16_t* __restrict__ dst, long ld, int sections, int lane) {
+    if (w.item % sd.n_inner != 0) return;
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    for (int p0 = 0; p0 < sd.L; p0 += 8) {
+        const int p = p0 + (lane >> 3);
+        if (p < sd.L)
+            for (int sec = 0; sec < sections; ++sec)
+                *reinterpret_cast<uint4*>(dst + (base - 1 + (long)p * sd.pos_stride) * ld + (long)sec * sd.D + w.head * ATT_HD + (lane & 7) * 8) = z;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ forward
 template <bool SHARED>
-__global__ __launch_bounds__(256, 2) void attn_fwd_mfma(SeqDesc sd, int nt, const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse) {
+__global__ __launch_bounds__(256, 2) void attn_fwd_mfma(SeqDesc sd, int nt, const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse, int zero0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -257,6 +271,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma(SeqDesc sd, int nt, cons
     const long base = seq_base(sd, w.item);
     const long ld3 = 3L * sd.D, pse = sd.pos_stride * ld3;
     const bf16_t* qh = qkv + base * ld3 + w.head * ATT_HD;
+    if (!SHARED && zero0) zero_prev_slot(sd, w, base, out, sd.D, 1, lane);
     // wave-private variant (temporal): K, V AND Q tiles of the sequence in LDS.  Q used to be fetched as MFMA fragments straight from
     // global memory -- 16 bytes per lane from 32 different rows per instruction, a quarter of every cache line per request -- and the
     // result went out as 8-byte pieces per lane; both now move as whole 128-byte rows (direct-to-LDS loads in, store_tile_staged out
@@ -1132,7 +1147,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma(SeqDesc sd, int nt, c
 // rowsum(dO * O) = sum_j P_ij (dO_i . V_j) = sum_j P_ij dP_ij comes out of the accumulators the dQ pass holds anyway (lane = query: 16
 // multiply-adds + one half-wave exchange, in f32) -- the O tensor (a sixth of the kernel's bytes, read as 8-byte pieces per lane) is not touched.
 __global__ __launch_bounds__(256, 2) void attn_bwd_one_tile(SeqDesc sd, const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
-                                                         const float* __restrict__ lse, bf16_t* __restrict__ dqkv) {
+                                                         const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int zero0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1143,6 +1158,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_one_tile(SeqDesc sd, const bf
     const long ld3 = 3L * sd.D, pse = sd.pos_stride * ld3, pso = sd.pos_stride * sd.D;
     const bf16_t* qh = qkv + base * ld3 + w.head * ATT_HD;
     const bf16_t* doh = dout + base * sd.D + w.head * ATT_HD;
+    if (zero0) zero_prev_slot(sd, w, base, dqkv, ld3, 3, lane);
     char* qt_ = smem + wave * (4 * TILE_B + 256);
     char* kt = qt_ + TILE_B; char* vt = kt + TILE_B; char* dot_ = vt + TILE_B;
     float2* ldw = reinterpret_cast<float2*>(dot_ + TILE_B);
@@ -1367,6 +1383,13 @@ bool tcow_attn_mfma_supported(const SeqDesc& d, bool shared) {
     return true;      // temporal: wave-private tiles up to T = 64, the streaming kernels beyond
 }
 
+// true when the kernel this shape dispatches to writes the zero rows of the skipped slot 0 itself (wave-private temporal kernels)
+bool tcow_attn_mfma_zeroes_slot0(const SeqDesc& d, bool shared, bool backward) {
+    const int nt = (d.L + 31) / 32;
+    if (shared || d.offset != 1 || d.inner_stride != 1 || d.n_inner < 1) return false;
+    return backward ? nt == 1 : nt <= 2;
+}
+
 int tcow_attn_mfma_fwd(hipStream_t st, const SeqDesc& d, bool shared, const void* qkv, void* out, float* lse) {
     const int nt = (d.L + 31) / 32;
     const int pairs = d.n_outer * d.n_inner * d.heads;
@@ -1385,11 +1408,11 @@ int tcow_attn_mfma_fwd(hipStream_t st, const SeqDesc& d, bool shared, const void
     } else if (shared) {
         const int lds = 2 * nt * TILE_B;
         set_lds_attr(attn_fwd_mfma<true>, lds);
-        hipLaunchKernelGGL(attn_fwd_mfma<true>, dim3(pairs), dim3(256), lds, st, d, nt, (const bf16_t*)qkv, (bf16_t*)out, lse);
+        hipLaunchKernelGGL(attn_fwd_mfma<true>, dim3(pairs), dim3(256), lds, st, d, nt, (const bf16_t*)qkv, (bf16_t*)out, lse, 0);
     } else {
         const int lds = 4 * 3 * nt * TILE_B;
         set_lds_attr(attn_fwd_mfma<false>, lds);
-        hipLaunchKernelGGL(attn_fwd_mfma<false>, dim3(cdiv(pairs, 4)), dim3(256), lds, st, d, nt, (const bf16_t*)qkv, (bf16_t*)out, lse);
+        hipLaunchKernelGGL(attn_fwd_mfma<false>, dim3(cdiv(pairs, 4)), dim3(256), lds, st, d, nt, (const bf16_t*)qkv, (bf16_t*)out, lse, tcow_attn_mfma_zeroes_slot0(d, shared, false) ? 1 : 0);
     }
     TCOW_CHECK_LAUNCH();
     return TCOW_OK;
@@ -1407,7 +1430,7 @@ int tcow_attn_mfma_bwd(hipStream_t st, const SeqDesc& d, bool shared, const void
     if (!shared && nt == 1) {
         const int lds = 4 * (4 * TILE_B + 256);
         set_lds_attr(attn_bwd_one_tile, lds);
-        hipLaunchKernelGGL(attn_bwd_one_tile, dim3(cdiv(pairs, 4)), dim3(256), lds, st, d, (const bf16_t*)qkv, (const bf16_t*)dout, lse, (bf16_t*)dqkv);
+        hipLaunchKernelGGL(attn_bwd_one_tile, dim3(cdiv(pairs, 4)), dim3(256), lds, st, d, (const bf16_t*)qkv, (const bf16_t*)dout, lse, (bf16_t*)dqkv, tcow_attn_mfma_zeroes_slot0(d, shared, true) ? 1 : 0);
         TCOW_CHECK_LAUNCH();
         return TCOW_OK;
     }

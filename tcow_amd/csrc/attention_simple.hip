@@ -308,6 +308,7 @@ static int check_shape(const tcow_attn_shape* s, const char* who) {
 }
 
 bool tcow_attn_mfma_supported(const SeqDesc& d, bool shared);
+bool tcow_attn_mfma_zeroes_slot0(const SeqDesc& d, bool shared, bool backward);
 int tcow_attn_mfma_fwd(hipStream_t st, const SeqDesc& d, bool shared, const void* qkv, void* out, float* lse);
 long tcow_attn_mfma_bwd_workspace_bytes(const SeqDesc& d);
 int tcow_attn_mfma_bwd(hipStream_t st, const SeqDesc& d, bool shared, const void* qkv, const void* out, const void* dout, const float* lse, void* ws,
@@ -328,7 +329,7 @@ static bool use_mfma(const tcow_attn_shape* s, const SeqDesc& d, int spatial) {
 int tcow_attn_fwd_dispatch(hipStream_t st, const tcow_attn_shape* s, int spatial, const void* qkv, void* out, float* lse) {
     const SeqDesc d = spatial ? spatial_desc(s) : temporal_desc(s);
     int rc;
-    if (!spatial || d.offset == 1) {   // slot-0 rows are not produced by the kernels: define them as zero
+    if ((!spatial || d.offset == 1) && !(use_mfma(s, d, spatial) && tcow_attn_mfma_zeroes_slot0(d, spatial != 0, false))) {   // slot-0 rows are not produced by the kernels: define them as zero
         rc = (s->dtype == TCOW_BF16) ? zero_slot0<bf16_t>(st, out, s->D, s, s->D) : zero_slot0<float>(st, out, s->D, s, s->D);
         if (rc) return rc;
     }
@@ -354,7 +355,7 @@ int tcow_attn_bwd_dispatch(hipStream_t st, const tcow_attn_shape* s, int spatial
     const SeqDesc d = spatial ? spatial_desc(s) : temporal_desc(s);
     const long rows = (long)s->B * s->T * s->S;
     int rc;
-    if (!spatial || d.offset == 1) {
+    if ((!spatial || d.offset == 1) && !(use_mfma(s, d, spatial) && tcow_attn_mfma_zeroes_slot0(d, spatial != 0, true))) {
         rc = (s->dtype == TCOW_BF16) ? zero_slot0<bf16_t>(st, dqkv, 3L * s->D, s, 3 * s->D) : zero_slot0<float>(st, dqkv, 3L * s->D, s, 3 * s->D);
         if (rc) return rc;
     }

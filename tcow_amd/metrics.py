@@ -26,18 +26,25 @@ def calculate_metrics_mask_track(output_mask, target_mask, plugin=False):
     has = t_area > 0
     sn = has[:, :, 0]
 
-    def agg(sel, values):                  # masked mean as tensor ops: no host round trip (the reference loops on the host)
-        n = sel.sum()
-        mean = torch.where(n > 0, (values * sel).sum() / n.clamp(min=1), torch.full_like(n, -1.0, dtype=torch.float64))
-        return mean.to(torch.float32), n.to(torch.int32)
-
-    res = {}
-    res['snitch_iou'] = agg(sn, iou[:, :, 0])
-    res['occl_mask_iou'] = agg(has[:, :, 1], iou[:, :, 1]) if Cmt >= 2 else (-1.0, 0)
-    res['cont_mask_iou'] = agg(has[:, :, 2], iou[:, :, 2]) if Cmt >= 3 else (-1.0, 0)
-    res['snitch_during_vis_iou'] = agg(sn & ~has[:, :, 1], iou[:, :, 0]) if Cmt >= 2 else (-1.0, 0)      # metrics.py:70-72
-    res['snitch_during_occl_iou'] = agg(sn & has[:, :, 1], iou[:, :, 0]) if Cmt >= 2 else (-1.0, 0)      # metrics.py:74-76
-    res['snitch_during_cont_iou'] = agg(sn & has[:, :, 2], iou[:, :, 0]) if Cmt >= 3 else (-1.0, 0)      # metrics.py:78-80
+    # the six masked means as ONE set of tensor reductions over a stacked selection (no host round trip; the reference loops on the host)
+    names, sels, vals = [], [], []
+    def want(name, sel, values):
+        names.append(name); sels.append(sel); vals.append(values)
+    want('snitch_iou', sn, iou[:, :, 0])
+    if Cmt >= 2:
+        want('occl_mask_iou', has[:, :, 1], iou[:, :, 1])
+        want('snitch_during_vis_iou', sn & ~has[:, :, 1], iou[:, :, 0])                                   # metrics.py:70-72
+        want('snitch_during_occl_iou', sn & has[:, :, 1], iou[:, :, 0])                                   # metrics.py:74-76
+    if Cmt >= 3:
+        want('cont_mask_iou', has[:, :, 2], iou[:, :, 2])
+        want('snitch_during_cont_iou', sn & has[:, :, 2], iou[:, :, 0])                                   # metrics.py:78-80
+    sel = torch.stack(sels).flatten(1); val = torch.stack(vals).flatten(1)
+    n = sel.sum(dim=1)
+    mean = torch.where(n > 0, (val * sel).sum(dim=1) / n.clamp(min=1), torch.full_like(n, -1.0, dtype=torch.float64)).to(torch.float32)
+    n32 = n.to(torch.int32)
+    res = {k: (-1.0, 0) for k in ('snitch_iou', 'occl_mask_iou', 'cont_mask_iou', 'snitch_during_vis_iou', 'snitch_during_occl_iou', 'snitch_during_cont_iou')}
+    for i, k in enumerate(names):
+        res[k] = (mean[i], n32[i])
     dev = output_mask.device
     out = {}
     for k, (m, n) in res.items():
