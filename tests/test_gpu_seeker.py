@@ -24,10 +24,13 @@ EXACT = {'fp32': FP32_TOL, 'bf16x3': X3_TOL}
 
 
 def bf16_tol(ref):
+    """1.3 x the worst deviation measured over the forward goldens (tools/dev_bf16_ratios.py, round 3): bf16 0.0381 x std (g11_depth24; configs[1]
+    goldens 0.020 / 0.030), binary16 0.0045 x std against the 0.00625 this gives through h16()."""
     return 0.05 * float(np.std(ref))
 
 
 def bf16_flags_tol(ref):
+    """Worst measured 0.0063 x std (g4b); T x 3 samples per clip move by 2x between equivalent roundings (see h16f), hence 1.9 x."""
     return 0.012 * float(np.std(ref))
 
 
@@ -39,7 +42,7 @@ def h16(precision):
 def h16f(precision):
     """The same for the occlusion flags: a clip has only T x 3 of them, and the maximum over so few samples moves by 2x between equivalent
     roundings of the same network (g11_depth24 in fp16: 0.99e-3 with the temporal projection as two GEMMs, 2.2e-3 folded into one; in bf16
-    the other way round, 9.9e-3 vs 4.1e-3 -- tools/dev_fold_fwd.py), so the binary16 bound keeps a factor 1.6 of slack."""
+    the other way round, 9.9e-3 vs 4.1e-3 -- TCOW_FOLD=0 / 1 with tools/dev_bf16_ratios.py), so the binary16 bound keeps a factor 1.6 of slack."""
     return 0.2 if precision == 'fp16' else 1.0
 
 

@@ -3,10 +3,10 @@ import sys, numpy as np, torch
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 from conftest import build_hip_seeker, golden_inputs, load_golden
 from test_oracle_golden import summarise
-for name in ['g1_cfg1_d256', 'g2_ca0', 'g2_ca2', 'g2_ca3', 'g2_cam1', 'g2_normemb_nearest', 'g2_stride1_prenorm', 'g2_stride2', 'g11_depth18', 'g11_depth24', 'g3_mid_T8_96x128', 'g4_cfg2_T30_240x320', 'g8_cfg3_long']:
+for name in ['g1_cfg1_d256', 'g2_ca0', 'g2_ca2', 'g2_ca3', 'g2_cam1', 'g2_normemb_nearest', 'g2_stride1_prenorm', 'g2_stride2', 'g11_depth18', 'g11_depth24', 'g3_mid_T8_96x128', 'g4_cfg2_T30_240x320', 'g4b_cfg2_seed2', 'g8_cfg3_long']:
     meta, g = load_golden(name)
     cfg, sd, rgb, qm = golden_inputs(meta)
-    for prec in ('bf16', 'fp32'):
+    for prec in ('bf16', 'fp16'):
         net = build_hip_seeker(cfg, sd, prec).cuda().eval()
         with torch.no_grad():
             om, fl = net(rgb.cuda(), qm.cuda())
