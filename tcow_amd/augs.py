@@ -11,9 +11,13 @@ column of the cropped image); with them
     ATen's _compute_indices_weights_aa in float32) and the crop / flip / frame selection folded into the source addressing.
 The reference runs slicing + torch.flip + slicing + torchvision Resize as four full-tensor passes per modality on the CPU loader workers.
 
-Out of scope: the photometric operators (ColorJitter / GaussianBlur / Grayscale, augs.py:33-35,175-181) are torchvision's own random
-transforms (their parameters come from torchvision's internal torch-RNG draws); torchvision is not installed here, so no vector of the
-reference's can pin them.  `apply_augs` raises when a parameter set asks for one.
+The photometric operators of the rgb modality (augs.py:33-35,175-181: torchvision ColorJitter(0.2, 0.2, 0.2, 0.1), GaussianBlur(5, sigma in
+[0.1, 3.5]), Grayscale(3)) run as elementwise tensor passes on the device, on the selected frames at source resolution and BEFORE flip / crop /
+resize like the reference (the contrast mean is taken over the whole centre-cropped frame).  torchvision is not installed here, so no vector
+of the reference's can pin them: they follow torchvision's published tensor definitions (functional_tensor: _blend, rgb_to_grayscale
+0.2989 / 0.587 / 0.114, _rgb2hsv / _hsv2rgb, the 5-tap Gaussian with reflect padding) and `photometric_draws` consumes torch's global RNG in
+torchvision's order (randperm(4), then one uniform_ per jitter factor; one uniform_ for sigma).  PARITY UNPINNED against the reference for
+these three operators; tests/test_augs.py checks them against an independent float64 restatement (python's colorsys for the hue path).
 
 `sample_augs_params` draws from numpy's GLOBAL generator in exactly the reference's order, so `np.random.seed(s)` reproduces the
 reference's parameters draw for draw (pinned by tests/golden/g13_augs.npz).
@@ -78,18 +82,24 @@ def sample_augs_params(num_frames_load, num_frames_clip, frame_stride, do_random
                 crop_rect=np.array([d['crop_y1'], d['crop_y2'], d['crop_x1'], d['crop_x2']]) if (do_random_augs and augs_2d) else -np.ones(4))
 
 
-def crop_maps(augs_params, H, W, out_h, out_w, center_crop=False):
-    """Source (frame, row, column) of every (frame, row, column) of the image the final resize sees: centre crop to the output aspect
-    ratio (torchvision CenterCrop: top = round((H - h) / 2)), horizontal flip, fractional crop rectangle (int(y1 * H) : int(y2 * H) on the
-    post-flip image) -- augs.py:150-194.  Returns (frame_idx [Tc] int32, ys [h] int64, xs [w] int64)."""
-    frame_idx = np.asarray(augs_params['frame_inds_clip'], dtype=np.int32)
+def center_rect(H, W, out_h, out_w, center_crop):
+    """(y0, x0, h, w) of the centre crop to the output aspect ratio (augs.py:163-171; torchvision CenterCrop: top = round((H - h) / 2))."""
     y0, x0, h, w = 0, 0, H, W
-    if center_crop:                                                        # augs.py:163-171
+    if center_crop:
         cur, want = W / H, out_w / out_h
         if cur > want:
             cw = int(H * want); x0 = int(round((W - cw) / 2.0)); w = cw
         elif cur < want:
             ch = int(W / want); y0 = int(round((H - ch) / 2.0)); h = ch
+    return y0, x0, h, w
+
+
+def crop_maps(augs_params, H, W, out_h, out_w, center_crop=False):
+    """Source (frame, row, column) of every (frame, row, column) of the image the final resize sees: centre crop to the output aspect
+    ratio (torchvision CenterCrop: top = round((H - h) / 2)), horizontal flip, fractional crop rectangle (int(y1 * H) : int(y2 * H) on the
+    post-flip image) -- augs.py:150-194.  Returns (frame_idx [Tc] int32, ys [h] int64, xs [w] int64)."""
+    frame_idx = np.asarray(augs_params['frame_inds_clip'], dtype=np.int32)
+    y0, x0, h, w = center_rect(H, W, out_h, out_w, center_crop)
     ys = np.arange(h, dtype=np.int64) + y0                                 # source row of each row of the current image
     xs = np.arange(w, dtype=np.int64) + x0
     if bool(augs_params['horz_flip']):                                     # augs.py:184-185
@@ -165,17 +175,130 @@ def resize_clip_aa(frames, frame_idx, ys, xs, out_h, out_w):
                          t(xmin, torch.int32), t(xsz, torch.int32), t(wx, torch.float32), kx, out_h, out_w)
 
 
-def apply_augs(modalities, augs_params, out_h, out_w, center_crop=False):
-    """augs.py:137-207: dict name -> (C, Tv, H, W) CUDA tensor (uint8 / float32); tensors with fewer than 4 dimensions pass through."""
-    if augs_params.get('color_jitter') or augs_params.get('rgb_blur') or augs_params.get('rgb_grayscale'):
-        if any('rgb' in name for name in modalities):
-            raise NotImplementedError('ColorJitter / GaussianBlur / Grayscale (augs.py:175-181) are torchvision operators: out of scope (see module docstring)')
+# ---- photometric operators of the rgb modality (augs.py:175-181), torchvision's tensor definitions on (T, 3, h, w) float images in [0, 1]
+def rgb_to_gray(img):
+    return (0.2989 * img[:, 0] + 0.587 * img[:, 1] + 0.114 * img[:, 2]).unsqueeze(1)
+
+
+def _blend(a, b, ratio):
+    return (ratio * a + (1.0 - ratio) * b).clamp(0.0, 1.0)
+
+
+def adjust_brightness(img, f):
+    return _blend(img, 0.0 * img, f)
+
+
+def adjust_contrast(img, f):
+    return _blend(img, rgb_to_gray(img).mean(dim=(-3, -2, -1), keepdim=True), f)       # one mean per frame
+
+
+def adjust_saturation(img, f):
+    return _blend(img, rgb_to_gray(img), f)
+
+
+def adjust_hue(img, shift):
+    import torch
+    r, g, b = img[:, 0], img[:, 1], img[:, 2]
+    maxc = torch.maximum(torch.maximum(r, g), b); minc = torch.minimum(torch.minimum(r, g), b)
+    eq = maxc == minc
+    cr = maxc - minc
+    one = torch.ones_like(maxc)
+    sat = cr / torch.where(eq, one, maxc)
+    div = torch.where(eq, one, cr)
+    rc, gc, bc = (maxc - r) / div, (maxc - g) / div, (maxc - b) / div
+    is_r, is_g = maxc == r, maxc == g
+    h = is_r * (bc - gc) + (is_g & ~is_r) * (2.0 + rc - bc) + (~is_g & ~is_r) * (4.0 + gc - rc)
+    h = torch.fmod(h / 6.0 + 1.0, 1.0)
+    h = (h + shift) % 1.0
+    i = torch.floor(h * 6.0)
+    f = h * 6.0 - i
+    i = i.to(torch.int32) % 6
+    v = maxc
+    p = (v * (1.0 - sat)).clamp(0.0, 1.0); q = (v * (1.0 - sat * f)).clamp(0.0, 1.0); t = (v * (1.0 - sat * (1.0 - f))).clamp(0.0, 1.0)
+    pick = lambda opts: sum((i == k) * o for k, o in enumerate(opts))                   # (select by sextant, as torchvision's mask einsum)
+    return torch.stack([pick((v, q, p, p, t, v)), pick((t, v, v, q, p, p)), pick((p, p, t, v, v, q))], dim=1)
+
+
+def color_jitter(img, order, brightness, contrast, saturation, hue):
+    """torchvision ColorJitter.forward with its drawn parameters made explicit: the four adjustments in `order` (0 brightness, 1 contrast,
+    2 saturation, 3 hue), one parameter set for all frames of the clip (the reference passes the (T, 3, H, W) stack in one call)."""
+    for k in order:
+        k = int(k)
+        if k == 0: img = adjust_brightness(img, brightness)
+        elif k == 1: img = adjust_contrast(img, contrast)
+        elif k == 2: img = adjust_saturation(img, saturation)
+        else: img = adjust_hue(img, hue)
+    return img
+
+
+def gaussian_blur5(img, sigma):
+    """torchvision gaussian_blur(kernel_size=5, sigma): taps exp(-0.5 (x / sigma)^2) on x = -2..2, normalised, separable, reflect padding."""
+    import torch
+    x = torch.linspace(-2.0, 2.0, 5, dtype=img.dtype, device=img.device)
+    k = torch.exp(-0.5 * (x / sigma) ** 2); k = k / k.sum()
+    pad = torch.nn.functional.pad(img, (2, 2, 2, 2), mode='reflect')
+    H, W = img.shape[-2:]
+    hor = sum(k[j] * pad[..., :, j:j + W] for j in range(5))                            # (T, 3, H + 4, W)
+    return sum(k[j] * hor[..., j:j + H, :] for j in range(5))
+
+
+def grayscale3(img):
+    return rgb_to_gray(img).expand(-1, 3, -1, -1).contiguous()
+
+
+def photometric_draws(augs_params):
+    """The parameters torchvision's transforms draw from torch's GLOBAL generator when the reference calls them (augs.py:175-181), in the
+    same order: ColorJitter.get_params = randperm(4) then uniform_ for brightness, contrast, saturation in [0.8, 1.2] and hue in [-0.1, 0.1];
+    GaussianBlur.get_params = uniform_(0.1, 3.5)."""
+    import torch
+    out = {}
+    if augs_params.get('color_jitter'):
+        order = torch.randperm(4).tolist()
+        u = lambda lo, hi: float(torch.empty(1).uniform_(lo, hi))
+        out['color_jitter'] = (order, u(0.8, 1.2), u(0.8, 1.2), u(0.8, 1.2), u(-0.1, 0.1))
+    if augs_params.get('rgb_blur'):
+        out['rgb_blur'] = float(torch.empty(1).uniform_(0.1, 3.5))
+    if augs_params.get('rgb_grayscale'):
+        out['rgb_grayscale'] = True
+    return out
+
+
+def apply_photometric(img, draws):
+    """(T, 3, h, w) float image stack -> the same after ColorJitter / GaussianBlur / Grayscale, in the reference's order (augs.py:176-181)."""
+    if 'color_jitter' in draws:
+        img = color_jitter(img, *draws['color_jitter'])
+    if 'rgb_blur' in draws:
+        img = gaussian_blur5(img, draws['rgb_blur'])
+    if draws.get('rgb_grayscale'):
+        img = grayscale3(img)
+    return img
+
+
+def apply_augs(modalities, augs_params, out_h, out_w, center_crop=False, draws_in=None):
+    """augs.py:137-207: dict name -> (C, Tv, H, W) CUDA tensor (uint8 / float32); tensors with fewer than 4 dimensions pass through.
+    `draws_in`: the photometric parameters (photometric_draws) when the caller wants them fixed; drawn from torch's global RNG otherwise."""
     out = {}
     for name, fr in modalities.items():
         if fr.dim() < 4:
             out[name] = fr.clone()
             continue
         C, Tv, H, W = fr.shape
+        if 'rgb' in name and (augs_params.get('color_jitter') or augs_params.get('rgb_blur') or augs_params.get('rgb_grayscale')):
+            # photometric operators act on the selected, centre-cropped frames at source resolution, before flip / crop / resize (augs.py:175-201)
+            import torch
+            if not fr.is_floating_point():
+                raise NotImplementedError('photometric augmentation of integer rgb frames (the reference feeds float frames in [0, 1], data_kubric.py)')
+            draws = draws_in if draws_in is not None else photometric_draws(augs_params)
+            fi, ys, xs = crop_maps(augs_params, H, W, out_h, out_w, center_crop)
+            y0, x0, h, w = center_rect(H, W, out_h, out_w, center_crop)
+            sel = fr[:, torch.as_tensor(np.asarray(fi, dtype=np.int64), device=fr.device)][:, :, y0:y0 + h, x0:x0 + w].float()
+            img = apply_photometric(sel.permute(1, 0, 2, 3), draws).permute(1, 0, 2, 3).contiguous()
+            ident = np.arange(len(fi), dtype=np.int32)
+            if len(ys) == out_h and len(xs) == out_w:
+                out[name] = gather_clip(img, ident, (ys - y0).astype(np.int32), (xs - x0).astype(np.int32))
+            else:
+                out[name] = resize_clip_aa(img, ident, ys - y0, xs - x0, out_h, out_w)
+            continue
         if 'segm' in name or 'mask' in name:                                # integer valued: NEAREST (augs.py:196-198)
             fi, sy, sx = index_maps(augs_params, H, W, out_h, out_w, center_crop)
             out[name] = gather_clip(fr.contiguous(), fi, sy, sx)

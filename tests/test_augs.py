@@ -131,7 +131,67 @@ def test_resize_aa_kernel_vs_reference_pipeline(cuda):
         assert np.abs(dd.astype(np.float64).sum(axis=(2, 3)) - g[f'{tag}::depth_sum']).max() < 2e-4 * oh * ow
         n += 1
     assert n == 14
-    # the photometric operators are torchvision's: asking for one is an error, not a silent skip
+    # integer rgb frames with a photometric operator: an error, not a silent skip (the reference feeds float frames in [0, 1])
     p = _smooth_params([96, 128, 60, 80, 0, 1, 1, 3000]); p['color_jitter'] = True
     with pytest.raises(NotImplementedError):
-        augs.apply_augs({'rgb': torch.rand(3, 14, 96, 128, device=cuda)}, p, 60, 80)
+        augs.apply_augs({'rgb': torch.zeros(3, 14, 96, 128, dtype=torch.uint8, device=cuda)}, p, 60, 80)
+
+
+def test_photometric_operators_follow_the_published_definitions():
+    """augs.py:33-35,175-181: torchvision ColorJitter / GaussianBlur / Grayscale (not installed here: PARITY UNPINNED against the reference).
+    Checked against independent float64 restatements of torchvision's documented tensor semantics: blends written out in numpy, python's
+    colorsys for the RGB -> HSV -> RGB hue path, scipy's sampled Gaussian with mirror boundary for the blur."""
+    import colorsys
+    from scipy import ndimage
+    g = torch.Generator().manual_seed(5)
+    img = torch.rand(3, 3, 24, 20, generator=g)
+    img[0, :, :4, :4] = 0.5                                     # grey patch: max == min, the hue path's degenerate branch
+    x = img.double().numpy()
+    gray = (0.2989 * x[:, 0] + 0.587 * x[:, 1] + 0.114 * x[:, 2])[:, None]
+    assert np.abs(augs.adjust_brightness(img, 1.15).numpy() - np.clip(1.15 * x, 0, 1)).max() < 1e-6
+    assert np.abs(augs.adjust_contrast(img, 0.85).numpy() - np.clip(0.85 * x + 0.15 * gray.mean(axis=(1, 2, 3), keepdims=True), 0, 1)).max() < 1e-6
+    assert np.abs(augs.adjust_saturation(img, 1.2).numpy() - np.clip(1.2 * x - 0.2 * gray, 0, 1)).max() < 1e-6
+    assert np.abs(augs.grayscale3(img).numpy() - np.repeat(gray, 3, axis=1)).max() < 1e-6
+    for shift in (0.07, -0.1):
+        got = augs.adjust_hue(img, shift).numpy()
+        want = np.empty_like(x)
+        for t in range(3):
+            for i in range(24):
+                for j in range(20):
+                    h, sat, v = colorsys.rgb_to_hsv(*x[t, :, i, j])
+                    want[t, :, i, j] = colorsys.hsv_to_rgb((h + shift) % 1.0, sat, v)
+        assert np.abs(got - want).max() < 2e-6, shift
+    for sigma in (0.1, 0.9, 3.5):
+        want = ndimage.gaussian_filter1d(ndimage.gaussian_filter1d(x, sigma, axis=-1, mode='mirror', radius=2), sigma, axis=-2, mode='mirror', radius=2)
+        assert np.abs(augs.gaussian_blur5(img, sigma).numpy() - want).max() < 1e-6, sigma
+    # the order of the four adjustments is part of the draw; one parameter set serves every frame of the clip
+    a = augs.color_jitter(img, [1, 0, 3, 2], 1.1, 0.9, 1.15, 0.05)
+    b = augs.adjust_saturation(augs.adjust_hue(augs.adjust_brightness(augs.adjust_contrast(img, 0.9), 1.1), 0.05), 1.15)
+    assert torch.equal(a, b)
+    # draws: torch's global generator in torchvision's order (ColorJitter.get_params, GaussianBlur.get_params), inside the constructor's ranges
+    torch.manual_seed(11)
+    d = augs.photometric_draws({'color_jitter': True, 'rgb_blur': True, 'rgb_grayscale': True})
+    torch.manual_seed(11)
+    order = torch.randperm(4).tolist(); u = [float(torch.empty(1).uniform_(lo, hi)) for lo, hi in ((0.8, 1.2), (0.8, 1.2), (0.8, 1.2), (-0.1, 0.1), (0.1, 3.5))]
+    assert d['color_jitter'] == (order, u[0], u[1], u[2], u[3]) and d['rgb_blur'] == u[4] and d['rgb_grayscale'] is True
+    assert augs.photometric_draws({'color_jitter': False, 'rgb_blur': False, 'rgb_grayscale': False}) == {}
+
+
+@pytest.mark.gpu
+def test_apply_augs_with_photometric_operators(cuda):
+    """The rgb modality through apply_augs with all three photometric operators on: equal to the operators applied to the selected,
+    centre-cropped frames at source resolution followed by flip / crop / ATen's antialiased resize (the reference's order, augs.py:175-201)."""
+    g = torch.Generator().manual_seed(8)
+    for (H, W, oh, ow, cc, flip) in [(96, 128, 60, 80, 0, 1), (120, 200, 60, 80, 1, 0), (64, 64, 64, 64, 0, 1)]:
+        p = _smooth_params([H, W, oh, ow, cc, flip, 1, 4000 + H]); p.update(color_jitter=True, rgb_blur=True, rgb_grayscale=(H == 120))
+        rgb = torch.rand(3, 14, H, W, generator=g)
+        draws = {'color_jitter': ([2, 0, 1, 3], 1.12, 0.88, 1.07, -0.04), 'rgb_blur': 1.3}
+        if H == 120: draws['rgb_grayscale'] = True
+        got = augs.apply_augs({'rgb': rgb.to(cuda)}, p, oh, ow, center_crop=bool(cc), draws_in=draws)['rgb'].cpu()
+        fi, ys, xs = augs.crop_maps(p, H, W, oh, ow, bool(cc))
+        y0, x0, h, w = augs.center_rect(H, W, oh, ow, bool(cc))
+        sel = rgb[:, torch.as_tensor(np.asarray(fi, dtype=np.int64))][:, :, y0:y0 + h, x0:x0 + w]
+        img = augs.apply_photometric(sel.permute(1, 0, 2, 3), draws)
+        img = img[:, :, torch.as_tensor(ys - y0)][:, :, :, torch.as_tensor(xs - x0)]
+        want = torch.nn.functional.interpolate(img, size=(oh, ow), mode='bilinear', antialias=True, align_corners=False).permute(1, 0, 2, 3)
+        assert got.shape == want.shape and float((got - want).abs().max()) < 1e-5, (H, W)
