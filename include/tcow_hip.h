@@ -86,7 +86,8 @@ typedef struct {
     const float* resid; long ldr;
     int act;
     void* aux; long ldaux;
-    int tile;              /* 0 = choose by shape; 128 / 256 / 320 = force that bf16 NT tile kernel (tests and A/B runs) */
+    int tile;              /* 0 = choose by shape; 128 / 256 / 320 = force that bf16 NT tile kernel (tests and A/B runs); 8320 / 8256 = the
+                              phase-structured kernel of gemm_p8.hip with 320- / 256-row tiles (plain epilogues, K % 64 == 0 only) */
     const float* bias2;        /* second bias [N] with its own row scale (may be NULL) */
     const float* row_scale2;   /* [M] or NULL */
 } tcow_gemm_args;
