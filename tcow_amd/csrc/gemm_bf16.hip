@@ -431,7 +431,14 @@ constexpr int C_WTILE = C_BN * 128;             // 32 KiB
 constexpr int C_STAGE = C_ATILE + C_WTILE;      // 72 KiB
 constexpr int C_LDS = 2 * C_STAGE;              // 144 KiB
 
-template <typename E>
+// ML = 1: the main loop of gemm_p8.hip (16x16x32 MFMAs on 1 KiB subtiles, four phases per K tile, wave rows staggered by a barrier) in front of the
+// same epilogues: the accumulators then sit as [10 row blocks of 16][4 column blocks of 16] and only the staging step differs.
+#ifdef TCOW_FP16
+#define TCOW_MFMA_16x16x32_H16 __builtin_amdgcn_mfma_f32_16x16x32_f16
+#else
+#define TCOW_MFMA_16x16x32_H16 __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#endif
+template <typename E, int ML = 0>
 __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_320_kernel(NtParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -443,6 +450,112 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_320_kernel(NtParams p) {
     const int pid = xcd_remap(blockIdx.x, nblk);
     const int pm = pid / p.tiles_n, pn = pid - pm * p.tiles_n;
     const int m0 = pm * C_BM, n0 = pn * C_BN;
+    f32x16 acc[5][2];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    f32x4 acc16[10][4];
+#pragma unroll
+    for (int i = 0; i < 10; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc16[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (ML == 1) {
+        // (see gemm_p8.hip for the layout and the ordering argument; BM = 320: 20 row blocks, 5 per wave and phase)
+        constexpr int ARB = 20, RBH = 5, A_PLANE = ARB * 1024, KH = A_PLANE + 16 * 1024, KTILE = 2 * KH, NA = 3;
+        const int wr = wm, wc = wn;
+        const bf16_t* a_base = p.A + (size_t)m0 * p.lda;
+        const bf16_t* w_base = p.W + (size_t)n0 * p.ldw;
+        uint32_t a_src[NA], w_src[2];
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int r = (wave + 8 * j) * 16 + (lane >> 2);
+            const int rr = m0 + r < p.M ? r : p.M - 1 - m0;
+            a_src[j] = (uint32_t)(rr * p.lda + ((lane & 3) ^ ((lane >> 4) & 3)) * 8);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int r = (wave + 8 * j) * 16 + (lane >> 2);
+            const int rr = n0 + r < p.N ? r : p.N - 1 - n0;
+            w_src[j] = (uint32_t)(rr * p.ldw + ((lane & 3) ^ ((lane >> 4) & 3)) * 8);
+        }
+        const bool a_last = wave + 16 < ARB;
+        auto load_a = [&](int kt, int kh) {
+            char* dst = smem + (kt & 1) * KTILE + kh * KH;
+            const bf16_t* g = a_base + (size_t)kt * 64 + kh * 32;
+            glds16(g + a_src[0], dst + wave * 1024); glds16(g + a_src[1], dst + (wave + 8) * 1024);
+            if (a_last) glds16(g + a_src[2], dst + (wave + 16) * 1024);
+        };
+        auto load_w = [&](int kt, int kh) {
+            char* dst = smem + (kt & 1) * KTILE + kh * KH + A_PLANE;
+            const bf16_t* g = w_base + (size_t)kt * 64 + kh * 32;
+            glds16(g + w_src[0], dst + wave * 1024); glds16(g + w_src[1], dst + (wave + 8) * 1024);
+        };
+        typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
+        const uint32_t lds0_ = (uint32_t)(uintptr_t)(LDS_PTR(char))smem;
+        const uint32_t frag_off = (uint32_t)((lane & 15) * 64 + (((lane >> 4) ^ (((lane & 15) >> 2) & 3)) << 4));
+        const uint32_t a_ad = lds0_ + (wr * (ARB / 2)) * 1024 + frag_off;
+        const uint32_t w_ad = lds0_ + A_PLANE + (wc * 4) * 1024 + frag_off;
+        u32x4_ fa[2][RBH], fw[2][4];
+#define P8_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
+        auto read_a = [&](u32x4_ (&f)[RBH], uint32_t base, int ri) {
+            if (ri == 0) { P8_DSR(f[0], base, 0); P8_DSR(f[1], base, 1024); P8_DSR(f[2], base, 2048); P8_DSR(f[3], base, 3072); P8_DSR(f[4], base, 4096); }
+            else { P8_DSR(f[0], base, 5120); P8_DSR(f[1], base, 6144); P8_DSR(f[2], base, 7168); P8_DSR(f[3], base, 8192); P8_DSR(f[4], base, 9216); }
+        };
+        auto read_w = [&](u32x4_ (&f)[4], uint32_t base) { P8_DSR(f[0], base, 0); P8_DSR(f[1], base, 1024); P8_DSR(f[2], base, 2048); P8_DSR(f[3], base, 3072); };
+        auto mfma_block = [&](const u32x4_ (&fA)[RBH], const u32x4_ (&fW)[4], int ri) {
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < RBH; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc16[ri * RBH + i][j] = TCOW_MFMA_16x16x32_H16(__builtin_bit_cast(bf16x8, fW[j]), __builtin_bit_cast(bf16x8, fA[i]), acc16[ri * RBH + i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        };
+        auto wait_vm = [&](bool all) {
+            if (all) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (a_last) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        };
+#define P8_PHASE_TAIL(set_a, set_w, ri)                                                                   \
+        do {                                                                                              \
+            __builtin_amdgcn_s_barrier();                                                                 \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                           \
+            __builtin_amdgcn_sched_barrier(0);                                                            \
+            mfma_block(fa[set_a], fw[set_w], ri);                                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                            \
+            __builtin_amdgcn_s_barrier();                                                                 \
+        } while (0)
+        const int nk = p.K / 64;
+        load_a(0, 0); load_w(0, 0); load_a(0, 1); load_w(0, 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (wr == 1) __builtin_amdgcn_s_barrier();
+        for (int kt = 0; kt < nk; ++kt) {
+            const uint32_t bo = (uint32_t)(kt & 1) * KTILE;
+            const bool more = kt + 1 < nk;
+            read_w(fw[0], w_ad + bo); read_a(fa[0], a_ad + bo, 0);
+            if (more) load_a(kt + 1, 0);
+            P8_PHASE_TAIL(0, 0, 0);
+            read_a(fa[1], a_ad + bo, 1);
+            if (more) load_w(kt + 1, 0);
+            wait_vm(!more);
+            P8_PHASE_TAIL(1, 0, 1);
+            read_w(fw[1], w_ad + bo + KH); read_a(fa[0], a_ad + bo + KH, 0);
+            if (more) load_a(kt + 1, 1);
+            P8_PHASE_TAIL(0, 1, 0);
+            read_a(fa[1], a_ad + bo + KH, 1);
+            if (more) load_w(kt + 1, 1);
+            wait_vm(!more);
+            P8_PHASE_TAIL(1, 1, 1);
+        }
+        if (wr == 0) __builtin_amdgcn_s_barrier();
+#undef P8_DSR
+#undef P8_PHASE_TAIL
+    } else {
     // wave w issues wave-loads 5w..5w+4 of A (8 rows x 128 B each) and 4w..4w+3 of W per stage; 32-bit element offsets from the
     // tile's first row keep the nine addresses in nine registers
     const bf16_t* a_base = p.A + (size_t)m0 * p.lda;
@@ -462,14 +575,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_320_kernel(NtParams p) {
         const int rr = n0 + r < p.N ? r : p.N - 1 - n0;
         w_src[j] = (uint32_t)(rr * p.ldw + c * 8);
     }
-    f32x16 acc[5][2];
-#pragma unroll
-    for (int i = 0; i < 5; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
     const int nk = p.K / BK;
     auto issue = [&](int kt, int stage) {
         char* sa = smem + stage * C_STAGE;
@@ -536,6 +641,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_320_kernel(NtParams p) {
 #undef TCOW_READ_FRAGS
 #undef TCOW_MFMA10
 
+    }
     // ---- epilogue: every wave stages its 160 x 64 tile through a private 16 KiB LDS region, 64 rows at a time (the last pass 32),
     // and writes full 64-column row segments.  No workgroup barrier: a wave's LDS operations execute in order.
     // (explicit passes: a loop over the pass index that the optimizer declines to unroll would index acc[] dynamically -> scratch)
@@ -549,6 +655,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_320_kernel(NtParams p) {
     const int gn = n0 + wn * 64 + c4;
     const bool col_ok = gn < p.N;
     const float4 b4 = (p.bias && col_ok) ? ld4(p.bias + gn) : make_float4(0.f, 0.f, 0.f, 0.f);
+    // ML = 1: band b = row blocks 2b, 2b+1; lane (l & 15, l >> 4) owns row l & 15 of a block and columns 16 cb + 4 (l >> 4) .. + 3
+#define TCOW_STAGE(b, ii) do { if constexpr (ML == 1) stage_band16(b, ii); else stage_band(acc[b], ii); } while (0)
+    auto stage_band16 = [&](int b, int ii) {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                const f32x4 v = acc16[2 * b + rb][cb];
+                *reinterpret_cast<float4*>(ct + (ii * 32 + rb * 16 + (lane & 15)) * CT_LD + cb * 16 + 4 * (lane >> 4)) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+    };
     auto stage_band = [&](const f32x16 (&a)[2], int ii) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -618,18 +735,18 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_320_kernel(NtParams p) {
                 }
             }
         };
-        fetch(oa, 0); stage_band(acc[0], 0);
-        fetch(ob, 1); stage_band(acc[1], 1);
+        fetch(oa, 0); TCOW_STAGE(0, 0);
+        fetch(ob, 1); TCOW_STAGE(1, 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         apply(oa, 0, 0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        fetch(oa, 2); stage_band(acc[2], 0);
+        fetch(oa, 2); TCOW_STAGE(2, 0);
         apply(ob, 1, 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        fetch(ob, 3); stage_band(acc[3], 1);
+        fetch(ob, 3); TCOW_STAGE(3, 1);
         apply(oa, 2, 0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        fetch(oa, 4); stage_band(acc[4], 0);
+        fetch(oa, 4); TCOW_STAGE(4, 0);
         apply(ob, 3, 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         apply(oa, 4, 0);
@@ -670,27 +787,27 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_320_kernel(NtParams p) {
                 }
             }
         };
-        stage_band(acc[0], 0); stage_band(acc[1], 1);
+        TCOW_STAGE(0, 0); TCOW_STAGE(1, 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         rows8(0, 8);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        stage_band(acc[2], 0); stage_band(acc[3], 1);
+        TCOW_STAGE(2, 0); TCOW_STAGE(3, 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         rows8(64, 8);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        stage_band(acc[4], 0);
+        TCOW_STAGE(4, 0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         rows8(128, 4);
     } else {
-        stage_band(acc[0], 0); stage_band(acc[1], 1);
+        TCOW_STAGE(0, 0); TCOW_STAGE(1, 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (col_ok) epi_rows<16, E>(p, ct, CT_LD, b4, mrow, lane >> 4, 4, c4, gn);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        stage_band(acc[2], 0); stage_band(acc[3], 1);
+        TCOW_STAGE(2, 0); TCOW_STAGE(3, 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (col_ok) epi_rows<16, E>(p, ct, CT_LD, b4, mrow + 64, lane >> 4, 4, c4, gn);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        stage_band(acc[4], 0);
+        TCOW_STAGE(4, 0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (col_ok) epi_rows<8, E>(p, ct, CT_LD, b4, mrow + 128, lane >> 4, 4, c4, gn);
     }
@@ -809,17 +926,24 @@ int tcow_gemm_nt_bf16(hipStream_t stream, const tcow_gemm_args* a) {
             // epilogue specialisations for the combinations the path uses; anything else takes the run-time-configured kernel
             typedef void (*Kern)(NtParams);
             const int rows = (a->row_scale ? 1 : 0) | (a->resid ? 2 : 0) | (a->bias2 ? 4 : 0);
-            Kern k = gemm_nt_bf16_320_kernel<EpiAny>;
+            static const int ml = [] { const char* e = getenv("TCOW_GEMM_ML"); return e ? atoi(e) : 1; }();
             const bool vec8 = a->N % 8 == 0 && a->ldc % 8 == 0 && a->ldr % 8 == 0 && a->ldaux % 8 == 0;   // the row-operand epilogues move 8 columns per lane
-            if (!vec8) { /* run-time configured kernel */ }
-            else if (a->act == TCOW_ACT_NONE && rows == 0) k = gemm_nt_bf16_320_kernel<EpiCfg<TCOW_ACT_NONE, 0>>;
-            else if (a->act == TCOW_ACT_NONE && rows == 1) k = gemm_nt_bf16_320_kernel<EpiCfg<TCOW_ACT_NONE, 1>>;
-            else if (a->act == TCOW_ACT_NONE && rows == 2) k = gemm_nt_bf16_320_kernel<EpiCfg<TCOW_ACT_NONE, 2>>;
-            else if (a->act == TCOW_ACT_NONE && rows == 3) k = gemm_nt_bf16_320_kernel<EpiCfg<TCOW_ACT_NONE, 3>>;
-            else if (a->act == TCOW_ACT_NONE && rows == 7) k = gemm_nt_bf16_320_kernel<EpiCfg<TCOW_ACT_NONE, 7>>;
-            else if (a->act == TCOW_ACT_GELU_DSAVE && rows == 0) k = gemm_nt_bf16_320_kernel<EpiCfg<TCOW_ACT_GELU_DSAVE, 0>>;
-            else if (a->act == TCOW_ACT_MUL_AUX && rows == 0) k = gemm_nt_bf16_320_kernel<EpiCfg<TCOW_ACT_MUL_AUX, 0>>;
-            else if (a->act == TCOW_ACT_GELU && rows == 0) k = gemm_nt_bf16_320_kernel<EpiCfg<TCOW_ACT_GELU, 0>>;
+#define TCOW_PICK(R)                                                                                                                         \
+            do {                                                                                                                             \
+                k = gemm_nt_bf16_320_kernel<EpiAny, R>;                                                                                      \
+                if (!vec8) { /* run-time configured kernel */ }                                                                              \
+                else if (a->act == TCOW_ACT_NONE && rows == 0) k = gemm_nt_bf16_320_kernel<EpiCfg<TCOW_ACT_NONE, 0>, R>;                     \
+                else if (a->act == TCOW_ACT_NONE && rows == 1) k = gemm_nt_bf16_320_kernel<EpiCfg<TCOW_ACT_NONE, 1>, R>;                     \
+                else if (a->act == TCOW_ACT_NONE && rows == 2) k = gemm_nt_bf16_320_kernel<EpiCfg<TCOW_ACT_NONE, 2>, R>;                     \
+                else if (a->act == TCOW_ACT_NONE && rows == 3) k = gemm_nt_bf16_320_kernel<EpiCfg<TCOW_ACT_NONE, 3>, R>;                     \
+                else if (a->act == TCOW_ACT_NONE && rows == 7) k = gemm_nt_bf16_320_kernel<EpiCfg<TCOW_ACT_NONE, 7>, R>;                     \
+                else if (a->act == TCOW_ACT_GELU_DSAVE && rows == 0) k = gemm_nt_bf16_320_kernel<EpiCfg<TCOW_ACT_GELU_DSAVE, 0>, R>;         \
+                else if (a->act == TCOW_ACT_MUL_AUX && rows == 0) k = gemm_nt_bf16_320_kernel<EpiCfg<TCOW_ACT_MUL_AUX, 0>, R>;               \
+                else if (a->act == TCOW_ACT_GELU && rows == 0) k = gemm_nt_bf16_320_kernel<EpiCfg<TCOW_ACT_GELU, 0>, R>;                     \
+            } while (0)
+            Kern k;
+            if (ml && a->K % 64 == 0) TCOW_PICK(1); else TCOW_PICK(0);
+#undef TCOW_PICK
             tcow_ensure_lds(reinterpret_cast<const void*>(k), C_LDS);
             hipLaunchKernelGGL(k, dim3(p.tiles_m * p.tiles_n), dim3(512), C_LDS, stream, p);
             TCOW_CHECK_LAUNCH();
