@@ -12,10 +12,11 @@
 //    phases 2 and 4 (the planes a phase pair reads were requested >= 3 phases earlier).  Wave row 1 runs one barrier behind wave row 0, so
 //    on every SIMD (which hosts wave w and w + 4) one wave is in its MFMA block while the other is in its read / load part.
 //  * Plain epilogue only (bias, 16-bit or f32 output) in this version; the fused-epilogue GEMMs stay on gemm_bf16.hip.
-//  * STATUS (round 3, profiles/r03_gemm_cube.txt): correct (same tests as the shipped kernels) and at parity with them -- 1017-1106 TFLOP/s at
-//    4096^3 with BM = 256 (shipped 256 tile: 1019-1029), 1058-1156 on the path's K = 2304 / 3072 -> 768 shapes with BM = 320 (shipped: 1117-1196),
-//    slower at K = 768 (direct 8-byte stores in this epilogue) -- not at the 1320 the guide quotes for its template.  OFF by default:
-//    TCOW_GEMM_P8=1 (or tile = 8320 / 8256 in tcow_gemm_args) routes plain-epilogue problems here.
+//  * STATUS (round 3): the same loop with BM = 320 is now the DEFAULT main loop of gemm_nt_bf16_320_kernel (gemm_bf16.hip, template argument
+//    ML = 1) in front of that kernel's LDS-staged fused epilogues -- every path shape 3-13 % faster than the two-stage loop it replaced.  This
+//    file keeps the stand-alone plain-epilogue form (BM = 320 or 256, direct 8-byte stores: slower than the shipped kernel at K = 768) for
+//    measurements on square problems (profiles/r03_gemm_cube.txt: 1106-1188 TFLOP/s at 4096^3) and as the reference for the layout and the
+//    ordering argument.  TCOW_GEMM_P8=1 (or tile = 8320 / 8256 in tcow_gemm_args) routes plain-epilogue problems here.
 #include <stdint.h>
 #include <stdlib.h>
 
