@@ -37,6 +37,9 @@ struct P8Params {
     void* C; long ldc; int out_f32;
     const float* bias;
     int tiles_m, tiles_n;
+#ifdef TCOW_P8_DBG
+    long long* dbg; int dbg_kt;      // tools/ubench_gemm.hip: shader-clock stamps of one K tile, 32 per wave
+#endif
 };
 
 __device__ __forceinline__ int p8_xcd_remap(int bid, int nblk) {
@@ -53,6 +56,11 @@ __device__ __forceinline__ void p8_glds16(const void* gsrc, char* lds_wave_base)
 }
 
 typedef uint32_t p8_u32x4 __attribute__((ext_vector_type(4)));
+#ifdef TCOW_P8_DBG
+#define P8_STAMP(i) do { if (kt == p.dbg_kt && lane == 0) p.dbg[(blockIdx.x * 8 + wave) * 32 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define P8_STAMP(i) do { } while (0)
+#endif
 
 template <int BM>
 __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(P8Params p) {
@@ -146,14 +154,19 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(P8Params p) {
         else if (n_a == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     };
-#define P8_PHASE_TAIL(set_a, set_w, ri)                                                                   \
+#define P8_PHASE_TAIL(set_a, set_w, ri, st)                                                               \
     do {                                                                                                  \
+        P8_STAMP(st);                                                                                     \
         __builtin_amdgcn_s_barrier();                                                                     \
+        P8_STAMP(st + 1);                                                                                 \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                               \
         __builtin_amdgcn_sched_barrier(0);                                                                \
+        P8_STAMP(st + 2);                                                                                 \
         mfma_block(fa[set_a], fw[set_w], ri);                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                                \
+        P8_STAMP(st + 3);                                                                                 \
         __builtin_amdgcn_s_barrier();                                                                     \
+        P8_STAMP(st + 4);                                                                                 \
     } while (0)
 
     const int nk = p.K / 64;
@@ -164,24 +177,27 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(P8Params p) {
     for (int kt = 0; kt < nk; ++kt) {
         const uint32_t bo = (uint32_t)(kt & 1) * KTILE;
         const bool more = kt + 1 < nk;
+        P8_STAMP(0);
         // phase 1: row half 0, k half 0
         read_w(fw[0], w_ad + bo); read_a(fa[0], a_ad + bo, 0);
         if (more) load_a(kt + 1, 0);
-        P8_PHASE_TAIL(0, 0, 0);
+        P8_PHASE_TAIL(0, 0, 0, 1);
         // phase 2: row half 1, k half 0; afterwards the k-half-1 planes of this K tile must be complete
         read_a(fa[1], a_ad + bo, 1);
         if (more) load_w(kt + 1, 0);
+        P8_STAMP(6);
         wait_vm(!more);
-        P8_PHASE_TAIL(1, 0, 1);
+        P8_PHASE_TAIL(1, 0, 1, 7);
         // phase 3: row half 0, k half 1
         read_w(fw[1], w_ad + bo + KH); read_a(fa[0], a_ad + bo + KH, 0);
         if (more) load_a(kt + 1, 1);
-        P8_PHASE_TAIL(0, 1, 0);
+        P8_PHASE_TAIL(0, 1, 0, 12);
         // phase 4: row half 1, k half 1; afterwards the k-half-0 planes of the next K tile must be complete
         read_a(fa[1], a_ad + bo + KH, 1);
         if (more) load_w(kt + 1, 1);
+        P8_STAMP(17);
         wait_vm(!more);
-        P8_PHASE_TAIL(1, 1, 1);
+        P8_PHASE_TAIL(1, 1, 1, 18);
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();
 #undef P8_DSR
