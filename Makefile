@@ -51,6 +51,12 @@ build/ubench_gemm: tools/ubench_gemm.hip $(CSRC)/gemm_p8.hip $(CSRC)/common.h
 
 ubench_gemm: build/ubench_gemm
 
+build/ubench_tn: tools/ubench_tn.hip $(CSRC)/gemm_bf16.hip $(CSRC)/common.h
+	@mkdir -p build
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -Wno-unused-result -x hip $< -o $@
+
+ubench_tn: build/ubench_tn
+
 build/ubench_valu: tools/ubench_valu.hip $(CSRC)/attention_bf16.hip $(CSRC)/common.h
 	@mkdir -p build
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fno-honor-nans -fno-slp-vectorize -Wno-unused-result -x hip $< -o $@

@@ -1196,6 +1196,28 @@ __device__ __forceinline__ void tn256_body(const TnParams& p, const int pid, cha
             glds16(xs, sx + q * 1024);
         }
     };
+    // Full stages of interior tiles (every stage but a slice's last, every tile of the path's weight shapes) take 32-bit lane offsets computed
+    // once + one uniform base per stage; the general form above (row / column guards through a zero page: 64-bit address arithmetic and a
+    // select per load) cost ~ a fifth of a stage in issue time.
+    uint32_t y_src[4], x_src[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int q = wave * 4 + j;
+        y_src[j] = (uint32_t)((q * 2 + lrow) * p.ldy + ycol[j & 1]);
+        x_src[j] = (uint32_t)((q * 2 + lrow) * p.ldx + xcol[j & 1]);
+    }
+    const bool interior = n0 + T2 <= p.N && k0 + T2 <= p.K;
+    auto issue_fast = [&](int mt, int stage) {
+        char* sy = smem + stage * T2_STAGE;
+        char* sx = sy + T2_TILE;
+        const bf16_t* yb = p.dY + (size_t)mt * p.ldy;
+        const bf16_t* xb = p.X + (size_t)mt * p.ldx;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            glds16(yb + y_src[j], sy + (wave * 4 + j) * 1024);
+            glds16(xb + x_src[j], sx + (wave * 4 + j) * 1024);
+        }
+    };
 
     // transpose-read addressing (constant over the loop)
     const int q16 = lane & 15, g16 = (lane >> 4) & 1, hi = lane >> 5;
@@ -1214,11 +1236,12 @@ __device__ __forceinline__ void tn256_body(const TnParams& p, const int pid, cha
 
     // column-sum duty (bias gradient): column cs_col of the dY tile, rows [cs_r0, cs_r1) of every stage; the tiles_k workgroups
     // that share a dY tile split its 64 rows between them, and each between its two thread halves
+    // (thread t sums the eight columns of 16-byte chunk t & 31 over rows cs_lo + (t >> 5), + 16, ...: at most four b128 reads per stage instead
+    // of up to 32 two-byte ones; the sixteen row groups are folded through LDS once, after the loop)
     const int cs_col = tid & 255;
     const int cs_lo = pk * p.rows_per_pk, cs_hi = (cs_lo + p.rows_per_pk < T2_MC) ? cs_lo + p.rows_per_pk : T2_MC;
-    const int cs_mid = cs_lo + (cs_hi - cs_lo + 1) / 2;
-    const int cs_r0 = (tid >> 8) ? cs_mid : cs_lo, cs_r1 = (tid >> 8) ? cs_hi : (cs_mid < cs_hi ? cs_mid : cs_hi);
-    float colsum = 0.f;
+    const int cs_chunk = tid & 31, cs_rg = tid >> 5;
+    float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     const int nmt = (mend - mbeg + T2_MC - 1) / T2_MC;
     if (nmt > 0) {
@@ -1259,7 +1282,10 @@ __device__ __forceinline__ void tn256_body(const TnParams& p, const int pid, cha
     for (int it = 0; it < nmt; ++it) {
         const int stage = it & 1;
         const uint32_t so = (uint32_t)stage * T2_STAGE;
-        if (it + 1 < nmt) issue(mbeg + (it + 1) * T2_MC, stage ^ 1);
+        if (it + 1 < nmt) {
+            const int mt = mbeg + (it + 1) * T2_MC;
+            if (interior && mt + T2_MC <= mend) issue_fast(mt, stage ^ 1); else issue(mt, stage ^ 1);
+        }
         const char* sy = smem + stage * T2_STAGE;
         TCOW_TN_READ(1, 1, so);
         asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
@@ -1278,10 +1304,14 @@ __device__ __forceinline__ void tn256_body(const TnParams& p, const int pid, cha
         __builtin_amdgcn_sched_barrier(0);
         TCOW_TN_MFMA8(1);
         if (p.bias_part) {
-#pragma unroll 4
-            for (int r = cs_r0; r < cs_r1; ++r) {
-                const int off = r * T2_ROWB + ((((cs_col >> 3) ^ ((r & 3) << 2))) << 4) + (cs_col & 7) * 2;
-                colsum += bf2f(*reinterpret_cast<const bf16_t*>(sy + off));
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int r = cs_lo + cs_rg + 16 * u;
+                if (r < cs_hi) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(sy + r * T2_ROWB + ((cs_chunk ^ ((r & 3) << 2)) << 4));
+                    csum[0] += bflo(v.x); csum[1] += bfhi(v.x); csum[2] += bflo(v.y); csum[3] += bfhi(v.y);
+                    csum[4] += bflo(v.z); csum[5] += bfhi(v.z); csum[6] += bflo(v.w); csum[7] += bfhi(v.w);
+                }
             }
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -1293,8 +1323,23 @@ __device__ __forceinline__ void tn256_body(const TnParams& p, const int pid, cha
 #undef TCOW_TN_READ
 #undef TCOW_TN_FRAG
 #undef TCOW_TN_MFMA8
-    if (p.bias_part && n0 + cs_col < p.N)
-        p.bias_part[(((size_t)z * p.tiles_k + pk) * 2 + (tid >> 8)) * p.N + n0 + cs_col] = colsum;
+    if (p.bias_part) {
+        // fold the sixteen row groups (the operand stages are dead: the loop ended on a barrier): red[rg][256 columns]
+        float* red = reinterpret_cast<float*>(smem);
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[cs_rg * 256 + cs_chunk * 8 + e] = csum[e];
+        __syncthreads();
+        if (n0 + cs_col < p.N) {
+            float t = 0.f;
+            if (tid < 256) {
+#pragma unroll
+                for (int g = 0; g < 16; ++g) t += red[g * 256 + cs_col];
+            }
+            p.bias_part[(((size_t)z * p.tiles_k + pk) * 2 + (tid >> 8)) * p.N + n0 + cs_col] = t;      // (the second half-row of the table stays zero)
+        }
+        __syncthreads();
+    }
 
     float* out = p.slab + (size_t)z * p.N * p.K;
     const int l31 = lane & 31;
