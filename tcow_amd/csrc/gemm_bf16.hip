@@ -1152,6 +1152,13 @@ __device__ __forceinline__ bf16x8 tr_frag512(const char* tile, int off0) {
 }
 
 namespace {
+#ifdef TCOW_TN_DBG      // tools/ubench_tn.hip: shader-clock stamps of one stage of the weight-gradient loop, 16 per wave (each stamp drains the LDS
+                        // queue -- s_memtime returns through lgkmcnt -- so the pipelined read phases come out longer than they are)
+__device__ long long* g_tn_dbg; __device__ int g_tn_dbg_it;
+#define TN_STAMP(i) do { if (it == g_tn_dbg_it && lane == 0) g_tn_dbg[(blockIdx.x * 8 + wave) * 16 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define TN_STAMP(i) do { } while (0)
+#endif
 // one workgroup of the 256-tile weight-gradient GEMM `p`: pid = slice * tiles + tile
 __device__ __forceinline__ void tn256_body(const TnParams& p, const int pid, char* smem) {
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1282,27 +1289,34 @@ __device__ __forceinline__ void tn256_body(const TnParams& p, const int pid, cha
     for (int it = 0; it < nmt; ++it) {
         const int stage = it & 1;
         const uint32_t so = (uint32_t)stage * T2_STAGE;
+        TN_STAMP(0);
         if (it + 1 < nmt) {
             const int mt = mbeg + (it + 1) * T2_MC;
             if (interior && mt + T2_MC <= mend) issue_fast(mt, stage ^ 1); else issue(mt, stage ^ 1);
         }
+        TN_STAMP(1);
         const char* sy = smem + stage * T2_STAGE;
         TCOW_TN_READ(1, 1, so);
         asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
+        TN_STAMP(2);
         TCOW_TN_MFMA8(0);
         TCOW_TN_READ(0, 2, so);
         asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
+        TN_STAMP(3);
         TCOW_TN_MFMA8(1);
         TCOW_TN_READ(1, 3, so);
         asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
+        TN_STAMP(4);
         TCOW_TN_MFMA8(0);
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
+        TN_STAMP(5);
         TCOW_TN_MFMA8(1);
+        TN_STAMP(6);
         if (p.bias_part) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -1314,8 +1328,11 @@ __device__ __forceinline__ void tn256_body(const TnParams& p, const int pid, cha
                 }
             }
         }
+        TN_STAMP(7);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        TN_STAMP(8);
         __syncthreads();
+        TN_STAMP(9);
         if (it + 1 < nmt) TCOW_TN_READ(0, 0, so ^ (uint32_t)T2_STAGE);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

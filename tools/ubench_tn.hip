@@ -1,4 +1,7 @@
 // Phase timeline of the shipped weight-gradient loop (gemm_bf16.hip built with TCOW_TN_DBG).   make ubench_tn && ./build/ubench_tn
+// CAVEAT: every stamp is an s_memtime whose result comes back through lgkmcnt, i.e. it drains the wave's LDS queue -- this loop keeps the next
+// k-step's transpose reads in flight under the MFMAs, so the stamped build runs ~40 % slower and its read phases are inflated.  Good for
+// spotting phases that are long for OTHER reasons (it pointed at the load-address arithmetic and the bias column sums), not for budgets.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
