@@ -10,7 +10,9 @@ namespace {
 
 constexpr int LN_MAXV = 8;  // float4 per lane -> D <= 64*4*8 = 2048; kernels are instantiated for NV = 1, 2, 3, 4, 8 (NV = 3 is D = 768)
 
-template <typename T, int NV>
+// FULL: D == 256 * NV, i.e. every lane owns a float4 in every one of the NV passes -- the per-pass lane guards (divergent-branch code and a basic
+// block per pass, which keep hipcc from issuing a row's loads together) are compiled out.  D = 768 / 512 / 1024 take this form.
+template <typename T, int NV, bool FULL>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(int rows, int D, const float* __restrict__ x, long ldx, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float eps, T* __restrict__ y, long ldy,
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out) {
@@ -25,7 +27,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(int rows, int D, const floa
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = lane + i * 64;
-        if (c < nv) { g[i] = ld4(gamma + c * 4); b[i] = ld4(beta + c * 4); nx[i] = ld4(x + (size_t)row * ldx + c * 4); }
+        if (FULL || c < nv) { g[i] = ld4(gamma + c * 4); b[i] = ld4(beta + c * 4); nx[i] = ld4(x + (size_t)row * ldx + c * 4); }
     }
     for (; row < rows; row += rstep) {
         float4 v[NV];
@@ -33,13 +35,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(int rows, int D, const floa
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = lane + i * 64;
-            if (c < nv) { v[i] = nx[i]; s += (v[i].x + v[i].y) + (v[i].z + v[i].w); }
+            if (FULL || c < nv) { v[i] = nx[i]; s += (v[i].x + v[i].y) + (v[i].z + v[i].w); }
         }
         if (row + rstep < rows) {
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
                 const int c = lane + i * 64;
-                if (c < nv) nx[i] = ld4(x + (size_t)(row + rstep) * ldx + c * 4);
+                if (FULL || c < nv) nx[i] = ld4(x + (size_t)(row + rstep) * ldx + c * 4);
             }
         }
         const float mean = wave_sum(s) / (float)D;
@@ -47,7 +49,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(int rows, int D, const floa
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = lane + i * 64;
-            if (c < nv) {
+            if (FULL || c < nv) {
                 const float a = v[i].x - mean, bb = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
                 q += (a * a + bb * bb) + (cc * cc + d * d);
             }
@@ -61,7 +63,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(int rows, int D, const floa
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = lane + i * 64;
-            if (c < nv) {
+            if (FULL || c < nv) {
                 float4 o;
                 o.x = (v[i].x - mean) * rstd * g[i].x + b[i].x; o.y = (v[i].y - mean) * rstd * g[i].y + b[i].y;
                 o.z = (v[i].z - mean) * rstd * g[i].z + b[i].z; o.w = (v[i].w - mean) * rstd * g[i].w + b[i].w;
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(int rows, int D, const floa
 // dx_out = dres + dx (the gradient arriving through the residual connection is added here).
 // dgamma / dbeta partial sums: each wave keeps per-column partials over the rows it visits, the block folds its
 // 4 waves through LDS and writes one partial row per block; tcow_launch_slab_reduce finishes the sum.
-template <typename T, int NV, bool CSUM>
+template <typename T, int NV, bool CSUM, bool FULL>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int D, const T* __restrict__ dy, long lddy, const float* __restrict__ x, long ldx,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const float* __restrict__ dres, long lddres,
@@ -93,7 +95,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int D, const T* _
         gsum[i] = make_float4(0.f, 0.f, 0.f, 0.f); bsum[i] = gsum[i];
         if (CSUM) csum[i] = gsum[i];
         const int c = lane + i * 64;
-        gam[i] = (c < nv) ? ld4(gamma + c * 4) : gsum[i];
+        gam[i] = (FULL || c < nv) ? ld4(gamma + c * 4) : gsum[i];
     }
     // Software-pipelined over the rows a wave visits: the loads of the NEXT row are issued before this row's results are stored.
     // (vmcnt counts stores too: a "load, compute, store" loop body makes every row wait for the previous row's stores.)
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int D, const T* _
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = lane + i * 64;
-            if (c < nv) {
+            if (FULL || c < nv) {
                 xn[i] = ld4(x + (size_t)r * ldx + c * 4);
                 dn[i] = ld4(dy + (size_t)r * lddy + c * 4);
                 if (dres) rn[i] = ld4(dres + (size_t)r * lddres + c * 4);
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int D, const T* _
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = lane + i * 64;
-            if (c < nv) {
+            if (FULL || c < nv) {
                 const float4 xv = xn[i], d = dn[i];
                 rr[i] = rn[i];
                 xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int D, const T* _
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = lane + i * 64;
-            if (c < nv) {
+            if (FULL || c < nv) {
                 float4 o = make_float4(rs * (g[i].x - m1 - xh[i].x * m2), rs * (g[i].y - m1 - xh[i].y * m2), rs * (g[i].z - m1 - xh[i].z * m2),
                                        rs * (g[i].w - m1 - xh[i].w * m2));
                 if (dres) { o.x += rr[i].x; o.y += rr[i].y; o.z += rr[i].z; o.w += rr[i].w; }
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int D, const T* _
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = lane + i * 64;
-            if (c < nv) *reinterpret_cast<float4*>(red + (size_t)wave * D + c * 4) = qn == 0 ? gsum[i] : (qn == 1 ? bsum[i] : csum[CSUM ? i : 0]);
+            if (FULL || c < nv) *reinterpret_cast<float4*>(red + (size_t)wave * D + c * 4) = qn == 0 ? gsum[i] : (qn == 1 ? bsum[i] : csum[CSUM ? i : 0]);
         }
         __syncthreads();
         for (int i = threadIdx.x; i < D; i += 256)
@@ -191,12 +193,14 @@ int tcow_layernorm_fwd(void* stream, int dtype, int rows, int D, const float* x,
     const dim3 grid(fblocks), block(256);
     if (dtype != TCOW_BF16 && dtype != TCOW_F32) { tcow_set_error("tcow_layernorm_fwd: unknown dtype %d", dtype); return TCOW_ERR_INVALID_ARG; }
     const int nvl = (D / 4 + 63) / 64;
-#define LN_FWD(NVV)                                                                                                                               \
+#define LN_FWD(NVV, FULLV)                                                                                                                               \
     do {                                                                                                                                          \
-        if (dtype == TCOW_BF16) hipLaunchKernelGGL((ln_fwd_kernel<bf16_t, NVV>), grid, block, 0, (hipStream_t)stream, rows, D, x, ldx, gamma, beta, eps, (bf16_t*)y, ldy, mean, rstd); \
-        else hipLaunchKernelGGL((ln_fwd_kernel<float, NVV>), grid, block, 0, (hipStream_t)stream, rows, D, x, ldx, gamma, beta, eps, (float*)y, ldy, mean, rstd); \
+        if (dtype == TCOW_BF16) hipLaunchKernelGGL((ln_fwd_kernel<bf16_t, NVV, FULLV>), grid, block, 0, (hipStream_t)stream, rows, D, x, ldx, gamma, beta, eps, (bf16_t*)y, ldy, mean, rstd); \
+        else hipLaunchKernelGGL((ln_fwd_kernel<float, NVV, FULLV>), grid, block, 0, (hipStream_t)stream, rows, D, x, ldx, gamma, beta, eps, (float*)y, ldy, mean, rstd); \
     } while (0)
-    if (nvl <= 1) LN_FWD(1); else if (nvl == 2) LN_FWD(2); else if (nvl == 3) LN_FWD(3); else if (nvl == 4) LN_FWD(4); else LN_FWD(8);
+    const bool full = D == 256 * nvl && nvl <= 4;
+    if (full) { if (nvl == 1) LN_FWD(1, true); else if (nvl == 2) LN_FWD(2, true); else if (nvl == 3) LN_FWD(3, true); else LN_FWD(4, true); }
+    else if (nvl <= 1) LN_FWD(1, false); else if (nvl == 2) LN_FWD(2, false); else if (nvl == 3) LN_FWD(3, false); else if (nvl == 4) LN_FWD(4, false); else LN_FWD(8, false);
 #undef LN_FWD
     TCOW_CHECK_LAUNCH();
     return TCOW_OK;
@@ -222,14 +226,16 @@ int tcow_layernorm_bwd(void* stream, int dtype, int rows, int D, const void* dy,
     const size_t lds = want_param_grads ? (size_t)4 * D * 4 : 0;
     if (dtype != TCOW_BF16 && dtype != TCOW_F32) { tcow_set_error("tcow_layernorm_bwd: unknown dtype %d", dtype); return TCOW_ERR_INVALID_ARG; }
     const int nvl = (D / 4 + 63) / 64;
-#define LN_BWD(NVV)                                                                                                                               \
+#define LN_BWD(NVV, FULLV)                                                                                                                               \
     do {                                                                                                                                          \
-        if (dtype == TCOW_BF16 && csum) hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, NVV, true>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, rows, D, (const bf16_t*)dy, lddy, x, ldx, mean, rstd, gamma, dres, lddres, dx, lddx, part, (bf16_t*)dx_cast, lddx_cast, cast_row_scale, colsum_row_scale); \
-        else if (dtype == TCOW_BF16) hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, NVV, false>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, rows, D, (const bf16_t*)dy, lddy, x, ldx, mean, rstd, gamma, dres, lddres, dx, lddx, part, (bf16_t*)dx_cast, lddx_cast, cast_row_scale, colsum_row_scale); \
-        else if (csum) hipLaunchKernelGGL((ln_bwd_kernel<float, NVV, true>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, rows, D, (const float*)dy, lddy, x, ldx, mean, rstd, gamma, dres, lddres, dx, lddx, part, (float*)dx_cast, lddx_cast, cast_row_scale, colsum_row_scale); \
-        else hipLaunchKernelGGL((ln_bwd_kernel<float, NVV, false>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, rows, D, (const float*)dy, lddy, x, ldx, mean, rstd, gamma, dres, lddres, dx, lddx, part, (float*)dx_cast, lddx_cast, cast_row_scale, colsum_row_scale); \
+        if (dtype == TCOW_BF16 && csum) hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, NVV, true, FULLV>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, rows, D, (const bf16_t*)dy, lddy, x, ldx, mean, rstd, gamma, dres, lddres, dx, lddx, part, (bf16_t*)dx_cast, lddx_cast, cast_row_scale, colsum_row_scale); \
+        else if (dtype == TCOW_BF16) hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, NVV, false, FULLV>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, rows, D, (const bf16_t*)dy, lddy, x, ldx, mean, rstd, gamma, dres, lddres, dx, lddx, part, (bf16_t*)dx_cast, lddx_cast, cast_row_scale, colsum_row_scale); \
+        else if (csum) hipLaunchKernelGGL((ln_bwd_kernel<float, NVV, true, FULLV>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, rows, D, (const float*)dy, lddy, x, ldx, mean, rstd, gamma, dres, lddres, dx, lddx, part, (float*)dx_cast, lddx_cast, cast_row_scale, colsum_row_scale); \
+        else hipLaunchKernelGGL((ln_bwd_kernel<float, NVV, false, FULLV>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, rows, D, (const float*)dy, lddy, x, ldx, mean, rstd, gamma, dres, lddres, dx, lddx, part, (float*)dx_cast, lddx_cast, cast_row_scale, colsum_row_scale); \
     } while (0)
-    if (nvl <= 1) LN_BWD(1); else if (nvl == 2) LN_BWD(2); else if (nvl == 3) LN_BWD(3); else if (nvl == 4) LN_BWD(4); else LN_BWD(8);
+    const bool full = D == 256 * nvl && nvl <= 4;
+    if (full) { if (nvl == 1) LN_BWD(1, true); else if (nvl == 2) LN_BWD(2, true); else if (nvl == 3) LN_BWD(3, true); else LN_BWD(4, true); }
+    else if (nvl <= 1) LN_BWD(1, false); else if (nvl == 2) LN_BWD(2, false); else if (nvl == 3) LN_BWD(3, false); else if (nvl == 4) LN_BWD(4, false); else LN_BWD(8, false);
 #undef LN_BWD
     TCOW_CHECK_LAUNCH();
     if (want_param_grads) {
