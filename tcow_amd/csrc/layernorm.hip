@@ -111,7 +111,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int D, const T* _
             if (FULL || c < nv) {
                 xn[i] = ld4(x + (size_t)r * ldx + c * 4);
                 dn[i] = ld4(dy + (size_t)r * lddy + c * 4);
-                if (dres) rn[i] = ld4(dres + (size_t)r * lddres + c * 4);
+            }
+        }
+        if (dres) {                                              // (one uniform branch per row, not one per pass: the passes stay one basic block)
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = lane + i * 64;
+                if (FULL || c < nv) rn[i] = ld4(dres + (size_t)r * lddres + c * 4);
             }
         }
     };
@@ -139,19 +145,28 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int D, const T* _
         float* dxr = dx + (size_t)row * lddx;
         const float cs_row = (dxc && cscale) ? cscale[row] : 1.0f;
         const float ss_row = (CSUM && sumscale) ? sumscale[row] : 1.0f;
+        float4 o[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            o[i] = make_float4(rs * (g[i].x - m1 - xh[i].x * m2), rs * (g[i].y - m1 - xh[i].y * m2), rs * (g[i].z - m1 - xh[i].z * m2), rs * (g[i].w - m1 - xh[i].w * m2));
+        if (dres) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) { o[i].x += rr[i].x; o[i].y += rr[i].y; o[i].z += rr[i].z; o[i].w += rr[i].w; }
+        }
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = lane + i * 64;
             if (FULL || c < nv) {
-                float4 o = make_float4(rs * (g[i].x - m1 - xh[i].x * m2), rs * (g[i].y - m1 - xh[i].y * m2), rs * (g[i].z - m1 - xh[i].z * m2),
-                                       rs * (g[i].w - m1 - xh[i].w * m2));
-                if (dres) { o.x += rr[i].x; o.y += rr[i].y; o.z += rr[i].z; o.w += rr[i].w; }
-                st4(dxr + c * 4, o);
-                if (CSUM) { csum[i].x = fmaf(ss_row, o.x, csum[i].x); csum[i].y = fmaf(ss_row, o.y, csum[i].y); csum[i].z = fmaf(ss_row, o.z, csum[i].z); csum[i].w = fmaf(ss_row, o.w, csum[i].w); }
-                if (dxc) {       // the same gradient as the next GEMM's operand: dtype(dx * row scale), saves a separate cast pass
-                    const float cs = cs_row;
-                    st4(dxc + (size_t)row * lddxc + c * 4, make_float4(o.x * cs, o.y * cs, o.z * cs, o.w * cs));
-                }
+                st4(dxr + c * 4, o[i]);
+                if (CSUM) { csum[i].x = fmaf(ss_row, o[i].x, csum[i].x); csum[i].y = fmaf(ss_row, o[i].y, csum[i].y); csum[i].z = fmaf(ss_row, o[i].z, csum[i].z); csum[i].w = fmaf(ss_row, o[i].w, csum[i].w); }
+            }
+        }
+        if (dxc) {           // the same gradient as the next GEMM's operand: dtype(dx * row scale), saves a separate cast pass
+            const float cs = cs_row;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = lane + i * 64;
+                if (FULL || c < nv) st4(dxc + (size_t)row * lddxc + c * 4, make_float4(o[i].x * cs, o[i].y * cs, o[i].z * cs, o[i].w * cs));
             }
         }
     }
