@@ -239,7 +239,7 @@ __device__ __forceinline__ void gemm_x3_body(const F32Params& p, const int bid, 
     const int c4 = (lane & 15) * 4, r4 = lane >> 4;
     const int gn = n0 + wn * 64 + c4;
     const bool v16 = p.slab ? ((reinterpret_cast<uintptr_t>(p.slab) & 15) == 0 && (p.N & 3) == 0)
-                            : (((reinterpret_cast<uintptr_t>(p.C) | reinterpret_cast<uintptr_t>(p.resid) | reinterpret_cast<uintptr_t>(p.aux)) & 15) == 0 &&
+                            : (((reinterpret_cast<uintptr_t>(p.C) | reinterpret_cast<uintptr_t>(p.resid) | reinterpret_cast<uintptr_t>(p.aux) | reinterpret_cast<uintptr_t>(p.bias2)) & 15) == 0 &&
                                ((p.ldc | p.ldr | p.ldaux) & 3) == 0);
     float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (!p.slab && p.bias) {

@@ -16,10 +16,13 @@ over replicas (loss.py:356-369), so the MI355X counterpart is plain gradient ave
   * parameters the step does not touch (model.norm.*, flag_post_linear.* in Kubric training) have no gradient on
     any rank and are simply not part of any bucket -- no unused-parameter handshake is needed.
 """
+import collections
 import os
 
 import torch
 import torch.distributed as dist
+
+STATS_WINDOW = 256      # finish() calls whose exposed-wait measurements are kept (a training run must not grow per-step state forever)
 
 
 def init_distributed(backend=None):
@@ -43,13 +46,16 @@ class GradSync:
     per completed bucket and drains it (`finish()`) before handing the gradients to autograd, so after `loss.backward()`
     every param.grad is already the mean over ranks."""
 
-    def __init__(self, world_size=None, group=None, overlap=None, bucket_dtype='f32'):
+    def __init__(self, world_size=None, group=None, overlap=None, bucket_dtype='f32', force=False):
         """overlap: launch each bucket's all-reduce as soon as the backward has produced it (default; `TCOW_DDP_OVERLAP=0` or
         overlap=False issues them all after the last bucket instead -- the fallback should RCCL kernels holding CUs during the
         backward cost more than they hide).
         bucket_dtype: 'f32' moves the f32 buckets as they are (488.6 MB per step at ViT-B); 'bf16' all-reduces a bf16 copy of each
         bucket (244.3 MB: half the per-link xGMI time) and widens the mean back into the f32 bucket -- master weights, moments and
-        the clip norm stay f32 (AdamW reads the f32 bucket)."""
+        the clip norm stay f32 (AdamW reads the f32 bucket).
+        force: run the collectives even in a group of one rank (the single-GPU RCCL check of tests/test_gpu_ddp.py: values unchanged, but the
+        library is loaded and AVG / async wait() / the event bracketing of finish() execute on hardware)."""
+        self.force = bool(force)
         self.group = group
         self.world = world_size if world_size is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
         self.overlap = (os.environ.get('TCOW_DDP_OVERLAP', '1') != '0') if overlap is None else bool(overlap)
@@ -61,9 +67,11 @@ class GradSync:
         self.pending = []
         self.deferred = []
         self.bytes = 0
-        self.launched = []
-        self.steps = 0                  # finish() calls
-        self._exposed = []              # per finish(): (start event, end event) on the compute stream, or seconds on the CPU path
+        self.launched = []              # bucket tags of the CURRENT / most recent backward (reset when the next one publishes its first bucket)
+        self.steps = 0                  # finish() calls since reset_stats()
+        self._nbuckets = 0              # buckets published since reset_stats()
+        self._fresh = True
+        self._exposed = collections.deque(maxlen=STATS_WINDOW)   # per finish(): (start event, end event) on the compute stream, or seconds on the CPU path
 
     def _launch(self, flat):
         op = dist.ReduceOp.AVG if self.native_avg else dist.ReduceOp.SUM
@@ -72,9 +80,12 @@ class GradSync:
         self.pending.append((dist.all_reduce(wire, op=op, group=self.group, async_op=True), flat, wire))
 
     def __call__(self, name, flat):
-        if self.world <= 1 or flat.numel() == 0:
+        if (self.world <= 1 and not self.force) or flat.numel() == 0:
             return
+        if self._fresh:
+            self.launched = []; self._fresh = False
         self.launched.append(name)
+        self._nbuckets += 1
         if self.overlap:
             self._launch(flat)
         else:
@@ -88,6 +99,7 @@ class GradSync:
             self._launch(flat)
         self.deferred = []
         self.steps += 1
+        self._fresh = True
         if not self.pending:
             return
         on_gpu = self.pending[0][1].is_cuda
@@ -103,18 +115,18 @@ class GradSync:
             self._exposed.append(time.perf_counter() - t0)
 
     def reset_stats(self):
-        self.bytes = 0; self.launched = []; self.steps = 0; self._exposed = []
+        self.bytes = 0; self.launched = []; self.steps = 0; self._nbuckets = 0; self._fresh = True; self._exposed.clear()
 
     def stats(self):
         """Since the last reset_stats(): all-reduce bytes and buckets per step and the mean exposed wait per step in ms (synchronises)."""
         n = max(self.steps, 1)
         ms = 0.0
-        for e in self._exposed:
+        for e in self._exposed:                                   # (the last STATS_WINDOW steps; bench runs are shorter than the window)
             if isinstance(e, tuple):
                 e[1].synchronize(); ms += e[0].elapsed_time(e[1])
             else:
                 ms += e * 1e3
-        return dict(allreduce_exposed_ms=ms / n, allreduce_bytes=self.bytes // n, buckets=len(self.launched) // n, bucket_dtype=self.bucket_dtype,
+        return dict(allreduce_exposed_ms=ms / max(len(self._exposed), 1), allreduce_bytes=self.bytes // n, buckets=self._nbuckets // n, bucket_dtype=self.bucket_dtype,
                     overlap=self.overlap, native_avg=self.native_avg)
 
     def _drain(self):
@@ -127,12 +139,23 @@ class GradSync:
         self.pending = []
 
 
-def broadcast_parameters(module, src=0):
-    """One-time weight sync at start (DataParallel re-broadcasts every step; DDP does not need to)."""
-    if not dist.is_initialized() or dist.get_world_size() <= 1:
-        return
-    for p in module.parameters():
-        dist.broadcast(p.data, src=src)
+def broadcast_parameters(module, src=0, group=None):
+    """One-time weight (and buffer) sync at start (DataParallel re-broadcasts every step; DDP does not need to): ONE collective per dtype over a
+    flat copy of all tensors instead of one per tensor (251 at ViT-B).  Returns the number of collectives issued."""
+    if not dist.is_initialized() or dist.get_world_size(group) <= 1:
+        return 0
+    by_dtype = collections.OrderedDict()
+    for t in list(module.parameters()) + list(module.buffers()):
+        by_dtype.setdefault((t.dtype, t.device), []).append(t.data)
+    n = 0
+    for tensors in by_dtype.values():
+        flat = torch.cat([t.reshape(-1) for t in tensors])
+        dist.broadcast(flat, src=src, group=group)
+        off = 0
+        for t in tensors:
+            t.copy_(flat[off:off + t.numel()].view_as(t)); off += t.numel()
+        n += 1
+    return n
 
 
 def shard_seed(base_seed, rank):

@@ -135,7 +135,9 @@ def refresh_weights(module):
     mode = module.mode
     folds = module.__dict__.get('_foldreg')
     if folds:
-        _fold_products(list(folds.values()))
+        live = [ent for k, ent in folds.items() if k in reg]         # (a fold whose operand copies are no longer registered is stale: skip it)
+        if live:
+            _fold_products(live)
     ents = list(reg.items())
     sig = tuple((k, p.data_ptr(), 0 if Wc is None else Wc.data_ptr(), 0 if Wt is None else Wt.data_ptr()) for k, (p, Wc, Wt, N, K) in ents) + (mode,)
     tab = module.__dict__.get('_wtab')

@@ -107,7 +107,8 @@ class FusedAdamWClip(torch.optim.Optimizer):
                                              float(self.max_norm or 0.0), self.scratch.data_ptr()), 'tcow_adamw_clip_step')
         # precision='fp16': a non-finite gradient norm means the scaled backward overflowed binary16 -- the kernels above skipped the update
         # (clip coefficient -1); lower the module's loss-scale exponent by 4, otherwise let it creep back towards -2.  All on the device.
-        ls = getattr(self._tracker, 'ls_log2', None) if self._tracker is not None else None
+        trk = self._tracker
+        ls = getattr(trk, 'ls_log2', None) if trk is not None and getattr(trk, 'precision', None) == 'fp16' and getattr(trk, 'loss_scale', None) == 'dynamic' else None
         if ls is not None and ls.device == self.scratch.device:
             ok = self.scratch[-3] >= 0                       # clip coefficient -1 = skipped
             ls.copy_(torch.minimum(ls + torch.where(ok, 1.0 / 256.0, -4.0), torch.full_like(ls, -2.0)))
@@ -131,6 +132,9 @@ class FusedAdamWClip(torch.optim.Optimizer):
         sd = super().state_dict()
         skipped = float(self.scratch[-1]) if self.scratch is not None else 0.0
         if skipped:
+            # torch's Optimizer.state_dict() hands out the LIVE per-parameter dicts: adjust copies, never self.state (the device counter is
+            # subtracted again inside the update kernel, so rewriting the live 'step' would double-count every skip after each save)
+            sd['state'] = {k: dict(st) for k, st in sd['state'].items()}
             for st in sd['state'].values():
                 if 'step' in st:
                     st['step'] = st['step'] - skipped

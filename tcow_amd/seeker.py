@@ -207,7 +207,7 @@ class QueryMaskTracker(nn.Module):
         self.loss_scale = 'dynamic'                                             # fp16 only: power-of-two factor on the backward's gradients (engine.run_backward); a number = static
         self.gemm_mode = ops.F32X3 if precision == 'bf16x3' else self.mode     # GEMM arithmetic; storage / every other kernel follow `mode`
         self._wcache = {}
-        self.__dict__.pop('_wreg', None); self.__dict__.pop('_wtab', None)
+        self.__dict__.pop('_wreg', None); self.__dict__.pop('_wtab', None); self.__dict__.pop('_foldreg', None)
         return self
 
     def invalidate_weight_cache(self):
@@ -220,7 +220,7 @@ class QueryMaskTracker(nn.Module):
 
     def _apply(self, fn, *a, **k):
         self._wcache = {}
-        self.__dict__.pop('_wreg', None); self.__dict__.pop('_wtab', None)
+        self.__dict__.pop('_wreg', None); self.__dict__.pop('_wtab', None); self.__dict__.pop('_foldreg', None)
         self._gbufs = {}
         return super()._apply(fn, *a, **k)
 
@@ -270,7 +270,7 @@ class QueryMaskTracker(nn.Module):
             # torch.nn.DataParallel (train.py:222-223) re-creates shallow replicas every forward: their dicts alias the original's, so give
             # each replica private operand / gradient caches for this call instead of growing the shared ones with dead entries
             self._wcache, self._gbufs = {}, {}
-            self.__dict__.pop('_wreg', None); self.__dict__.pop('_wtab', None)
+            self.__dict__.pop('_wreg', None); self.__dict__.pop('_wtab', None); self.__dict__.pop('_foldreg', None)
         rgb = input_frames.to(torch.float32).contiguous()                 # mask_tracker.py:103-104 (inputs not mutated)
         qm = query_mask.to(torch.float32).contiguous()
         from .engine import SeekerFunction
