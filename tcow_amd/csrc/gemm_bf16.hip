@@ -325,7 +325,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_320_kernel(NtParams p) {
     for (int i = 0; i < 10; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc16[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if constexpr (ML >= 1) {
+    if constexpr (ML == 1) {
         // (see gemm_p8.hip for the layout and the ordering argument; BM = 320: 20 row blocks, 5 per wave and phase)
         constexpr int ARB = 20, RBH = 5, A_PLANE = ARB * 1024, KH = A_PLANE + 16 * 1024, KTILE = 2 * KH, NA = 3;
         const int wr = wm, wc = wn;
@@ -334,26 +334,26 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_320_kernel(NtParams p) {
         uint32_t a_src[NA], w_src[2];
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
-            const int r = (wave + 8 * j) * 16 + (ML == 3 ? (lane >> 3) : (lane >> 2));                     // (ML = 3: timing-only probe, whole-line pieces)
+            const int r = (wave + 8 * j) * 16 + (lane >> 2);
             const int rr = m0 + r < p.M ? r : p.M - 1 - m0;
-            a_src[j] = (uint32_t)(rr * p.lda + (ML == 3 ? (lane & 7) * 8 : ((lane & 3) ^ ((lane >> 4) & 3)) * 8));
+            a_src[j] = (uint32_t)(rr * p.lda + ((lane & 3) ^ ((lane >> 4) & 3)) * 8);
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int r = (wave + 8 * j) * 16 + (ML == 3 ? (lane >> 3) : (lane >> 2));
+            const int r = (wave + 8 * j) * 16 + (lane >> 2);
             const int rr = n0 + r < p.N ? r : p.N - 1 - n0;
-            w_src[j] = (uint32_t)(rr * p.ldw + (ML == 3 ? (lane & 7) * 8 : ((lane & 3) ^ ((lane >> 4) & 3)) * 8));
+            w_src[j] = (uint32_t)(rr * p.ldw + ((lane & 3) ^ ((lane >> 4) & 3)) * 8);
         }
         const bool a_last = wave + 16 < ARB;
         auto load_a = [&](int kt, int kh) {
             char* dst = smem + (kt & 1) * KTILE + kh * KH;
-            const bf16_t* g = ML == 3 ? a_base + (size_t)kt * 64 + (size_t)(kh * 8) * p.lda : a_base + (size_t)kt * 64 + kh * 32;
+            const bf16_t* g = a_base + (size_t)kt * 64 + kh * 32;
             glds16(g + a_src[0], dst + wave * 1024); glds16(g + a_src[1], dst + (wave + 8) * 1024);
             if (a_last) glds16(g + a_src[2], dst + (wave + 16) * 1024);
         };
         auto load_w = [&](int kt, int kh) {
             char* dst = smem + (kt & 1) * KTILE + kh * KH + A_PLANE;
-            const bf16_t* g = ML == 3 ? w_base + (size_t)kt * 64 + (size_t)(kh * 8) * p.ldw : w_base + (size_t)kt * 64 + kh * 32;
+            const bf16_t* g = w_base + (size_t)kt * 64 + kh * 32;
             glds16(g + w_src[0], dst + wave * 1024); glds16(g + w_src[1], dst + (wave + 8) * 1024);
         };
         typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
@@ -399,24 +399,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_320_kernel(NtParams p) {
         for (int kt = 0; kt < nk; ++kt) {
             const uint32_t bo = (uint32_t)(kt & 1) * KTILE;
             const bool more = kt + 1 < nk;
-            if constexpr (ML == 2) {
-                // PAIRED loads (round 4): both k halves of a row piece are requested back to back, so the second 64-byte half of every 128-byte
-                // line hits the line the first request brought into the CU's L1 -- with the halves two phases apart (ML = 1) the L1 has
-                // turned over in between and every line crosses the L2 -> L1 path twice (tools/ubench_c2.hip: the load stream of these
-                // kernels saturates the L2s at HALF the useful bytes a full-line stream reaches).  W pair in phase 1 (its k-half-1 plane was
-                // last read in phase 3 of the tile before), A pair in phase 2 (last read in phase 4); one vmcnt(0) in phase 4, >= 2 phases later.
-                read_w(fw[0], w_ad + bo); read_a(fa[0], a_ad + bo, 0);
-                if (more) { load_w(kt + 1, 0); load_w(kt + 1, 1); }
-                P8_PHASE_TAIL(0, 0, 0);
-                read_a(fa[1], a_ad + bo, 1);
-                if (more) { load_a(kt + 1, 0); load_a(kt + 1, 1); }
-                P8_PHASE_TAIL(1, 0, 1);
-                read_w(fw[1], w_ad + bo + KH); read_a(fa[0], a_ad + bo + KH, 0);
-                P8_PHASE_TAIL(0, 1, 0);
-                read_a(fa[1], a_ad + bo + KH, 1);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                P8_PHASE_TAIL(1, 1, 1);
-            } else {
             read_w(fw[0], w_ad + bo); read_a(fa[0], a_ad + bo, 0);
             if (more) load_a(kt + 1, 0);
             P8_PHASE_TAIL(0, 0, 0);
@@ -431,7 +413,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_320_kernel(NtParams p) {
             if (more) load_w(kt + 1, 1);
             wait_vm(!more);
             P8_PHASE_TAIL(1, 1, 1);
-            }
         }
         if (wr == 0) __builtin_amdgcn_s_barrier();
 #undef P8_DSR
@@ -523,7 +504,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_320_kernel(NtParams p) {
 #undef TCOW_MFMA10
 
     }
-    wave_tile_epilogue_160x64<E, (ML >= 1 ? 1 : 0)>(p, smem + wave * (64 * 68 * 4), acc, acc16, lane, m0 + wm * 160, n0 + wn * 64);
+    wave_tile_epilogue_160x64<E, ML>(p, smem + wave * (64 * 68 * 4), acc, acc16, lane, m0 + wm * 160, n0 + wn * 64);
 }
 
 __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(NtParams p) {
@@ -633,9 +614,13 @@ int tcow_gemm_nt_bf16(hipStream_t stream, const tcow_gemm_args* a) {
         const long rounds = (t320 + 255) / 256;
         const bool fills = t320 * 100 >= rounds * 256 * 80;   // (measured: still ahead of the 256 / 128 tiles at 88 % -- configs[3], configs[4])
         // the 160 x 256 tile at two workgroups per CU (gemm_nt_c2.hip): same shapes (its tiles are the wave rows of the 320 tile)
+        // TCOW_GEMM_C2: 0 (default) = never, 1 = every shape the 320 tile takes, 2 = only where it measured ahead of the 320 tile at M = 27 090
+        // (profiles/r04_gemm_c2.txt): short-K GEMMs with an f32 residual epilogue (the HBM-bound epilogue hides under the co-resident
+        // workgroup's main loop) and plain short-K GEMMs of three rounds
         static const int c2 = [] { const char* e = getenv("TCOW_GEMM_C2"); return e ? atoi(e) : 0; }();
-        if (a->tile == 160 || (a->tile == 0 && c2 && wide && (wide == 2 || (fills && t320 >= 200)) && tcow_gemm_nt_c2_ok(a))) {
-            TCOW_CHECK_ARG(tcow_gemm_nt_c2_ok(a), "tcow_gemm_nt(bf16): tile 160 needs K %% 64 == 0");
+        const bool c2_pick = c2 == 1 || (c2 == 2 && a->K <= 1024 && ((a->out_f32 && a->resid) || (a->act == TCOW_ACT_NONE && !a->row_scale && !a->resid && !a->bias2 && a->N >= 2304 && a->N < 3072)));
+        if (a->tile == 160 || (a->tile == 0 && c2_pick && wide && (wide == 2 || (fills && t320 >= 200)) && tcow_gemm_nt_c2_ok(a))) {
+            TCOW_CHECK_ARG(tcow_gemm_nt_c2_ok(a), "tcow_gemm_nt(bf16): tile 160 needs K %% 128 == 0 and operands below 2 GiB");
             return tcow_gemm_nt_bf16_c2(stream, a);
         }
         if (a->tile == 320 || (a->tile == 0 && wide && (wide == 2 || (fills && t320 >= 200)))) {
@@ -659,7 +644,7 @@ int tcow_gemm_nt_bf16(hipStream_t stream, const tcow_gemm_args* a) {
                 else if (a->act == TCOW_ACT_GELU && rows == 0) k = gemm_nt_bf16_320_kernel<EpiCfg<TCOW_ACT_GELU, 0>, R>;                     \
             } while (0)
             Kern k;
-            if (ml == 3 && a->K % 64 == 0) TCOW_PICK(3); else if (ml == 2 && a->K % 64 == 0) TCOW_PICK(2); else if (ml && a->K % 64 == 0) TCOW_PICK(1); else TCOW_PICK(0);
+            if (ml && a->K % 64 == 0) TCOW_PICK(1); else TCOW_PICK(0);
 #undef TCOW_PICK
             tcow_ensure_lds(reinterpret_cast<const void*>(k), C_LDS);
             hipLaunchKernelGGL(k, dim3(p.tiles_m * p.tiles_n), dim3(512), C_LDS, stream, p);
@@ -877,6 +862,9 @@ __device__ long long* g_tn_dbg; __device__ int g_tn_dbg_it;
 #define TN_STAMP(i) do { } while (0)
 #endif
 // one workgroup of the 256-tile weight-gradient GEMM `p`: pid = slice * tiles + tile
+// AB: ablation switches of tools/ubench_tn_ab.hip (0 in the library): 2 = no loads after the first stage, 4 = no barriers in the loop, 8 = no slab
+// store (accumulators kept alive), 16 = no transpose reads in the loop, 32 = no MFMAs, 64 = no bias column sums.
+template <int AB = 0>
 __device__ __forceinline__ void tn256_body(const TnParams& p, const int pid, char* smem) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -987,6 +975,7 @@ __device__ __forceinline__ void tn256_body(const TnParams& p, const int pid, cha
 #define TCOW_TRR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
 #define TCOW_TN_READ(buf, ks, so)                                                                                          \
     do {                                                                                                                   \
+        if (AB & 16) break;                                                                                                \
         _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                    \
             TCOW_TRR(fxl[buf][j], xa[j] + (so), T2_TILE + (ks) * 16 * T2_ROWB);                                            \
             TCOW_TRR(fxh[buf][j], xa[j] + (so), T2_TILE + (ks) * 16 * T2_ROWB + 4 * T2_ROWB);                              \
@@ -998,16 +987,25 @@ __device__ __forceinline__ void tn256_body(const TnParams& p, const int pid, cha
     } while (0)
 #define TCOW_TN_FRAG(lo, hi) __builtin_bit_cast(bf16x8, (u32x4){(lo).x, (lo).y, (hi).x, (hi).y})
 #define TCOW_TN_MFMA8(buf)                                                                                                 \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                          \
+    if (!(AB & 32)) _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                          \
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                      \
             acc[i][j] = TCOW_MFMA_32x32x16_H16(TCOW_TN_FRAG(fyl[buf][i], fyh[buf][i]), TCOW_TN_FRAG(fxl[buf][j], fxh[buf][j]), acc[i][j], 0, 0, 0)
 
     if (nmt > 0) TCOW_TN_READ(0, 0, 0u);
+    if (AB & 16) {                                                     // (ablation: fragment registers defined once)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { fxl[b][j] = (u32x2){1u, 2u}; fxh[b][j] = (u32x2){3u, 4u}; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { fyl[b][i] = (u32x2){5u, 6u}; fyh[b][i] = (u32x2){7u, 8u}; }
+        }
+    }
     for (int it = 0; it < nmt; ++it) {
         const int stage = it & 1;
         const uint32_t so = (uint32_t)stage * T2_STAGE;
         TN_STAMP(0);
-        if (it + 1 < nmt) {
+        if (it + 1 < nmt && !(AB & 2)) {
             const int mt = mbeg + (it + 1) * T2_MC;
             if (interior && mt + T2_MC <= mend) issue_fast(mt, stage ^ 1); else issue(mt, stage ^ 1);
         }
@@ -1034,7 +1032,7 @@ __device__ __forceinline__ void tn256_body(const TnParams& p, const int pid, cha
         TN_STAMP(5);
         TCOW_TN_MFMA8(1);
         TN_STAMP(6);
-        if (p.bias_part) {
+        if (p.bias_part && !(AB & 64)) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int r = cs_lo + cs_rg + 16 * u;
@@ -1048,7 +1046,7 @@ __device__ __forceinline__ void tn256_body(const TnParams& p, const int pid, cha
         TN_STAMP(7);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         TN_STAMP(8);
-        __syncthreads();
+        if (!(AB & 4)) __syncthreads();
         TN_STAMP(9);
         if (it + 1 < nmt) TCOW_TN_READ(0, 0, so ^ (uint32_t)T2_STAGE);
     }
@@ -1075,6 +1073,13 @@ __device__ __forceinline__ void tn256_body(const TnParams& p, const int pid, cha
         __syncthreads();
     }
 
+    if (AB & 8) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) asm volatile("" :: "v"(acc[i][j]));
+        return;
+    }
     float* out = p.slab + (size_t)z * p.N * p.K;
     const int l31 = lane & 31;
 #pragma unroll
@@ -1093,7 +1098,7 @@ __device__ __forceinline__ void tn256_body(const TnParams& p, const int pid, cha
 
 __global__ __launch_bounds__(512, 2) void gemm_tn_bf16_256_kernel(TnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    tn256_body(p, xcd_remap(blockIdx.x, gridDim.x), smem);
+    tn256_body<0>(p, xcd_remap(blockIdx.x, gridDim.x), smem);
 }
 
 // Grouped launch: the weight gradients of ONE transformer block (7 Linear layers, 153 tiles of 256 x 256 at ViT-B) as one grid.  Launched
@@ -1108,7 +1113,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_bf16_256_group_kernel(TnGroup 
     int k = 0;
     while (k + 1 < g.n && pid >= g.first[k + 1]) ++k;           // workgroup-uniform
     const TnParams p = g.p[k];
-    tn256_body(p, pid - g.first[k], smem);
+    tn256_body<0>(p, pid - g.first[k], smem);
 }
 
 }  // namespace

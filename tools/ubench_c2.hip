@@ -46,10 +46,6 @@ int main() {
             run<8 + 16 + 32>("no epilogue, loads only", M, N, K, A, W, C, D_LDS, 0.f);
             run<8 + 16 + 32 + 64>("no epilogue, A loads only", M, N, K, A, W, C, D_LDS, 0.f);
             run<8 + 16 + 32 + 128>("no epilogue, W loads only", M, N, K, A, W, C, D_LDS, 0.f);
-            run<8 + 16 + 32 + 256>("no epilogue, loads only, WHOLE-LINE pieces (8 rows x 128 B)", M, N, K, A, W, C, D_LDS, 0.f);
-            run<8 + 16 + 32 + 64 + 256>("no epilogue, A loads only, whole-line pieces", M, N, K, A, W, C, D_LDS, 0.f);
-            run<8 + 16 + 32 + 128 + 256>("no epilogue, W loads only, whole-line pieces", M, N, K, A, W, C, D_LDS, 0.f);
-            run<8 + 256>("no epilogue, full loop with whole-line pieces (wrong data)", M, N, K, A, W, C, D_LDS, 0.f);
             continue;
         }
         run<0>("as shipped", M, N, K, A, W, C, D_LDS, 0.45f);
