@@ -45,7 +45,7 @@ clean:
 
 # microbenchmarks (run on the GPU box: build/ubench_valu > profiles/rNN_ubench_valu.txt)
 ubench: build/ubench_valu
-build/ubench_gemm: tools/ubench_gemm.hip $(CSRC)/gemm_p8.hip $(CSRC)/common.h
+build/ubench_gemm: tools/ubench_gemm.hip tools/gemm_p8.hip $(CSRC)/common.h
 	@mkdir -p build
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -Wno-unused-result -x hip $< -o $@
 
@@ -57,7 +57,7 @@ build/ubench_tn: tools/ubench_tn.hip $(CSRC)/gemm_bf16.hip $(CSRC)/common.h
 
 ubench_tn: build/ubench_tn
 
-build/ubench_valu: tools/ubench_valu.hip $(CSRC)/attention_bf16.hip $(CSRC)/common.h
+build/ubench_valu: tools/ubench_valu.hip tools/attn_fwd_variants.inc $(CSRC)/attention_bf16.hip $(CSRC)/common.h
 	@mkdir -p build
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fno-honor-nans -fno-slp-vectorize -Wno-unused-result -x hip $< -o $@
 

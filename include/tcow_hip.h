@@ -86,8 +86,8 @@ typedef struct {
     const float* resid; long ldr;
     int act;
     void* aux; long ldaux;
-    int tile;              /* 0 = choose by shape; 128 / 256 / 320 = force that bf16 NT tile kernel (tests and A/B runs); 8320 / 8256 = the
-                              phase-structured kernel of gemm_p8.hip with 320- / 256-row tiles (plain epilogues, K % 64 == 0 only) */
+    int tile;              /* 0 = choose by shape; 128 / 256 / 320 = force that bf16 NT tile kernel (tests and A/B runs); 160 = the 160 x 256 kernel
+                              that runs two workgroups per CU (gemm_nt_c2.hip; K % 128 == 0) */
     const float* bias2;        /* second bias [N] with its own row scale (may be NULL) */
     const float* row_scale2;   /* [M] or NULL */
 } tcow_gemm_args;
@@ -212,6 +212,17 @@ int tcow_gather_frames(void* stream, int elem_bytes, int C, int Tv, int H, int W
 int tcow_resize_aa(void* stream, int C, int Tv, int H, int W, int Tc, int hc, int wc, int oh, int ow, const float* src, const int* frame_idx,
                    const int* ys, const int* xs, const int* ymin, const int* ysize, const float* wy, int ky, const int* xmin, const int* xsize,
                    const float* wx, int kx, float* out);
+
+/* Photometric augmentation of the rgb modality (data/augs.py:33-35,175-181: torchvision ColorJitter + GaussianBlur(5) + Grayscale(3)), fused
+ * (photometric.hip): src (3, Tv, H, W) f32 in [0, 1]; the Tc frames frame_idx[t] (device int32), centre-crop rectangle (y0, x0, h, w), are
+ * jittered with the n_ops adjustments ops[] (host array, application order: 0 brightness, 1 contrast, 2 saturation, 3 hue; one factor each),
+ * blurred with the five normalised taps (host array; blur = 0: skipped) with reflect padding, optionally folded to 3 equal grey channels, and
+ * written to out (3, Tc, h, w).  workspace: tcow_photometric_workspace_bytes(Tc) bytes (device), needed when contrast is among the ops. */
+long tcow_photometric_workspace_bytes(int Tc);
+int tcow_photometric(void* stream, int Tv, int H, int W, int Tc, int y0, int x0, int h, int w, const float* src, const int* frame_idx, int n_ops,
+                     const int* ops, float brightness, float contrast, float saturation, float hue, int blur, const float* taps, int gray,
+                     float* workspace, long workspace_bytes, float* out);
+
 int tcow_embed_fwd(void* stream, int B, int T, int S, int D, float* x, const float* cls, const float* pos,
                    const float* time_embed);
 int tcow_embed_bwd(void* stream, int B, int T, int S, int D, const float* g, float* dpos, float* dtime,

@@ -84,6 +84,9 @@ SIGNATURES = {
     'tcow_im2col': (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     'tcow_gather_frames': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'tcow_resize_aa': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp]),
+    'tcow_photometric_workspace_bytes': (_l, [_i]),
+    'tcow_photometric': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, ctypes.POINTER(ctypes.c_int), _f, _f, _f, _f, _i, ctypes.POINTER(ctypes.c_float), _i,
+                         _vp, _l, _vp]),
     'tcow_im2col_channels': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     'tcow_embed_fwd': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'tcow_embed_bwd': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _i]),

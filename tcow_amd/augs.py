@@ -12,8 +12,10 @@ column of the cropped image); with them
 The reference runs slicing + torch.flip + slicing + torchvision Resize as four full-tensor passes per modality on the CPU loader workers.
 
 The photometric operators of the rgb modality (augs.py:33-35,175-181: torchvision ColorJitter(0.2, 0.2, 0.2, 0.1), GaussianBlur(5, sigma in
-[0.1, 3.5]), Grayscale(3)) run as elementwise tensor passes on the device, on the selected frames at source resolution and BEFORE flip / crop /
-resize like the reference (the contrast mean is taken over the whole centre-cropped frame).  torchvision is not installed here, so no vector
+[0.1, 3.5]), Grayscale(3)) run as ONE fused device kernel (`tcow_photometric`, csrc/photometric.hip; + a per-frame mean pass when contrast is
+drawn) on the selected frames at source resolution and BEFORE flip / crop / resize like the reference (the contrast mean is taken over the
+whole centre-cropped frame).  The tensor functions below (adjust_*, gaussian_blur5, grayscale3) are the same definitions in torch: the CPU-side
+statement the tests compare with float64 restatements, and the second reference of the kernel's GPU test.  torchvision is not installed here, so no vector
 of the reference's can pin them: they follow torchvision's published tensor definitions (functional_tensor: _blend, rgb_to_grayscale
 0.2989 / 0.587 / 0.114, _rgb2hsv / _hsv2rgb, the 5-tap Gaussian with reflect padding) and `photometric_draws` consumes torch's global RNG in
 torchvision's order (randperm(4), then one uniform_ per jitter factor; one uniform_ for sigma).  PARITY UNPINNED against the reference for
@@ -274,6 +276,28 @@ def apply_photometric(img, draws):
     return img
 
 
+def blur_taps(sigma):
+    """torchvision's _get_gaussian_kernel1d(5, sigma) in float32: taps exp(-0.5 (x / sigma)^2) on x = -2 .. 2, normalised."""
+    import torch
+    x = torch.linspace(-2.0, 2.0, 5, dtype=torch.float32)
+    k = torch.exp(-0.5 * (x / float(sigma)) ** 2)
+    return (k / k.sum()).tolist()
+
+
+def photometric_hip(fr, frame_idx, rect, draws):
+    """The three photometric operators as ONE fused device kernel (csrc/photometric.hip): fr (3, Tv, H, W) f32 CUDA frames in [0, 1], the clip's
+    source-frame table and centre-crop rectangle (y0, x0, h, w), the draws of `photometric_draws` -> (3, T, h, w)."""
+    import torch
+    from . import ops
+    order, factors = [], (1.0, 1.0, 1.0, 0.0)
+    if 'color_jitter' in draws:
+        o, fb, fc, fs, fh = draws['color_jitter']
+        order, factors = [int(k) for k in o], (fb, fc, fs, fh)
+    taps = blur_taps(draws['rgb_blur']) if 'rgb_blur' in draws else None
+    fi = torch.as_tensor(np.asarray(frame_idx, dtype=np.int32), device=fr.device)
+    return ops.photometric(fr.contiguous(), fi, rect, order, factors, taps, bool(draws.get('rgb_grayscale')))
+
+
 def apply_augs(modalities, augs_params, out_h, out_w, center_crop=False, draws_in=None):
     """augs.py:137-207: dict name -> (C, Tv, H, W) CUDA tensor (uint8 / float32); tensors with fewer than 4 dimensions pass through.
     `draws_in`: the photometric parameters (photometric_draws) when the caller wants them fixed; drawn from torch's global RNG otherwise."""
@@ -291,8 +315,7 @@ def apply_augs(modalities, augs_params, out_h, out_w, center_crop=False, draws_i
             draws = draws_in if draws_in is not None else photometric_draws(augs_params)
             fi, ys, xs = crop_maps(augs_params, H, W, out_h, out_w, center_crop)
             y0, x0, h, w = center_rect(H, W, out_h, out_w, center_crop)
-            sel = fr[:, torch.as_tensor(np.asarray(fi, dtype=np.int64), device=fr.device)][:, :, y0:y0 + h, x0:x0 + w].float()
-            img = apply_photometric(sel.permute(1, 0, 2, 3), draws).permute(1, 0, 2, 3).contiguous()
+            img = photometric_hip(fr.float(), fi, (y0, x0, h, w), draws)            # frame selection + centre crop + the three operators: one kernel
             ident = np.arange(len(fi), dtype=np.int32)
             if len(ys) == out_h and len(xs) == out_w:
                 out[name] = gather_clip(img, ident, (ys - y0).astype(np.int32), (xs - x0).astype(np.int32))

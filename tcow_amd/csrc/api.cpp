@@ -39,8 +39,6 @@ int tcow_gemm_tn_f32(hipStream_t stream, int M, int N, int K, const float* dY, l
 int tcow_gemm_nt_x3(hipStream_t stream, const tcow_gemm_args* a);
 int tcow_gemm_tn_x3(hipStream_t stream, int M, int N, int K, const float* dY, long ldy, const float* X, long ldx, float* dW, long lddw, int accumulate,
                     float* slab, int splits);
-bool tcow_gemm_nt_p8_ok(const tcow_gemm_args* a);
-int tcow_gemm_nt_p8(hipStream_t stream, const tcow_gemm_args* a, int bm);
 int tcow_tn_group_max(void);
 bool tcow_tn_group_ok(int n, const tcow_tn_problem* pr);
 int tcow_tn_group_slices(int n, const tcow_tn_problem* pr);
@@ -60,7 +58,7 @@ int tcow_launch_colsum(hipStream_t stream, int dtype, const void* Y, long ldy, i
 
 extern "C" {
 
-int tcow_version(void) { return 5; }
+int tcow_version(void) { return 6; }
 const char* tcow_last_error(void) { return g_err; }
 
 // ---- optional low-overhead HIP-event timing of the dominant kernel (the NT GEMM), on the launch stream
@@ -122,18 +120,6 @@ static int gemm_nt_dispatch(void* stream, const tcow_gemm_args* a) {
     TCOW_CHECK_ARG(a->act >= TCOW_ACT_NONE && a->act <= TCOW_ACT_MUL_AUX, "tcow_gemm_nt: unknown activation %d", a->act);
     TCOW_CHECK_ARG(a->bias2 || !a->row_scale2, "tcow_gemm_nt: row_scale2 without bias2");
     if (a->dtype == TCOW_BF16) {
-        // TCOW_GEMM_P8=1: plain-epilogue problems go to the phase-structured kernel (gemm_p8.hip); 320-row tiles when they fill the rounds better
-        static const int p8 = [] { const char* e = getenv("TCOW_GEMM_P8"); return e ? atoi(e) : 0; }();
-        if (a->tile == 8320 || a->tile == 8256) {
-            TCOW_CHECK_ARG(tcow_gemm_nt_p8_ok(a), "tcow_gemm_nt: tile %d (phase-structured kernel) takes plain epilogues with K %% 64 == 0 only", a->tile);
-            return tcow_gemm_nt_p8((hipStream_t)stream, a, a->tile - 8000);
-        }
-        if (p8 && a->tile == 0 && tcow_gemm_nt_p8_ok(a) && (p8 != 2 || a->K >= 2048)) {        // (2: only the main-loop-bound long-K problems)
-            const long tn = (a->N + 255) / 256, t320 = ((a->M + 319) / 320) * tn, t256 = ((a->M + 255) / 256) * tn;
-            const double e320 = (double)t320 / (((t320 + 255) / 256) * 256.0) / 1.0, e256 = (double)t256 / (((t256 + 255) / 256) * 256.0);
-            const int bm = p8 == 320 ? 320 : (p8 == 256 ? 256 : (e320 * (double)a->M / (t320 / tn * 320.0) >= e256 * (double)a->M / (t256 / tn * 256.0) ? 320 : 256));
-            return tcow_gemm_nt_p8((hipStream_t)stream, a, bm);
-        }
         return tcow_gemm_nt_bf16((hipStream_t)stream, a);
     }
     if (a->dtype == TCOW_F32) return tcow_gemm_nt_f32((hipStream_t)stream, a);

@@ -30,6 +30,9 @@
 namespace {
 
 constexpr int TILE_B = 4096;                 // 32 rows x 128 B
+#ifdef UBENCH_ATTN
+__device__ long long* g_attn_dbg;
+#endif
 constexpr float kScale = 0.125f;             // head_dim^-0.5 (vit.py:70)
 constexpr float kLog2e = 1.4426950408889634f;
 
@@ -375,544 +378,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_stream(SeqDesc sd, int nt, co
     if (active) fwd_store(sd, base, head, q, hi, m, l, o0, o1, out, lse);
 }
 
-// ------------------------------------------------------------------------------------------------ resident forward (spatial, S <= 320)
-// One 256-thread workgroup per (frame, head): the whole K and V of the sequence (nt <= 10 tiles each, 80 KiB) are brought into LDS
-// ONCE (the streaming kernel's three workgroups per pair each pull all of K / V through the global->LDS path: 259 MB per launch at
-// S = 301 against 86 MB here) and every wave owns TWO query tiles: the K and V fragments it reads feed two MFMAs each, and the two
-// softmax chains are independent instruction streams inside one wave.  Two workgroups per CU (2 x 80 KiB), so one workgroup's load
-// phase runs under the other's arithmetic; inside a workgroup the tiles arrive in three groups behind COUNTED waits (raw s_barrier,
-// the loads of groups 1 and 2 stay in flight while group 0 is multiplied).
-// Balance at nt = 10: waves 0..3 take query tiles (0,1) (2,3) (4,5) (6,7) against all keys; tiles 8 and 9 are then split BY KEYS
-// over the wave pairs (0,1) and (2,3) (flash-decoding style), and the two partial (m, l, O) are merged through LDS -- every wave
-// does 10 double steps + nt/2 single steps, no idle wave slots (the streaming kernel ran 10 tiles on 12 wave slots).
-//
-// The step arithmetic is VALU-issue-bound (tools/ubench_valu.hip, profiles/r03_ubench_valu.txt: a wave64 v_fma / v_max3 / v_cvt_pk
-// occupies the SIMD for ~4 cycles, v_add / v_mul 2.4, v_exp_f32 8.2; one MFMA gap hides <= 5 of them), so the loop carries no
-// address arithmetic at all: every LDS read is inline asm with a compile-time offset (the 10 steps are unrolled), the K fragments
-// of step j+1 are requested before the softmax of step j, V's transposed fragments right behind the score MFMAs.  (Inline asm also
-// because hipcc cannot tell a ds_read_b64_tr_b16 builtin from the LDS writes of the direct-to-LDS loads still in flight and would
-// put s_waitcnt vmcnt(0) in front of it, draining the tile groups that are meant to arrive under the arithmetic.)
-constexpr int RES_MAX_NT = 10;
-constexpr int RES_V0 = RES_MAX_NT * TILE_B;  // V tiles behind the K tiles (fixed: all LDS offsets are immediates)
-constexpr int RES_LDS = 2 * RES_MAX_NT * TILE_B;
-constexpr int RES_MERGE_B = 34 * 256;        // one wave's (O0, O1, m, l) image: 34 floats per lane
-
-typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
-typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-#define RES_RD128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
-#define RES_RDTR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
-#define RES_FRAG(lo, hi) __builtin_bit_cast(bf16x8, (u32x4_t){(lo).x, (lo).y, (hi).x, (hi).y})
-
-__device__ __forceinline__ void gload_frag_asm(bf16x8& dst, const bf16_t* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory"); }
-
-// per-lane LDS byte offsets inside a tile: kad[ks] = row-fragment of k-step ks (frag_row), vad[2 dt + h] = transposed-read base of
-// d-tile dt, row half h (frag_tr; the k-slot s is a plain +2048 because swz_g(r + 16) == swz_g(r))
-__device__ __forceinline__ void res_offsets(uint32_t (&kad)[4], uint32_t (&vad)[4], int lane) {
-    const int l31 = lane & 31, hi = lane >> 5;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) kad[ks] = l31 * 128 + (((2 * ks + hi) ^ swz_g(l31)) << 4);
-    const int q16 = lane & 15, g16 = (lane >> 4) & 1;
-    const int r0 = 4 * hi + (q16 >> 2), r1 = r0 + 8;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt) {
-        const int chunk = 4 * dt + 2 * g16 + ((q16 & 3) >> 1);
-        vad[2 * dt] = r0 * 128 + ((chunk ^ swz_g(r0)) << 4) + (q16 & 1) * 8;
-        vad[2 * dt + 1] = r1 * 128 + ((chunk ^ swz_g(r1)) << 4) + (q16 & 1) * 8;
-    }
-}
-template <int OFF>
-__device__ __forceinline__ void res_read_k(u32x4_t (&kf)[4], const uint32_t (&kad)[4]) {
-    RES_RD128(kf[0], kad[0], OFF); RES_RD128(kf[1], kad[1], OFF); RES_RD128(kf[2], kad[2], OFF); RES_RD128(kf[3], kad[3], OFF);
-}
-struct VFrag { u32x2_t l00, h00, l01, h01, l10, h10, l11, h11; };      // <s><dt>: key rows 16 s .., channels 32 dt ..
-template <int OFF>
-__device__ __forceinline__ void res_read_v(VFrag& v, const uint32_t (&vad)[4]) {
-    RES_RDTR(v.l00, vad[0], OFF); RES_RDTR(v.h00, vad[1], OFF); RES_RDTR(v.l01, vad[2], OFF); RES_RDTR(v.h01, vad[3], OFF);
-    RES_RDTR(v.l10, vad[0], OFF + 2048); RES_RDTR(v.h10, vad[1], OFF + 2048); RES_RDTR(v.l11, vad[2], OFF + 2048); RES_RDTR(v.h11, vad[3], OFF + 2048);
-}
-
-// scores of one query tile -> probabilities (packed operands of the P V MFMAs) + running statistics; see fwd_tile for the lazy maximum
-__device__ __forceinline__ void res_softmax(f32x16& s, bool mask_tail, int key0, int L, int hi, float& m, float& l, f32x16& o0, f32x16& o1, bf16x8& p0, bf16x8& p1) {
-    const float sc = kScale * kLog2e;
-    if (mask_tail) {                                         // the sequence's last key tile: keys past the end take no part
-        TCOW_NO_IFCVT();
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            if (key0 + crow32(r, hi) >= L) s[r] = -1e30f;
-    }
-    float mx = s[0];
-#pragma unroll
-    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
-    mx = half_max(mx) * sc;
-    if (__any(mx > m + 8.0f)) {
-        const float mn = fmaxf(m, mx);
-        const float alpha = exp2f(m - mn);
-        l *= alpha; m = mn;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
-    }
-    float p[16];
-    float ps = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { p[r] = __builtin_amdgcn_exp2f(fmaf(s[r], sc, -m)); ps += p[r]; }
-    l += ps;                                    // (masked scores are -1e30: exp2 underflows to exactly 0; every row sees >= 1 valid key per tile)
-    p0 = pack8(p); p1 = pack8(p + 8);
-}
-
-// One key tile (compile-time LDS offsets KOFF / VOFF relative to the address registers) against the wave's two query tiles.  On entry the
-// K fragments kf of this tile are in flight; on exit (PREFETCH) those of the next tile are, in kn.
-template <int KOFF, int VOFF, bool PREFETCH>
-__device__ __forceinline__ void res_step2(int L, int key0, const uint32_t (&kad)[4], const uint32_t (&vad)[4], u32x4_t (&kf)[4], u32x4_t (&kn)[4],
-                                          const bf16x8 (&qa)[4], const bf16x8 (&qb)[4], int hi,
-                                          float& ma, float& la, f32x16& oa0, f32x16& oa1, float& mb, float& lb, f32x16& ob0, f32x16& ob1) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3]) :: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    f32x16 sa, sb;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { sa[r] = 0.f; sb[r] = 0.f; }
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        sa = TCOW_MFMA_32x32x16_H16(__builtin_bit_cast(bf16x8, kf[ks]), qa[ks], sa, 0, 0, 0);
-        sb = TCOW_MFMA_32x32x16_H16(__builtin_bit_cast(bf16x8, kf[ks]), qb[ks], sb, 0, 0, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    VFrag v;
-    res_read_v<VOFF>(v, vad);
-    if (PREFETCH) res_read_k<KOFF + TILE_B>(kn, kad);
-    __builtin_amdgcn_sched_barrier(0);
-    const bool tail = key0 + 31 >= L;
-    bf16x8 pa0, pa1, pb0, pb1;
-    res_softmax(sa, tail, key0, L, hi, ma, la, oa0, oa1, pa0, pa1);
-    res_softmax(sb, tail, key0, L, hi, mb, lb, ob0, ob1, pb0, pb1);
-    if (PREFETCH) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(v.l00), "+v"(v.h00), "+v"(v.l01), "+v"(v.h01), "+v"(v.l10), "+v"(v.h10), "+v"(v.l11), "+v"(v.h11) :: "memory");
-    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v.l00), "+v"(v.h00), "+v"(v.l01), "+v"(v.h01), "+v"(v.l10), "+v"(v.h10), "+v"(v.l11), "+v"(v.h11) :: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    oa0 = TCOW_MFMA_32x32x16_H16(RES_FRAG(v.l00, v.h00), pa0, oa0, 0, 0, 0); ob0 = TCOW_MFMA_32x32x16_H16(RES_FRAG(v.l00, v.h00), pb0, ob0, 0, 0, 0);
-    oa1 = TCOW_MFMA_32x32x16_H16(RES_FRAG(v.l01, v.h01), pa0, oa1, 0, 0, 0); ob1 = TCOW_MFMA_32x32x16_H16(RES_FRAG(v.l01, v.h01), pb0, ob1, 0, 0, 0);
-    oa0 = TCOW_MFMA_32x32x16_H16(RES_FRAG(v.l10, v.h10), pa1, oa0, 0, 0, 0); ob0 = TCOW_MFMA_32x32x16_H16(RES_FRAG(v.l10, v.h10), pb1, ob0, 0, 0, 0);
-    oa1 = TCOW_MFMA_32x32x16_H16(RES_FRAG(v.l11, v.h11), pa1, oa1, 0, 0, 0); ob1 = TCOW_MFMA_32x32x16_H16(RES_FRAG(v.l11, v.h11), pb1, ob1, 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-}
-// the same for ONE query tile (the key-split leftover tiles); addresses kad / vad already point at the first tile of the wave's key range
-template <int OFF, bool PREFETCH>
-__device__ __forceinline__ void res_step1(int L, int key0, const uint32_t (&kad)[4], const uint32_t (&vad)[4], u32x4_t (&kf)[4], u32x4_t (&kn)[4],
-                                          const bf16x8 (&qx)[4], int hi, float& m, float& l, f32x16& o0, f32x16& o1) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3]) :: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    f32x16 s;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) s[r] = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) s = TCOW_MFMA_32x32x16_H16(__builtin_bit_cast(bf16x8, kf[ks]), qx[ks], s, 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    VFrag v;
-    res_read_v<OFF>(v, vad);
-    if (PREFETCH) res_read_k<OFF + TILE_B>(kn, kad);
-    __builtin_amdgcn_sched_barrier(0);
-    bf16x8 p0, p1;
-    res_softmax(s, key0 + 31 >= L, key0, L, hi, m, l, o0, o1, p0, p1);
-    if (PREFETCH) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(v.l00), "+v"(v.h00), "+v"(v.l01), "+v"(v.h01), "+v"(v.l10), "+v"(v.h10), "+v"(v.l11), "+v"(v.h11) :: "memory");
-    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v.l00), "+v"(v.h00), "+v"(v.l01), "+v"(v.h01), "+v"(v.l10), "+v"(v.h10), "+v"(v.l11), "+v"(v.h11) :: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    o0 = TCOW_MFMA_32x32x16_H16(RES_FRAG(v.l00, v.h00), p0, o0, 0, 0, 0);
-    o1 = TCOW_MFMA_32x32x16_H16(RES_FRAG(v.l01, v.h01), p0, o1, 0, 0, 0);
-    o0 = TCOW_MFMA_32x32x16_H16(RES_FRAG(v.l10, v.h10), p1, o0, 0, 0, 0);
-    o1 = TCOW_MFMA_32x32x16_H16(RES_FRAG(v.l11, v.h11), p1, o1, 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-}
-
-// wait until at most n of this wave's tile loads (8 direct-to-LDS wave-loads per K + V tile) are still in flight; the empty asm pins the
-// inline-asm query-fragment loads (older than every tile load, so landed whenever a tile group has) in front of their first use
-#define RES_WAIT_TILES(n)                                                                          \
-    do {                                                                                           \
-        if ((n) >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");                            \
-        else if ((n) == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                        \
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                      \
-        asm volatile("" : "+v"(qa[0]), "+v"(qa[1]), "+v"(qa[2]), "+v"(qa[3]), "+v"(qb[0]), "+v"(qb[1]), "+v"(qb[2]), "+v"(qb[3]) :: "memory"); \
-        __builtin_amdgcn_s_barrier();                                                              \
-    } while (0)
-#define RES_STEP2(J, KF, KN, PRE) res_step2<(J) * TILE_B, (J) * TILE_B, PRE>(L, 32 * (J), kad, vad, KF, KN, qa, qb, hi, ma, la, oa0, oa1, mb, lb, ob0, ob1)
-
-// dbg != nullptr (tools/ubench_valu.hip only): wave 0 records s_memtime stamps of its phases, 16 per workgroup
-#define RES_STAMP(i) do { if (dbg && tid == 0) dbg[blockIdx.x * 16 + (i)] = (i) == 0 ? (long long)wall_clock64() : (long long)__builtin_readcyclecounter(); } while (0)
-__global__ __launch_bounds__(256, 2) void attn_fwd_res(SeqDesc sd, int nt, const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse, long long* __restrict__ dbg) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, hi = lane >> 5;
-    const int pair = blockIdx.x;
-    RES_STAMP(0); RES_STAMP(1);
-    const int item = pair / sd.heads, head = pair - item * sd.heads;
-    const long base = seq_base(sd, item);
-    const long ld3 = 3L * sd.D, pse = sd.pos_stride * ld3;
-    const bf16_t* qh = qkv + base * ld3 + head * ATT_HD;
-    char* kt = smem;
-    char* vt = smem + RES_V0;
-    const int L = sd.L;
-    // query tiles of this wave: (ta, ta + 1) against all keys, tx against one half of the keys
-    const int nd = nt < 8 ? nt : 8;
-    const int ta = 2 * wave, tx = 8 + (wave >> 1);
-    const bool act_a = ta < nd, act_b = ta + 1 < nd, act_x = tx < nt;
-    const int qra = 32 * ta + l31, qrb = qra + 32, qrx = 32 * tx + l31;
-    bf16x8 qa[4], qb[4];
-    {
-        const int ca = qra < L ? qra : L - 1, cb = qrb < L ? qrb : L - 1;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            gload_frag_asm(qa[ks], qh + (size_t)ca * pse + 16 * ks + 8 * hi);
-            gload_frag_asm(qb[ks], qh + (size_t)cb * pse + 16 * ks + 8 * hi);
-        }
-    }
-    int mine = 0;                                    // tiles this wave loads: wave, wave + 4, wave + 8
-#pragma unroll
-    for (int g = 0; g < 3; ++g) {
-        const int t = 4 * g + wave;
-        if (t < nt) {
-            load_tile(qh + sd.D, pse, 32 * t, L, kt + t * TILE_B, lane);
-            load_tile(qh + 2 * sd.D, pse, 32 * t, L, vt + t * TILE_B, lane);
-            ++mine;
-        }
-    }
-    f32x16 oa0, oa1, ob0, ob1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { oa0[r] = 0.f; oa1[r] = 0.f; ob0[r] = 0.f; ob1[r] = 0.f; }
-    float ma = -1e30f, la = 0.f, mb = -1e30f, lb = 0.f;
-    uint32_t kad[4], vad[4];
-    res_offsets(kad, vad, lane);
-    {
-        const uint32_t s0 = (uint32_t)(uintptr_t)(LDS_PTR(char))smem;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { kad[i] += s0; vad[i] += s0 + RES_V0; }        // (immediate offsets are 16 bits: V gets its own base)
-    }
-    u32x4_t k0[4], k1[4];
-    // ---- key tiles 0..3
-    RES_STAMP(2);
-    RES_WAIT_TILES(mine - 1);
-    RES_STAMP(3);
-    if (act_a) {
-        res_read_k<0>(k0, kad);
-        RES_STEP2(0, k0, k1, true);
-        if (nt > 1) RES_STEP2(1, k1, k0, true);
-        if (nt > 2) RES_STEP2(2, k0, k1, true);
-        if (nt > 3) RES_STEP2(3, k1, k0, false);
-    }
-    RES_STAMP(4);
-    if (nt > 4) {
-        RES_WAIT_TILES(mine - 2);
-        RES_STAMP(5);
-        if (act_a) {
-            res_read_k<4 * TILE_B>(k0, kad);
-            RES_STEP2(4, k0, k1, true);
-            if (nt > 5) RES_STEP2(5, k1, k0, true);
-            if (nt > 6) RES_STEP2(6, k0, k1, true);
-            if (nt > 7) RES_STEP2(7, k1, k0, false);
-        }
-    }
-    RES_STAMP(6);
-    bf16x8 qx[4];
-    if (act_x) {                                    // query fragments of the leftover tile: in flight before the last tile-group wait, which covers them
-        const int cx = qrx < L ? qrx : L - 1;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) gload_frag_asm(qx[ks], qh + (size_t)cx * pse + 16 * ks + 8 * hi);
-    }
-    if (nt > 8) {
-        RES_WAIT_TILES(0);
-        RES_STAMP(7);
-        if (act_x) asm volatile("" : "+v"(qx[0]), "+v"(qx[1]), "+v"(qx[2]), "+v"(qx[3]) :: "memory");
-        if (act_a) {
-            res_read_k<8 * TILE_B>(k0, kad);
-            RES_STEP2(8, k0, k1, true);
-            if (nt > 9) RES_STEP2(9, k1, k0, false);
-        }
-    }
-    // (a trailing prefetch past the last tile reads allocated LDS; its destination registers stay reserved until it has landed)
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(k0[0]), "+v"(k0[1]), "+v"(k0[2]), "+v"(k0[3]), "+v"(k1[0]), "+v"(k1[1]), "+v"(k1[2]), "+v"(k1[3]) :: "memory");
-    RES_STAMP(8);
-    if (act_a) fwd_store(sd, base, head, qra, hi, ma, la, oa0, oa1, out, lse);
-    if (act_b) fwd_store(sd, base, head, qrb, hi, mb, lb, ob0, ob1, out, lse);
-    RES_STAMP(9);
-    if (nt <= 8) return;
-    // ---- the leftover query tiles, split by keys over the wave pairs; all of K / V is resident by now
-    const int half = wave & 1;
-    const int ksplit = nt >> 1;
-    const int j0 = half ? ksplit : 0, nj = half ? nt - ksplit : ksplit;       // nt in {9, 10}: 4 or 5 steps
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { oa0[r] = 0.f; oa1[r] = 0.f; }
-    ma = -1e30f; la = 0.f;
-    if (act_x) {
-        uint32_t kx[4], vx[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { kx[i] = kad[i] + j0 * TILE_B; vx[i] = vad[i] + j0 * TILE_B; }
-        res_read_k<0>(k0, kx);
-        res_step1<0, true>(L, 32 * j0, kx, vx, k0, k1, qx, hi, ma, la, oa0, oa1);
-        res_step1<TILE_B, true>(L, 32 * j0 + 32, kx, vx, k1, k0, qx, hi, ma, la, oa0, oa1);
-        res_step1<2 * TILE_B, true>(L, 32 * j0 + 64, kx, vx, k0, k1, qx, hi, ma, la, oa0, oa1);
-        res_step1<3 * TILE_B, true>(L, 32 * j0 + 96, kx, vx, k1, k0, qx, hi, ma, la, oa0, oa1);
-        if (nj > 4) res_step1<4 * TILE_B, false>(L, 32 * j0 + 128, kx, vx, k0, k1, qx, hi, ma, la, oa0, oa1);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(k0[0]), "+v"(k0[1]), "+v"(k0[2]), "+v"(k0[3]), "+v"(k1[0]), "+v"(k1[1]), "+v"(k1[2]), "+v"(k1[3]) :: "memory");
-    RES_STAMP(10);
-    __builtin_amdgcn_s_barrier();                   // every wave is done with K / V: the region now carries the partial results
-    RES_STAMP(11);
-    float* mb_ = reinterpret_cast<float*>(smem + (wave >> 1) * RES_MERGE_B);
-    if (half == 1 && act_x) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { mb_[r * 64 + lane] = oa0[r]; mb_[(16 + r) * 64 + lane] = oa1[r]; }
-        mb_[32 * 64 + lane] = ma; mb_[33 * 64 + lane] = la;
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (half == 0 && act_x) {
-        const float m2 = mb_[32 * 64 + lane], l2 = mb_[33 * 64 + lane];
-        const float mn = fmaxf(ma, m2);
-        const float a1 = exp2f(ma - mn), a2 = exp2f(m2 - mn);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { oa0[r] = oa0[r] * a1 + mb_[r * 64 + lane] * a2; oa1[r] = oa1[r] * a1 + mb_[(16 + r) * 64 + lane] * a2; }
-        la = la * a1 + l2 * a2;
-        fwd_store(sd, base, head, qrx, hi, mn, la, oa0, oa1, out, lse);
-    }
-    RES_STAMP(12);
-    if (dbg && tid == 0) dbg[blockIdx.x * 16 + 13] = (long long)wall_clock64();
-}
-
-// ------------------------------------------------------------------------------------------------ persistent forward (spatial, S <= 320)
-// What the timeline of the resident kernel showed (tools/ubench_valu.hip part D, profiles/r03_ubench_valu.txt): a wave that issues its
-// 24 tile loads up front sits in the ISSUE of those loads for 11 500 cycles (the memory pipe takes ~12 B/clk per CU, all CUs pulling at once),
-// a quarter of the workgroup's life, and 1080 workgroups on 512 slots run as three rounds.  So: ONE persistent 640-thread workgroup per CU
-// walks its (frame, head) pairs; LDS holds TWO K / V images (2 x 80 KiB = all of it) and while pair p is multiplied out of one, every wave
-// drips the loads of pair p + 1 into the other -- one direct-to-LDS wave-load per key step, its query fragments by inline-asm loads -- so no
-// wave ever waits for memory except behind the first pair.  Wave w owns query tile w (10 waves for the 10 tiles of S = 301, no idle slots,
-// no key split) and loads K / V tile w.  One raw s_barrier per pair; the finished tile is stored after it, so the store latency runs under
-// the next pair.  PRE: the caller delivers Q already multiplied by log2(e) / 8 (folded into the projection weights, engine.py) -- then the
-// running maximum enters through the C operand of the first score MFMA (a 16-register tuple holding -m) and the exponent argument needs
-// no VALU instruction at all.
-constexpr int P10_WAVES = 10;
-
-// qnext != nullptr: this is the pair's last key step -- once its score MFMAs have issued (i.e. read their operands) the query fragment
-// registers are free, and the NEXT pair's fragments are requested into them (inline-asm loads; the end-of-pair vmcnt(0) covers them).
-template <int OFF, bool FIRST, bool PREFETCH, bool PRE>
-__device__ __forceinline__ void p10_step(int L, int key0, const uint32_t (&kad)[4], const uint32_t (&vad)[4], u32x4_t (&kf)[4], bf16x8 (&q)[4], int hi,
-                                         float& m, float& l, f32x16& negm, f32x16& o0, f32x16& o1, const bf16_t* qnext = nullptr) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3]) :: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    f32x16 s;
-    if (PRE) {
-        // D = A B + C with C = the tuple holding -m and a separate D (the builtin ties C to D: 16 moves per step)
-        asm volatile("s_nop 1\n\t" TCOW_MFMA_32x32x16_H16_ASM " %0, %1, %2, %3" : "=&v"(s) : "v"(kf[0]), "v"(q[0]), "v"(negm));
-    } else {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = 0.f;
-        s = TCOW_MFMA_32x32x16_H16(__builtin_bit_cast(bf16x8, kf[0]), q[0], s, 0, 0, 0);
-    }
-#pragma unroll
-    for (int ks = 1; ks < 4; ++ks) s = TCOW_MFMA_32x32x16_H16(__builtin_bit_cast(bf16x8, kf[ks]), q[ks], s, 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    VFrag v;
-    res_read_v<OFF>(v, vad);
-    if (PREFETCH) res_read_k<OFF + TILE_B>(kf, kad);         // (the score MFMAs above have issued, i.e. read their operands)
-    if (qnext) {
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) gload_frag_asm(q[ks], qnext + 16 * ks);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (key0 + 31 >= L) {                                    // the sequence's last key tile: keys past the end take no part
-        // (asm: one compare against a scalar + one select per register through VCC; left to hipcc, each of the ten unrolled steps keeps
-        // sixteen compare results in SGPR pairs and the kernel spills hundreds of SGPRs)
-        const int kk = key0 + 4 * hi;
-        const float neg = -1e30f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int thr = L - ((r & 3) + 8 * (r >> 2));             // key0 + crow32(r, hi) >= L  <=>  thr <= kk
-            asm volatile("v_cmp_le_i32 vcc, %1, %2\n\tv_cndmask_b32 %0, %0, %3, vcc" : "+v"(s[r]) : "s"(thr), "v"(kk), "v"(neg) : "vcc");
-        }
-    }
-    float mx = s[0];
-#pragma unroll
-    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
-    mx = half_max(mx);
-    float p[16];
-    float ps = 0.f;
-    if (PRE) {
-        // s = score - m already (log2 units).  First tile: the reference maximum becomes this tile's; later: lazy, see fwd_tile
-        if (FIRST || __any(mx > 8.0f)) {
-            const float delta = FIRST ? mx : fmaxf(mx, 0.f);
-            if (!FIRST) {
-                const float alpha = exp2f(-delta);
-                l *= alpha;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
-            }
-            m += delta;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] -= delta; negm[r] = -m; }
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { p[r] = __builtin_amdgcn_exp2f(s[r]); ps += p[r]; }
-    } else {
-        const float sc = kScale * kLog2e;
-        mx *= sc;
-        if (__any(mx > m + 8.0f)) {
-            const float mn = fmaxf(m, mx);
-            const float alpha = exp2f(m - mn);
-            l *= alpha; m = mn;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { p[r] = __builtin_amdgcn_exp2f(fmaf(s[r], sc, -m)); ps += p[r]; }
-    }
-    l += ps;
-    const bf16x8 p0 = pack8(p), p1 = pack8(p + 8);
-    if (PREFETCH) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(v.l00), "+v"(v.h00), "+v"(v.l01), "+v"(v.h01), "+v"(v.l10), "+v"(v.h10), "+v"(v.l11), "+v"(v.h11) :: "memory");
-    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v.l00), "+v"(v.h00), "+v"(v.l01), "+v"(v.h01), "+v"(v.l10), "+v"(v.h10), "+v"(v.l11), "+v"(v.h11) :: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    o0 = TCOW_MFMA_32x32x16_H16(RES_FRAG(v.l00, v.h00), p0, o0, 0, 0, 0);
-    o1 = TCOW_MFMA_32x32x16_H16(RES_FRAG(v.l01, v.h01), p0, o1, 0, 0, 0);
-    o0 = TCOW_MFMA_32x32x16_H16(RES_FRAG(v.l10, v.h10), p1, o0, 0, 0, 0);
-    o1 = TCOW_MFMA_32x32x16_H16(RES_FRAG(v.l11, v.h11), p1, o1, 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-}
-
-// normalise + store one query tile with 16-byte stores: the O^T accumulators hold, per lane (q, hi), the channels 8 g + 4 hi + 0..3 of
-// every group g; one v_permlane32_swap per dword trades the odd group of the lower half-wave against the even group of the upper one,
-// after which each lane owns 8 consecutive channels (MI355X guide T21: half the store instructions for the same bytes)
-__device__ __forceinline__ void fwd_store16(const SeqDesc& sd, long base, int head, int q, int hi, float m, float l, const f32x16& o0, const f32x16& o1,
-                                            bf16_t* __restrict__ out, float* __restrict__ lse) {
-    l = half_sum(l);
-    const float inv = 1.0f / l;
-    const long row = base + (long)(q < sd.L ? q : sd.L - 1) * sd.pos_stride;
-    bf16_t* orow = out + row * sd.D + head * ATT_HD + (hi ? 8 : 0);
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt) {
-        const f32x16& o = dt ? o1 : o0;
-#pragma unroll
-        for (int gp = 0; gp < 2; ++gp) {
-            const int g = 2 * gp;
-            uint32_t x0 = pack_bf2(o[4 * g] * inv, o[4 * g + 1] * inv), x1 = pack_bf2(o[4 * g + 2] * inv, o[4 * g + 3] * inv);
-            uint32_t y0 = pack_bf2(o[4 * g + 4] * inv, o[4 * g + 5] * inv), y1 = pack_bf2(o[4 * g + 6] * inv, o[4 * g + 7] * inv);
-            asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x0), "+v"(y0));
-            asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x1), "+v"(y1));
-            if (q < sd.L) *reinterpret_cast<uint4*>(orow + 32 * dt + 16 * gp) = make_uint4(x0, x1, y0, y1);
-        }
-    }
-    if (lse && hi == 0 && q < sd.L) lse[row * sd.heads + head] = (m + log2f(l)) * 0.6931471805599453f;
-}
-
-#define P10_STEP(J, FIRST, PRE_) p10_step<(J) * TILE_B, FIRST, PRE_, PRE>(L, 32 * (J), kad, vad, kf, q, hi, m, l, negm, o0, o1, (J) == nt - 1 ? qnext : nullptr)
-// One wave-load of the NEXT pair per key step: K chunks 0..3 of tile `wave` before steps 0..3, V chunks before steps 4..7.  Inline asm with a
-// scalar base (the pair's K / V column, uniform) + a 32-bit per-lane offset that is the same for every pair (4 registers for the whole
-// kernel; as 64-bit per-lane pointers the eight addresses were recomputed per pair and spilled), M0 = LDS destination of the wave-load.
-__device__ __forceinline__ void glds16_sbase(uint32_t voff, const void* sbase, uint32_t lds_dst) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
-}
-#define P10_DRIP(J)                                                                                                                  \
-    do {                                                                                                                             \
-        if (feed) {                                                                                                                  \
-            if ((J) < 4) glds16_sbase(doff[(J) & 3], qn_h + sd.D, ndst + ((J) & 3) * 1024);                                                    \
-            else if ((J) < 8) glds16_sbase(doff[(J) & 3], qn_h + 2 * sd.D, ndst + RES_V0 + ((J) & 3) * 1024);                        \
-        }                                                                                                                            \
-    } while (0)
-
-template <bool PRE>
-__global__ __launch_bounds__(640) void attn_fwd_p10(SeqDesc sd, int nt, int npairs, const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse,
-                                                   long long* __restrict__ dbg) {
-#define P10_STAMP(i) do { if (dbg && lane == 0 && it == 1) dbg[(blockIdx.x * 10 + wave) * 8 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, hi = lane >> 5;
-    const long ld3 = 3L * sd.D, pse = sd.pos_stride * ld3;
-    const int L = sd.L;
-    const bool act = wave < nt;                      // this wave owns query tile `wave` and loads K / V tile `wave`
-    const int qr = 32 * wave + l31;
-    const int qc = qr < L ? qr : L - 1;
-    uint32_t kad[4], vad[4];
-    res_offsets(kad, vad, lane);
-    const uint32_t s0 = (uint32_t)(uintptr_t)(LDS_PTR(char))smem;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { kad[i] += s0; vad[i] += s0 + RES_V0; }
-    uint32_t doff[4];                                // byte offset of this lane's 16 bytes in wave-load c of tile `wave`, relative to the pair's K (V) column
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const int r = 8 * c + (lane >> 3);
-        int pos = 32 * wave + r; pos = pos < L ? pos : L - 1;
-        doff[c] = (uint32_t)((long)pos * pse * 2 + (((lane & 7) ^ swz_g(r)) << 4));
-    }
-
-    int pair = blockIdx.x;
-    bf16x8 q[4];
-    {   // first pair: everything at once, nothing to hide behind
-        const int item = pair / sd.heads, head = pair - item * sd.heads;
-        const bf16_t* qh = qkv + seq_base(sd, item) * ld3 + head * ATT_HD;
-        if (act) {
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) gload_frag_asm(q[ks], qh + (size_t)qc * pse + 16 * ks + 8 * hi);
-            load_tile(qh + sd.D, pse, 32 * wave, L, smem + wave * TILE_B, lane);
-            load_tile(qh + 2 * sd.D, pse, 32 * wave, L, smem + RES_V0 + wave * TILE_B, lane);
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]) :: "memory");
-    __builtin_amdgcn_s_barrier();
-    for (int it = 0;; ++it) {
-        const int cur = it & 1;
-        const int item = pair / sd.heads, head = pair - item * sd.heads;
-        const long base = seq_base(sd, item);
-        const int npair = pair + gridDim.x;
-        const bool feed = act && npair < npairs;
-        const int nitem = feed ? npair / sd.heads : item, nhead = feed ? npair - nitem * sd.heads : head;
-        const bf16_t* qn_h = qkv + seq_base(sd, nitem) * ld3 + nhead * ATT_HD;
-        const uint32_t ndst = s0 + (cur ^ 1) * RES_LDS + wave * TILE_B;      // LDS address of K tile `wave` in the other image
-        f32x16 o0, o1, negm;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; negm[r] = 0.f; }
-        float m = PRE ? 0.f : -1e30f, l = 0.f;
-        const bf16_t* qnext = feed ? qn_h + (size_t)qc * pse + 8 * hi : nullptr;
-        u32x4_t kf[4];
-        P10_STAMP(0);
-        if (act) {
-            res_read_k<0>(kf, kad);
-            P10_DRIP(0); P10_STEP(0, true, true);
-            if (nt > 1) { P10_DRIP(1); P10_STEP(1, false, true); }
-            if (nt > 2) { P10_DRIP(2); P10_STEP(2, false, true); }
-            if (nt > 3) { P10_DRIP(3); P10_STEP(3, false, true); }
-            P10_STAMP(1);
-            if (nt > 4) { P10_DRIP(4); P10_STEP(4, false, true); }
-            if (nt > 5) { P10_DRIP(5); P10_STEP(5, false, true); }
-            if (nt > 6) { P10_DRIP(6); P10_STEP(6, false, true); }
-            if (nt > 7) { P10_DRIP(7); P10_STEP(7, false, true); }
-            P10_STAMP(2);
-            if (nt > 8) { P10_STEP(8, false, true); }
-            if (nt > 9) { P10_STEP(9, false, false); }
-            if (nt < 8) {                            // short sequences: the wave-loads no key step carried
-#pragma unroll
-                for (int c = 0; c < 8; ++c) if (c >= nt) P10_DRIP(c);
-            }
-            // (a trailing K prefetch past the last tile reads allocated LDS; its destination registers stay reserved until it has landed)
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3]) :: "memory");
-        }
-        // the next pair's image and query fragments have landed (every wave waits for its own loads), and every wave is done with this one
-        P10_STAMP(3);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]) :: "memory");
-        P10_STAMP(4);
-        __builtin_amdgcn_s_barrier();
-        P10_STAMP(5);
-        if (act) fwd_store_rows(sd, base, head, 32 * wave, lane, m, l, o0, o1, s0 + cur * RES_LDS + RES_V0 + wave * TILE_B, out, lse);
-        P10_STAMP(6);
-        if (npair >= npairs) break;
-        pair = npair;
-        if (cur == 0) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { kad[i] += RES_LDS; vad[i] += RES_LDS; }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { kad[i] -= RES_LDS; vad[i] -= RES_LDS; }
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------ backward prep
 // ld[(item*heads + h)*Lp + q] = (lse, delta), delta = sum_d dO*O  -- packed per sequence so the kernels read it contiguously
 __global__ void attn_bwd_prep_kernel(SeqDesc sd, int Lp, const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout, const float* __restrict__ lse,
@@ -1228,12 +693,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_one_tile(SeqDesc sd, const bf
 // wave, and walks the other side in chunks of 4 tiles staged in 32 KiB of LDS (wave w loads tile 4c+w of the chunk).
 template <int CH>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_stream(SeqDesc sd, int nt, const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
-                                                           const float2* __restrict__ ld, bf16_t* __restrict__ dqkv, long long* __restrict__ dbg) {
+                                                           const float2* __restrict__ ld, bf16_t* __restrict__ dqkv) {
     __shared__ __attribute__((aligned(16))) char smem[2 * CH * TILE_B];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
-#define STREAM_STAMP(i) do { if (dbg && lane == 0) dbg[(blockIdx.x * 4 + wave) * 24 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+#ifdef UBENCH_ATTN          // phase stamps of tools/ubench_valu.hip (part E): compiled into the micro-benchmark only
+#define STREAM_STAMP(i) do { if (g_attn_dbg && lane == 0) g_attn_dbg[(blockIdx.x * 4 + wave) * 24 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define STREAM_STAMP(i) do { } while (0)
+#endif
     const StreamWork sw_ = stream_work(sd.n_outer * sd.n_inner * sd.heads, (nt + 3) / 4);
     if (!sw_.valid) return;
     STREAM_STAMP(0);
@@ -1289,7 +758,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_stream(SeqDesc sd, int nt
 // its queries and publishes the packed (lse, delta) table that the dK / dV kernel reads -- no separate preparation launch.)
 template <int CH>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_stream(SeqDesc sd, int nt, const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
-                                                          const float* __restrict__ lse, float2* __restrict__ ld, bf16_t* __restrict__ dqkv, long long* __restrict__ dbg) {
+                                                          const float* __restrict__ lse, float2* __restrict__ ld, bf16_t* __restrict__ dqkv) {
     __shared__ __attribute__((aligned(16))) char smem[2 * CH * TILE_B];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1364,23 +833,18 @@ static void set_lds_attr(K kernel, int bytes) {
 
 }  // namespace
 
-// nt = number of 32-position tiles; returns false when the MFMA kernels do not cover this shape
-// shared sequences: 1 = resident K/V (S <= 320), 2 = streaming (any length, default)
-static int shared_variant() { static const int v = [] { const char* e = getenv("TCOW_ATTN_SHARED"); return e ? atoi(e) : 2; }(); return v; }
-// spatial sequences of <= 10 tiles without a causal mask: TCOW_ATTN_RES=1 the resident kernel (2 workgroups per CU), =2 the persistent
-// 10-wave kernel, 0 (default) the streaming kernels -- see profiles/r03_attention.md for the measurements behind the default
+// nt = number of 32-position tiles.  Workgroup-shared (spatial) sequences and temporal sequences of more than 64 positions take the streaming
+// kernels; shorter temporal sequences the wave-private ones.  (The resident / persistent forward variants of round 3 are in
+// tools/attn_fwd_variants.inc, the whole-sequence-resident SHARED = true instantiations of the *_mfma kernels are no longer built.)
 // streaming kernels: tiles per LDS chunk -- 5 when that saves a chunk round (nt = 10: two rounds instead of three), else 4; TCOW_ATTN_CH=4|5 forces
 static bool stream_ch5(int nt) {
     static const int v = [] { const char* e = getenv("TCOW_ATTN_CH"); return e ? atoi(e) : 0; }();
     return v == 5 || (v != 4 && (nt + 4) / 5 < (nt + 3) / 4);
 }
-static int res_variant() { static const int v = [] { const char* e = getenv("TCOW_ATTN_RES"); return e ? atoi(e) : 0; }(); return v; }
-static bool use_res(const SeqDesc& d, bool shared, int nt) { return shared && res_variant() != 0 && nt <= RES_MAX_NT && d.diag >= (1 << 27) && d.L >= 2; }
 
 bool tcow_attn_mfma_supported(const SeqDesc& d, bool shared) {
-    const int nt = (d.L + 31) / 32;
-    if (shared) return shared_variant() == 2 ? true : nt <= 10;
-    return true;      // temporal: wave-private tiles up to T = 64, the streaming kernels beyond
+    (void)d; (void)shared;
+    return true;      // every length: wave-private tiles for temporal sequences up to T = 64, the streaming kernels otherwise
 }
 
 // true when the kernel this shape dispatches to writes the zero rows of the skipped slot 0 itself (wave-private temporal kernels)
@@ -1393,22 +857,9 @@ bool tcow_attn_mfma_zeroes_slot0(const SeqDesc& d, bool shared, bool backward) {
 int tcow_attn_mfma_fwd(hipStream_t st, const SeqDesc& d, bool shared, const void* qkv, void* out, float* lse) {
     const int nt = (d.L + 31) / 32;
     const int pairs = d.n_outer * d.n_inner * d.heads;
-    if (use_res(d, shared, nt) && res_variant() == 2) {
-        static int ncu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
-        const int grid = pairs < ncu ? pairs : ncu;
-        set_lds_attr(attn_fwd_p10<false>, 2 * RES_LDS);
-        hipLaunchKernelGGL(attn_fwd_p10<false>, dim3(grid), dim3(640), 2 * RES_LDS, st, d, nt, pairs, (const bf16_t*)qkv, (bf16_t*)out, lse, (long long*)nullptr);
-    } else if (use_res(d, shared, nt)) {
-        const int lds = RES_LDS;
-        set_lds_attr(attn_fwd_res, lds);
-        hipLaunchKernelGGL(attn_fwd_res, dim3(pairs), dim3(256), lds, st, d, nt, (const bf16_t*)qkv, (bf16_t*)out, lse, (long long*)nullptr);
-    } else if ((shared && shared_variant() == 2) || (!shared && nt > 2)) {
+    if (shared || nt > 2) {
         // (forward: four tiles per chunk -- with five, 40 KiB per workgroup, the fourth workgroup of a CU no longer fits and 56 us become 60)
         hipLaunchKernelGGL(attn_fwd_stream<4>, dim3(stream_grid(pairs, cdiv(nt, 4))), dim3(256), 0, st, d, nt, (const bf16_t*)qkv, (bf16_t*)out, lse);
-    } else if (shared) {
-        const int lds = 2 * nt * TILE_B;
-        set_lds_attr(attn_fwd_mfma<true>, lds);
-        hipLaunchKernelGGL(attn_fwd_mfma<true>, dim3(pairs), dim3(256), lds, st, d, nt, (const bf16_t*)qkv, (bf16_t*)out, lse, 0);
     } else {
         const int lds = 4 * 3 * nt * TILE_B;
         set_lds_attr(attn_fwd_mfma<false>, lds);
@@ -1437,29 +888,23 @@ int tcow_attn_mfma_bwd(hipStream_t st, const SeqDesc& d, bool shared, const void
     float2* ld = (float2*)ws;
     const long total = (long)pairs * nt * 32;
     int blocks = cdiv(total, 256); if (blocks > 8192) blocks = 8192;
-    if ((shared && shared_variant() == 2) || (!shared && nt > 2)) {
+    if (shared || nt > 2) {
         const dim3 sg(stream_grid(pairs, cdiv(nt, 4)));
         if (stream_ch5(nt)) {
-            hipLaunchKernelGGL(attn_bwd_dq_stream<5>, sg, dim3(256), 0, st, d, nt, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, ld, (bf16_t*)dqkv, (long long*)nullptr);
+            hipLaunchKernelGGL(attn_bwd_dq_stream<5>, sg, dim3(256), 0, st, d, nt, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, ld, (bf16_t*)dqkv);
             TCOW_CHECK_LAUNCH();
-            hipLaunchKernelGGL(attn_bwd_dkv_stream<5>, sg, dim3(256), 0, st, d, nt, (const bf16_t*)qkv, (const bf16_t*)dout, ld, (bf16_t*)dqkv, (long long*)nullptr);
+            hipLaunchKernelGGL(attn_bwd_dkv_stream<5>, sg, dim3(256), 0, st, d, nt, (const bf16_t*)qkv, (const bf16_t*)dout, ld, (bf16_t*)dqkv);
         } else {
-            hipLaunchKernelGGL(attn_bwd_dq_stream<4>, sg, dim3(256), 0, st, d, nt, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, ld, (bf16_t*)dqkv, (long long*)nullptr);
+            hipLaunchKernelGGL(attn_bwd_dq_stream<4>, sg, dim3(256), 0, st, d, nt, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, ld, (bf16_t*)dqkv);
             TCOW_CHECK_LAUNCH();
-            hipLaunchKernelGGL(attn_bwd_dkv_stream<4>, sg, dim3(256), 0, st, d, nt, (const bf16_t*)qkv, (const bf16_t*)dout, ld, (bf16_t*)dqkv, (long long*)nullptr);
+            hipLaunchKernelGGL(attn_bwd_dkv_stream<4>, sg, dim3(256), 0, st, d, nt, (const bf16_t*)qkv, (const bf16_t*)dout, ld, (bf16_t*)dqkv);
         }
         TCOW_CHECK_LAUNCH();
         return TCOW_OK;
     }
     hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3(blocks), dim3(256), 0, st, d, nt * 32, (const bf16_t*)out, (const bf16_t*)dout, lse, ld);
     TCOW_CHECK_LAUNCH();
-    if (shared) {
-        const int lds = 2 * nt * TILE_B;
-        set_lds_attr(attn_bwd_dkv_mfma<true>, lds); set_lds_attr(attn_bwd_dq_mfma<true>, lds);
-        hipLaunchKernelGGL(attn_bwd_dkv_mfma<true>, dim3(pairs), dim3(256), lds, st, d, nt, (const bf16_t*)qkv, (const bf16_t*)dout, ld, (bf16_t*)dqkv);
-        TCOW_CHECK_LAUNCH();
-        hipLaunchKernelGGL(attn_bwd_dq_mfma<true>, dim3(pairs), dim3(256), lds, st, d, nt, (const bf16_t*)qkv, (const bf16_t*)dout, ld, (bf16_t*)dqkv);
-    } else {
+    {
         const int lds = 4 * 2 * nt * TILE_B;
         set_lds_attr(attn_bwd_dkv_mfma<false>, lds); set_lds_attr(attn_bwd_dq_mfma<false>, lds);
         hipLaunchKernelGGL(attn_bwd_dkv_mfma<false>, dim3(cdiv(pairs, 4)), dim3(256), lds, st, d, nt, (const bf16_t*)qkv, (const bf16_t*)dout, ld, (bf16_t*)dqkv);

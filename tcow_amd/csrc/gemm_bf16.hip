@@ -298,7 +298,7 @@ constexpr int C_WTILE = C_BN * 128;             // 32 KiB
 constexpr int C_STAGE = C_ATILE + C_WTILE;      // 72 KiB
 constexpr int C_LDS = 2 * C_STAGE;              // 144 KiB
 
-// ML = 1: the main loop of gemm_p8.hip (16x16x32 MFMAs on 1 KiB subtiles, four phases per K tile, wave rows staggered by a barrier) in front of the
+// ML = 1: the main loop first built stand-alone in tools/gemm_p8.hip (16x16x32 MFMAs on 1 KiB subtiles, four phases per K tile, wave rows staggered by a barrier) in front of the
 // same epilogues: the accumulators then sit as [10 row blocks of 16][4 column blocks of 16] and only the staging step differs.
 template <typename E, int ML = 0>
 __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_320_kernel(NtParams p) {
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_320_kernel(NtParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc16[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if constexpr (ML == 1) {
-        // (see gemm_p8.hip for the layout and the ordering argument; BM = 320: 20 row blocks, 5 per wave and phase)
+        // (see tools/gemm_p8.hip for the layout and the ordering argument; BM = 320: 20 row blocks, 5 per wave and phase)
         constexpr int ARB = 20, RBH = 5, A_PLANE = ARB * 1024, KH = A_PLANE + 16 * 1024, KTILE = 2 * KH, NA = 3;
         const int wr = wm, wc = wn;
         const bf16_t* a_base = p.A + (size_t)m0 * p.lda;

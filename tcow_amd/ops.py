@@ -195,6 +195,31 @@ def resize_aa(frames, frame_idx, ys, xs, ymin, ysize, wy, ky, xmin, xsize, wx, k
     return out
 
 
+def photometric(frames, frame_idx, rect, order, factors, taps, gray):
+    """frames (3,Tv,H,W) f32 CUDA tensor in [0, 1], frame_idx int32 CUDA table, rect = (y0, x0, h, w) -> (3,Tc,h,w) f32: ColorJitter adjustments
+    `order` (list of 0 brightness / 1 contrast / 2 saturation / 3 hue, may be empty) with `factors` = (brightness, contrast, saturation, hue),
+    5-tap blur with the normalised `taps` (None: no blur), grayscale fold (see tcow_photometric)."""
+    import ctypes
+    _need_cuda(frames, frame_idx)
+    if frames.dtype != torch.float32 or not frames.is_contiguous() or frames.dim() != 4 or frames.shape[0] != 3:
+        raise L.TcowError('photometric: contiguous (3, Tv, H, W) f32 frames expected')
+    if frame_idx.dtype != torch.int32 or not frame_idx.is_contiguous():
+        raise L.TcowError('photometric: frame_idx must be a contiguous int32 tensor')
+    _, Tv, H, W = frames.shape
+    y0, x0, h, w = (int(v) for v in rect)
+    Tc = frame_idx.numel()
+    lib = L.lib()
+    nb = lib.tcow_photometric_workspace_bytes(Tc)
+    ws = torch.empty(max(nb // 4, 1), dtype=torch.float32, device=frames.device)
+    out = torch.empty(3, Tc, h, w, dtype=torch.float32, device=frames.device)
+    ops_arr = (ctypes.c_int * 4)(*([int(o) for o in order] + [0] * (4 - len(order))))
+    taps_arr = (ctypes.c_float * 5)(*([float(t) for t in taps] if taps is not None else [0.0] * 5))
+    fb, fc, fs, fh = (float(v) for v in factors)
+    L.check(lib.tcow_photometric(_stream(), Tv, H, W, Tc, y0, x0, h, w, frames.data_ptr(), frame_idx.data_ptr(), len(order), ops_arr, fb, fc, fs, fh,
+                                 1 if taps is not None else 0, taps_arr, 1 if gray else 0, ws.data_ptr(), nb, out.data_ptr()), 'tcow_photometric')
+    return out
+
+
 def im2col_channels(mode, src, P, normalise, out):
     """src (B,C,T,H,W) f32 -> out [B*T*S, C*P*P] (see tcow_im2col_channels)."""
     B, C, T, H, W = src.shape

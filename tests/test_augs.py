@@ -177,6 +177,67 @@ def test_photometric_operators_follow_the_published_definitions():
     assert augs.photometric_draws({'color_jitter': False, 'rgb_blur': False, 'rgb_grayscale': False}) == {}
 
 
+def _photometric_f64(x, draws):
+    """Independent float64 restatement of the three operators on a (T, 3, h, w) numpy stack: blends written out, python's colorsys for the
+    RGB -> HSV -> RGB hue path, scipy's sampled Gaussian with mirror boundary for the blur (no code shared with tcow_amd.augs)."""
+    import colorsys
+    from scipy import ndimage
+    x = x.astype(np.float64).copy()
+    gray = lambda a: (0.2989 * a[:, 0] + 0.587 * a[:, 1] + 0.114 * a[:, 2])[:, None]
+    if 'color_jitter' in draws:
+        order, fb, fc, fs, fh = draws['color_jitter']
+        for k in order:
+            if k == 0: x = np.clip(fb * x, 0, 1)
+            elif k == 1: x = np.clip(fc * x + (1 - fc) * gray(x).mean(axis=(1, 2, 3), keepdims=True), 0, 1)
+            elif k == 2: x = np.clip(fs * x + (1 - fs) * gray(x), 0, 1)
+            else:
+                y = np.empty_like(x)
+                for t in range(x.shape[0]):
+                    for i in range(x.shape[2]):
+                        for j in range(x.shape[3]):
+                            hh, sat, v = colorsys.rgb_to_hsv(*x[t, :, i, j])
+                            y[t, :, i, j] = colorsys.hsv_to_rgb((hh + fh) % 1.0, sat, v)
+                x = y
+    if 'rgb_blur' in draws:
+        sg = draws['rgb_blur']
+        x = ndimage.gaussian_filter1d(ndimage.gaussian_filter1d(x, sg, axis=-1, mode='mirror', radius=2), sg, axis=-2, mode='mirror', radius=2)
+    if draws.get('rgb_grayscale'):
+        x = np.repeat(gray(x), 3, axis=1)
+    return x
+
+
+@pytest.mark.gpu
+def test_photometric_kernel_vs_independent_float64(cuda):
+    """csrc/photometric.hip (ColorJitter in the drawn order + 5-tap reflect-padded blur + grayscale, frame selection and centre crop folded in)
+    against the INDEPENDENT float64 restatements above -- not against tcow_amd.augs' own tensor functions -- and, as a second reference, against
+    those tensor functions.  Frame sizes that are not multiples of the kernel's 32 x 32 tile, every operator alone and all orders of the jitter
+    chain that put contrast first / in the middle / last (its mean is taken on the image as the adjustments in front of it left it)."""
+    from tcow_amd import ops
+    g = torch.Generator().manual_seed(21)
+    cases = [
+        ((3, 6, 40, 52), (1, 3, 37, 45), [4, 0, 2], {'color_jitter': ([1, 0, 3, 2], 1.1, 0.9, 1.15, 0.05), 'rgb_blur': 1.3, 'rgb_grayscale': True}),
+        ((3, 5, 33, 70), (0, 2, 33, 64), [1, 1, 3], {'color_jitter': ([0, 2, 1, 3], 0.85, 1.18, 0.8, -0.1)}),
+        ((3, 4, 64, 64), (0, 0, 64, 64), [3, 0], {'color_jitter': ([3, 2, 0, 1], 1.2, 0.8, 1.2, 0.1), 'rgb_blur': 0.1}),
+        ((3, 3, 24, 20), (2, 1, 20, 17), [0, 2, 1], {'rgb_blur': 3.5}),
+        ((3, 3, 24, 20), (2, 1, 20, 17), [2], {'rgb_grayscale': True}),
+        ((3, 3, 35, 35), (1, 1, 33, 33), [1, 2], {'color_jitter': ([2, 3, 1, 0], 1.0, 1.0, 1.0, 0.0)}),
+    ]
+    for shape, rect, fi, draws in cases:
+        fr = torch.rand(*shape, generator=g)
+        fr[:, 0, :5, :5] = 0.5                                  # grey patch: max == min, the hue path's degenerate branch
+        y0, x0, h, w = rect
+        got = augs.photometric_hip(fr.to(cuda), fi, rect, draws).cpu()
+        assert tuple(got.shape) == (3, len(fi), h, w)
+        sel = fr[:, fi][:, :, y0:y0 + h, x0:x0 + w].permute(1, 0, 2, 3)                       # (T, 3, h, w)
+        want = _photometric_f64(sel.numpy(), draws).transpose(1, 0, 2, 3)
+        assert np.abs(got.numpy() - want).max() < 3e-6, (shape, draws)
+        second = augs.apply_photometric(sel, draws).permute(1, 0, 2, 3)
+        assert float((got - second).abs().max()) < 2e-6, (shape, draws)
+    # argument errors surface as exceptions
+    with pytest.raises(ops.L.TcowError):
+        ops.photometric(torch.zeros(3, 2, 8, 8, device=cuda), torch.zeros(1, dtype=torch.int32, device=cuda), (0, 0, 9, 8), [], (1, 1, 1, 0), None, False)
+
+
 @pytest.mark.gpu
 def test_apply_augs_with_photometric_operators(cuda):
     """The rgb modality through apply_augs with all three photometric operators on: equal to the operators applied to the selected,

@@ -18,8 +18,9 @@ import torch.multiprocessing as mp
 
 pytestmark = pytest.mark.gpu
 
-CFG = dict(num_total_frames=4, frame_height=64, frame_width=64, patch_size=16, causal_attention=1, norm_embeddings=False, depth=4,
-           track_map_stride=4, track_map_resize='bilinear', embed_dim=256, num_heads=4)
+def _cfg():
+    from tcow_amd import synth
+    return synth.seeker_config(num_total_frames=4, frame_height=64, frame_width=64, depth=4, embed_dim=256, num_heads=4)
 
 
 def _free_port():
@@ -29,7 +30,7 @@ def _free_port():
 def _net(precision):
     from conftest import build_hip_seeker
     from tcow_amd import synth
-    net = build_hip_seeker(CFG, synth.make_state_dict(CFG, 4242), precision).cuda()
+    net = build_hip_seeker(_cfg(), synth.make_state_dict(_cfg(), 4242), precision).cuda()
     net.train(True)
     return net
 
@@ -37,7 +38,8 @@ def _net(precision):
 def _grads(net, seed, hook=None, loss_scale=None):
     """One forward + backward of the engine on the clip of `seed`; returns {name: gradient copy}."""
     from tcow_amd import synth
-    clip = synth.make_clip(1, CFG['num_total_frames'], CFG['frame_height'], CFG['frame_width'], seed=seed)
+    cfg = _cfg()
+    clip = synth.make_clip(1, cfg['num_total_frames'], cfg['frame_height'], cfg['frame_width'], seed=seed)
     rgb = torch.from_numpy(clip['rgb']).cuda(); qm = torch.from_numpy(synth.make_query_mask(clip, 0, 0)).cuda()
     net.seeker.grad_hook = hook
     if loss_scale is not None:
@@ -94,7 +96,7 @@ def test_two_ranks_on_one_gpu_average_the_engine_gradients(cuda, precision):
     res = sorted(q.get(timeout=600) for _ in procs)
     for p in procs: p.join(timeout=120)
     for rank, n, worst, bad, ncoll, buckets, nbytes, tags in res:
-        assert n > 200 and not bad, (rank, n, worst, bad)         # all 247 trained tensors, each == mean of the two single-process gradients
+        assert n >= 85 and not bad, (rank, n, worst, bad)         # every trained tensor of the 4-block model (89), each == mean of the two single-process gradients
         assert ncoll == 1                                         # parameters + buffers of one dtype: ONE broadcast, not 251
         assert buckets >= 2 and nbytes > 0 and tags, (buckets, nbytes, tags)
     assert res[0][5:] == res[1][5:]

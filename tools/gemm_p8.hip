@@ -20,7 +20,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 
-#include "common.h"
+#include "../tcow_amd/csrc/common.h"
 
 namespace {
 

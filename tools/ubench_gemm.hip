@@ -6,7 +6,7 @@
 #include <string.h>
 #include <vector>
 #define TCOW_P8_DBG 1
-#include "../tcow_amd/csrc/gemm_p8.hip"
+#include "gemm_p8.hip"
 void tcow_set_error(const char*, ...) {}
 void tcow_ensure_lds(const void* k, int bytes) { (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); }
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)

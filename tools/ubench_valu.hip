@@ -21,6 +21,7 @@
 
 #define UBENCH_ATTN 1
 #include "../tcow_amd/csrc/attention_bf16.hip"
+#include "attn_fwd_variants.inc"
 
 // the library's error plumbing, not linked here
 void tcow_set_error(const char*, ...) {}
@@ -449,10 +450,11 @@ int main(int argc, char** argv) {
             hipLaunchKernelGGL(attn_fwd_stream<5>, dim3(grid), dim3(256), 0, 0, sd, 10, qkv, o, lse); CK(hipDeviceSynchronize());
             for (int which = 0; which < 4; ++which) {
                 auto launch = [&](long long* d) {
-                    if (which == 0) hipLaunchKernelGGL(attn_bwd_dq_stream<4>, dim3(grid), dim3(256), 0, 0, sd, 10, qkv, o, dout, lse, ldt, dqkv, d);
-                    else if (which == 1) hipLaunchKernelGGL(attn_bwd_dkv_stream<4>, dim3(grid), dim3(256), 0, 0, sd, 10, qkv, dout, ldt, dqkv, d);
-                    else if (which == 2) hipLaunchKernelGGL(attn_bwd_dq_stream<5>, dim3(grid), dim3(256), 0, 0, sd, 10, qkv, o, dout, lse, ldt, dqkv, d);
-                    else hipLaunchKernelGGL(attn_bwd_dkv_stream<5>, dim3(grid), dim3(256), 0, 0, sd, 10, qkv, dout, ldt, dqkv, d);
+                    CK(hipMemcpyToSymbol(HIP_SYMBOL(g_attn_dbg), &d, sizeof(d)));
+                    if (which == 0) hipLaunchKernelGGL(attn_bwd_dq_stream<4>, dim3(grid), dim3(256), 0, 0, sd, 10, qkv, o, dout, lse, ldt, dqkv);
+                    else if (which == 1) hipLaunchKernelGGL(attn_bwd_dkv_stream<4>, dim3(grid), dim3(256), 0, 0, sd, 10, qkv, dout, ldt, dqkv);
+                    else if (which == 2) hipLaunchKernelGGL(attn_bwd_dq_stream<5>, dim3(grid), dim3(256), 0, 0, sd, 10, qkv, o, dout, lse, ldt, dqkv);
+                    else hipLaunchKernelGGL(attn_bwd_dkv_stream<5>, dim3(grid), dim3(256), 0, 0, sd, 10, qkv, dout, ldt, dqkv);
                 };
                 for (int rep = 0; rep < 3; ++rep) launch(nullptr);
                 CK(hipEventRecord(e0)); for (int rep = 0; rep < 20; ++rep) launch(nullptr);
