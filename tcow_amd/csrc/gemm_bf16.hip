@@ -864,7 +864,11 @@ __device__ long long* g_tn_dbg; __device__ int g_tn_dbg_it;
 // one workgroup of the 256-tile weight-gradient GEMM `p`: pid = slice * tiles + tile
 // AB: ablation switches of tools/ubench_tn_ab.hip (0 in the library): 2 = no loads after the first stage, 4 = no barriers in the loop, 8 = no slab
 // store (accumulators kept alive), 16 = no transpose reads in the loop, 32 = no MFMAs, 64 = no bias column sums.
-template <int AB = 0>
+// SCHED = 1 (round 4): the stage's ONE wait + barrier sits between the third and the fourth k-step instead of at the stage end: the fourth
+// k-step's fragments are in registers by then, so its MFMAs run right behind the barrier while the NEXT stage's first fragments are read and the
+// stage after next is requested into the buffer this stage has just released -- no stage boundary at which all eight waves wait for the barrier,
+// then for their first transpose reads, with the matrix pipe idle.  (SCHED = 0: the round-3 order, kept for A/B through TCOW_GEMM_TN_SCHED=0.)
+template <int AB = 0, int SCHED = 1>
 __device__ __forceinline__ void tn256_body(const TnParams& p, const int pid, char* smem) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -956,9 +960,14 @@ __device__ __forceinline__ void tn256_body(const TnParams& p, const int pid, cha
     float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     const int nmt = (mend - mbeg + T2_MC - 1) / T2_MC;
+    auto issue_stage = [&](int st_, int buf_) {
+        const int mt = mbeg + st_ * T2_MC;
+        if (interior && mt + T2_MC <= mend) issue_fast(mt, buf_); else issue(mt, buf_);
+    };
     if (nmt > 0) {
         issue(mbeg, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (SCHED == 1 && nmt > 1) { issue_stage(1, 1); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }      // stage 1 (8 loads per wave) stays in flight
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
     // Transpose reads software-pipelined by hand, as in the NT kernels: the 12 ds_read_b64_tr_b16 of k-step ks+1 are issued
@@ -1001,55 +1010,94 @@ __device__ __forceinline__ void tn256_body(const TnParams& p, const int pid, cha
             for (int i = 0; i < 4; ++i) { fyl[b][i] = (u32x2){5u, 6u}; fyh[b][i] = (u32x2){7u, 8u}; }
         }
     }
-    for (int it = 0; it < nmt; ++it) {
-        const int stage = it & 1;
-        const uint32_t so = (uint32_t)stage * T2_STAGE;
-        TN_STAMP(0);
-        if (it + 1 < nmt && !(AB & 2)) {
-            const int mt = mbeg + (it + 1) * T2_MC;
-            if (interior && mt + T2_MC <= mend) issue_fast(mt, stage ^ 1); else issue(mt, stage ^ 1);
-        }
-        TN_STAMP(1);
-        const char* sy = smem + stage * T2_STAGE;
-        TCOW_TN_READ(1, 1, so);
-        asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        TN_STAMP(2);
-        TCOW_TN_MFMA8(0);
-        TCOW_TN_READ(0, 2, so);
-        asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        TN_STAMP(3);
-        TCOW_TN_MFMA8(1);
-        TCOW_TN_READ(1, 3, so);
-        asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        TN_STAMP(4);
-        TCOW_TN_MFMA8(0);
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        TN_STAMP(5);
-        TCOW_TN_MFMA8(1);
-        TN_STAMP(6);
-        if (p.bias_part && !(AB & 64)) {
+    if constexpr (SCHED == 1) {
+        for (int it = 0; it < nmt; ++it) {
+            const int stage = it & 1;
+            const uint32_t so = (uint32_t)stage * T2_STAGE;
+            const char* sy = smem + stage * T2_STAGE;
+            TCOW_TN_READ(1, 1, so);
+            asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            TCOW_TN_MFMA8(0);
+            TCOW_TN_READ(0, 2, so);
+            asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            TCOW_TN_MFMA8(1);
+            TCOW_TN_READ(1, 3, so);
+            asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            TCOW_TN_MFMA8(0);
+            if (p.bias_part && !(AB & 64)) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int r = cs_lo + cs_rg + 16 * u;
-                if (r < cs_hi) {
-                    const uint4 v = *reinterpret_cast<const uint4*>(sy + r * T2_ROWB + ((cs_chunk ^ ((r & 3) << 2)) << 4));
-                    csum[0] += bflo(v.x); csum[1] += bfhi(v.x); csum[2] += bflo(v.y); csum[3] += bfhi(v.y);
-                    csum[4] += bflo(v.z); csum[5] += bfhi(v.z); csum[6] += bflo(v.w); csum[7] += bfhi(v.w);
+                for (int u = 0; u < 4; ++u) {
+                    const int r = cs_lo + cs_rg + 16 * u;
+                    if (r < cs_hi) {
+                        const uint4 v = *reinterpret_cast<const uint4*>(sy + r * T2_ROWB + ((cs_chunk ^ ((r & 3) << 2)) << 4));
+                        csum[0] += bflo(v.x); csum[1] += bfhi(v.x); csum[2] += bflo(v.y); csum[3] += bfhi(v.y);
+                        csum[4] += bflo(v.z); csum[5] += bfhi(v.z); csum[6] += bflo(v.w); csum[7] += bfhi(v.w);
+                    }
                 }
             }
+            // this wave's loads of stage it+1 (requested a whole stage ago) have landed, its reads of this stage are back (the fourth k-step's
+            // fragments are in registers): behind the barrier the buffer of this stage is free and stage it+1 is visible
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            if (!(AB & 4)) __syncthreads();
+            if (it + 2 < nmt && !(AB & 2)) issue_stage(it + 2, stage);
+            if (it + 1 < nmt) TCOW_TN_READ(0, 0, so ^ (uint32_t)T2_STAGE);
+            __builtin_amdgcn_sched_barrier(0);
+            TCOW_TN_MFMA8(1);
         }
-        TN_STAMP(7);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        TN_STAMP(8);
-        if (!(AB & 4)) __syncthreads();
-        TN_STAMP(9);
-        if (it + 1 < nmt) TCOW_TN_READ(0, 0, so ^ (uint32_t)T2_STAGE);
-    }
+    } else {
+    for (int it = 0; it < nmt; ++it) {
+            const int stage = it & 1;
+            const uint32_t so = (uint32_t)stage * T2_STAGE;
+            TN_STAMP(0);
+            if (it + 1 < nmt && !(AB & 2)) {
+                const int mt = mbeg + (it + 1) * T2_MC;
+                if (interior && mt + T2_MC <= mend) issue_fast(mt, stage ^ 1); else issue(mt, stage ^ 1);
+            }
+            TN_STAMP(1);
+            const char* sy = smem + stage * T2_STAGE;
+            TCOW_TN_READ(1, 1, so);
+            asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            TN_STAMP(2);
+            TCOW_TN_MFMA8(0);
+            TCOW_TN_READ(0, 2, so);
+            asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            TN_STAMP(3);
+            TCOW_TN_MFMA8(1);
+            TCOW_TN_READ(1, 3, so);
+            asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            TN_STAMP(4);
+            TCOW_TN_MFMA8(0);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            TN_STAMP(5);
+            TCOW_TN_MFMA8(1);
+            TN_STAMP(6);
+            if (p.bias_part && !(AB & 64)) {
+    #pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int r = cs_lo + cs_rg + 16 * u;
+                    if (r < cs_hi) {
+                        const uint4 v = *reinterpret_cast<const uint4*>(sy + r * T2_ROWB + ((cs_chunk ^ ((r & 3) << 2)) << 4));
+                        csum[0] += bflo(v.x); csum[1] += bfhi(v.x); csum[2] += bflo(v.y); csum[3] += bfhi(v.y);
+                        csum[4] += bflo(v.z); csum[5] += bfhi(v.z); csum[6] += bflo(v.w); csum[7] += bfhi(v.w);
+                    }
+                }
+            }
+            TN_STAMP(7);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            TN_STAMP(8);
+            if (!(AB & 4)) __syncthreads();
+            TN_STAMP(9);
+            if (it + 1 < nmt) TCOW_TN_READ(0, 0, so ^ (uint32_t)T2_STAGE);
+        }
+}
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #undef TCOW_TRR
 #undef TCOW_TN_READ
@@ -1096,9 +1144,10 @@ __device__ __forceinline__ void tn256_body(const TnParams& p, const int pid, cha
         }
 }
 
+template <int SCHED>
 __global__ __launch_bounds__(512, 2) void gemm_tn_bf16_256_kernel(TnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    tn256_body<0>(p, xcd_remap(blockIdx.x, gridDim.x), smem);
+    tn256_body<0, SCHED>(p, xcd_remap(blockIdx.x, gridDim.x), smem);
 }
 
 // Grouped launch: the weight gradients of ONE transformer block (7 Linear layers, 153 tiles of 256 x 256 at ViT-B) as one grid.  Launched
@@ -1107,13 +1156,14 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_bf16_256_kernel(TnParams p) {
 // every workgroup walks 5 418 token rows, the partials shrink 5x and one launch replaces seven.
 constexpr int TN_GROUP_MAX = 8;
 struct TnGroup { int n; int first[TN_GROUP_MAX + 1]; TnParams p[TN_GROUP_MAX]; };
+template <int SCHED>
 __global__ __launch_bounds__(512, 2) void gemm_tn_bf16_256_group_kernel(TnGroup g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int pid = xcd_remap(blockIdx.x, gridDim.x);
     int k = 0;
     while (k + 1 < g.n && pid >= g.first[k + 1]) ++k;           // workgroup-uniform
     const TnParams p = g.p[k];
-    tn256_body<0>(p, pid - g.first[k], smem);
+    tn256_body<0, SCHED>(p, pid - g.first[k], smem);
 }
 
 }  // namespace
@@ -1135,6 +1185,9 @@ bool tcow_tn_use_256(int M, int N, int K) {
     return on && M >= 4096 && N >= 256 && K >= 256 && tiles >= (on == 2 ? 1 : 9) && tiles <= 256;
 }
 
+// TCOW_GEMM_TN_SCHED=0: the round-3 stage order of the 256-tile weight-gradient loop (A/B; default 1, see tn256_body)
+static int tn_sched() { static const int v = [] { const char* e = getenv("TCOW_GEMM_TN_SCHED"); return e ? atoi(e) : 1; }(); return v; }
+
 int tcow_gemm_tn_bf16(hipStream_t stream, int M, int N, int K, const bf16_t* dY, long ldy, const bf16_t* X, long ldx, float* slab, int splits,
                       int* nz_out, float* bias_part, int* bias_parts_out) {
     TCOW_CHECK_ARG(N % 8 == 0 && K % 8 == 0 && ldy % 8 == 0 && ldx % 8 == 0, "tcow_gemm_tn(bf16): N, K, ldy, ldx must be multiples of 8");
@@ -1155,8 +1208,13 @@ int tcow_gemm_tn_bf16(hipStream_t stream, int M, int N, int K, const bf16_t* dY,
         p.tiles_n = cdiv(N, T2); p.tiles_k = cdiv(K, T2);
         p.rows_per_pk = cdiv(T2_MC, p.tiles_k);
         if (bias_parts_out) *bias_parts_out = nz * p.tiles_k * 2;
-        tcow_ensure_lds(reinterpret_cast<const void*>(gemm_tn_bf16_256_kernel), T2_LDS);
-        hipLaunchKernelGGL(gemm_tn_bf16_256_kernel, dim3(nz * p.tiles_n * p.tiles_k), dim3(512), T2_LDS, stream, p);
+        if (tn_sched()) {
+            tcow_ensure_lds(reinterpret_cast<const void*>(gemm_tn_bf16_256_kernel<1>), T2_LDS);
+            hipLaunchKernelGGL(gemm_tn_bf16_256_kernel<1>, dim3(nz * p.tiles_n * p.tiles_k), dim3(512), T2_LDS, stream, p);
+        } else {
+            tcow_ensure_lds(reinterpret_cast<const void*>(gemm_tn_bf16_256_kernel<0>), T2_LDS);
+            hipLaunchKernelGGL(gemm_tn_bf16_256_kernel<0>, dim3(nz * p.tiles_n * p.tiles_k), dim3(512), T2_LDS, stream, p);
+        }
         TCOW_CHECK_LAUNCH();
         return TCOW_OK;
     }
@@ -1212,8 +1270,13 @@ int tcow_gemm_tn_bf16_group(hipStream_t stream, int n, const tcow_tn_problem* pr
     g.first[n] = first;
     for (int i = n + 1; i <= TN_GROUP_MAX; ++i) g.first[i] = first;
     *nz_out = nz;
-    tcow_ensure_lds(reinterpret_cast<const void*>(gemm_tn_bf16_256_group_kernel), T2_LDS);
-    hipLaunchKernelGGL(gemm_tn_bf16_256_group_kernel, dim3(first), dim3(512), T2_LDS, stream, g);
+    if (tn_sched()) {
+        tcow_ensure_lds(reinterpret_cast<const void*>(gemm_tn_bf16_256_group_kernel<1>), T2_LDS);
+        hipLaunchKernelGGL(gemm_tn_bf16_256_group_kernel<1>, dim3(first), dim3(512), T2_LDS, stream, g);
+    } else {
+        tcow_ensure_lds(reinterpret_cast<const void*>(gemm_tn_bf16_256_group_kernel<0>), T2_LDS);
+        hipLaunchKernelGGL(gemm_tn_bf16_256_group_kernel<0>, dim3(first), dim3(512), T2_LDS, stream, g);
+    }
     TCOW_CHECK_LAUNCH();
     return TCOW_OK;
 }

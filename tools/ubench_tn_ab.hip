@@ -13,15 +13,15 @@ bool tcow_gemm_nt_c2_ok(const tcow_gemm_args*) { return false; }
 int tcow_gemm_nt_bf16_c2(hipStream_t, const tcow_gemm_args*) { return -1; }
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-template <int AB>
+template <int AB, int SCHED>
 __global__ __launch_bounds__(512, 2) void tn_ab_kernel(TnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    tn256_body<AB>(p, xcd_remap(blockIdx.x, gridDim.x), smem);
+    tn256_body<AB, SCHED>(p, xcd_remap(blockIdx.x, gridDim.x), smem);
 }
 
-template <int AB>
+template <int AB, int SCHED = 1>
 static void run(const char* what, const TnParams& p, int grid, double flops) {
-    auto k = tn_ab_kernel<AB>;
+    auto k = tn_ab_kernel<AB, SCHED>;
     tcow_ensure_lds((const void*)k, T2_LDS);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int r = 0; r < 3; ++r) hipLaunchKernelGGL(k, dim3(grid), dim3(512), T2_LDS, 0, p);
@@ -46,7 +46,9 @@ int main() {
     const int grid = p.nz * p.tiles_n * p.tiles_k;
     const double fl = 2.0 * M * N * K;
     printf("TN 256 tile  dW[%d x %d] over %d token rows, %d slices = %d workgroups (%.2f rounds of 256 CUs), %d stages of 64 tokens each\n", N, K, M, p.nz, grid, grid / 256.0, mps / 64);
-    run<0>("as shipped", p, grid, fl);
+    run<0>("as shipped (barrier between the third and fourth k-step)", p, grid, fl);
+    run<0, 0>("round-3 order (wait + barrier at the stage end)", p, grid, fl);
+    run<8 + 64, 0>("round-3 order, no slab store, no column sums", p, grid, fl);
     run<64>("no bias column sums", p, grid, fl);
     run<8>("no slab store", p, grid, fl);
     run<8 + 64>("no slab store, no column sums", p, grid, fl);
