@@ -27,6 +27,12 @@
 
 #include "attention_common.h"
 
+#ifdef TCOW_FP16
+#define TCOW_MFMA_16x16x32_H16 __builtin_amdgcn_mfma_f32_16x16x32_f16
+#else
+#define TCOW_MFMA_16x16x32_H16 __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#endif
+
 namespace {
 
 constexpr int TILE_B = 4096;                 // 32 rows x 128 B
@@ -401,7 +407,8 @@ __global__ void attn_bwd_prep_kernel(SeqDesc sd, int Lp, const bf16_t* __restric
 
 // One 32-query tile against the wave's 32-key tile (backward, dK / dV side).
 __device__ __forceinline__ void dkv_tile(const SeqDesc& sd, const char* qtile, const char* dotile, const float2* __restrict__ ldh, int i, int key,
-                                         const bf16x8 (&kf)[4], const bf16x8 (&vf)[4], int l31, int hi, int lane, f32x16& dk0, f32x16& dk1, f32x16& dv0, f32x16& dv1) {
+                                         const bf16x8 (&kf)[4], const bf16x8 (&vf)[4], int l31, int hi, int lane, f32x16& dk0, f32x16& dk1, f32x16& dv0, f32x16& dv1,
+                                         bf16x8* ds_out = nullptr) {
     f32x16 s, dp;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
@@ -438,6 +445,7 @@ __device__ __forceinline__ void dkv_tile(const SeqDesc& sd, const char* qtile, c
         }
     }
     const bf16x8 pa0 = pack8(pv), pa1 = pack8(pv + 8), da0 = pack8(dsv), da1 = pack8(dsv + 8);
+    if (ds_out) { ds_out[0] = da0; ds_out[1] = da1; }        // (one-kernel backward: the dS block goes to the dQ strip)
     dv0 = TCOW_MFMA_32x32x16_H16(frag_tr(dotile, 0, 0, lane), pa0, dv0, 0, 0, 0);
     dv0 = TCOW_MFMA_32x32x16_H16(frag_tr(dotile, 1, 0, lane), pa1, dv0, 0, 0, 0);
     dv1 = TCOW_MFMA_32x32x16_H16(frag_tr(dotile, 0, 1, lane), pa0, dv1, 0, 0, 0);
@@ -826,6 +834,189 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_stream(SeqDesc sd, int nt,
 #undef STREAM_STAMP
 }
 
+// ------------------------------------------------------------------------------------------------ backward, ONE kernel per (frame, head) (S <= 320)
+// The two streaming kernels above visit every (query tile, key tile) pair twice -- once for dQ, once for dK / dV: 28 MFMAs per pair, the
+// scores and dP recomputed, Q / K / V / dO read twice (HBM floor 82 us at configs[1]).  Here ONE 10-wave workgroup owns a (frame, head):
+//   * wave w owns key tile w: K_w, V_w fragments from the LDS copies, dK_w / dV_w in 64 accumulator registers, for the whole kernel;
+//   * the query side streams: Q_i / dO_i tiles through a double buffer (8 KiB per step, brought in by waves 0-7 one 1 KiB piece each);
+//   * per query tile i every wave runs the dK / dV step (dkv_tile: S, dP, P, dS, dV += P^T dO, dK += dS^T Q -- 16 MFMAs) and writes its
+//     32 x 32 dS block (bf16) into a [320 keys][32 queries] strip in LDS; after ONE barrier waves 0-7 form dQ_i^T = K^T dS_i in eight
+//     16 x 16 output blocks, each a chain of nt v_mfma_16x16x32 over ALL keys (operands by transpose reads: K from its LDS copy, dS from the
+//     strip) -- no partial sums across waves, no atomics; 20 MFMA-equivalents per pair instead of 28, every operand read once (floor 53 us).
+//   The strip and the Q / dO buffers are double-buffered, so the dQ phase of step i runs while other waves are already in step i+1: one
+//   barrier per step.  delta = rowsum(dO * O) and the log-sum-exp go into an LDS table in the prologue (wave w: query tile w).
+// LDS: K 40 + V 40 + Q/dO 16 + strip 40 + table 2.5 = 138.5 KiB, one workgroup per CU; 168 VGPRs (three waves on two of the SIMDs).
+constexpr int ONE_MAX_NT = 10;
+constexpr int ONE_K = 0, ONE_V = ONE_MAX_NT * TILE_B, ONE_QDO = 2 * ONE_MAX_NT * TILE_B, ONE_STRIP = ONE_QDO + 4 * TILE_B;
+constexpr int ONE_STRIP_B = ONE_MAX_NT * 32 * 64;                       // [320 keys][32 queries] bf16
+constexpr int ONE_TAB = ONE_STRIP + 2 * ONE_STRIP_B, ONE_DQ = ONE_TAB + ONE_MAX_NT * 32 * 8, ONE_LDS = ONE_DQ + 2 * TILE_B;      // + two dQ staging tiles
+
+__global__ __launch_bounds__(640) void attn_bwd_one_kernel(SeqDesc sd, int nt, const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
+                                                           const float* __restrict__ lse, bf16_t* __restrict__ dqkv) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int pair = blockIdx.x;
+    const int item = pair / sd.heads, head = pair - item * sd.heads;
+    const long base = seq_base(sd, item);
+    const long ld3 = 3L * sd.D, pse = sd.pos_stride * ld3, pso = sd.pos_stride * sd.D;
+    const bf16_t* qh = qkv + base * ld3 + head * ATT_HD;
+    const bf16_t* doh = dout + base * sd.D + head * ATT_HD;
+    const bf16_t* oh = o + base * sd.D + head * ATT_HD;
+    char* ktiles = smem + ONE_K; char* vtiles = smem + ONE_V;
+    float2* tab = reinterpret_cast<float2*>(smem + ONE_TAB);
+    const bool owner = wave < nt;
+    // ---- prologue: K_w / V_w tiles, the first two Q / dO tiles (a 1 KiB quarter per wave 0-7), the (lse, delta) table of query tile w
+    if (owner) {
+        load_tile(qh + sd.D, pse, 32 * wave, sd.L, ktiles + wave * TILE_B, lane);
+        load_tile(qh + 2 * sd.D, pse, 32 * wave, sd.L, vtiles + wave * TILE_B, lane);
+    }
+    auto load_qdo = [&](int i, int buf) {                     // waves 0-3: quarter `wave` of Q_i, waves 4-7: quarter `wave - 4` of dO_i
+        char* dst = smem + ONE_QDO + buf * (2 * TILE_B);
+        if (wave < 4) load_tile_chunk(qh, pse, 32 * i, sd.L, dst, wave, lane);
+        else if (wave < 8) load_tile_chunk(doh, pso, 32 * i, sd.L, dst + TILE_B, wave - 4, lane);
+    };
+    load_qdo(0, 0);
+    if (nt > 1) load_qdo(1, 1);
+    if (owner) {
+        // delta_q = sum_d dO * O, 8 lanes per row (one 16-byte piece each: every load instruction takes 8 whole rows), three butterfly steps.
+        // All nine loads of the wave are issued before the first use (in a loop hipcc waits for each row group's loads in turn: four
+        // dependent round trips, 26 000 cycles of the prologue in the first timeline of this kernel).
+        uint4 xo[4], yo[4]; float ls4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int q = 32 * wave + 8 * j + (lane >> 3); q = q < sd.L ? q : sd.L - 1;
+            xo[j] = *reinterpret_cast<const uint4*>(oh + (long)q * pso + (lane & 7) * 8); yo[j] = *reinterpret_cast<const uint4*>(doh + (long)q * pso + (lane & 7) * 8);
+            ls4[j] = lse[(base + (long)q * sd.pos_stride) * sd.heads + head];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = 32 * wave + 8 * j + (lane >> 3);
+            const uint4 x = xo[j], y = yo[j];
+            float part = bflo(x.x) * bflo(y.x) + bfhi(x.x) * bfhi(y.x) + bflo(x.y) * bflo(y.y) + bfhi(x.y) * bfhi(y.y)
+                       + bflo(x.z) * bflo(y.z) + bfhi(x.z) * bfhi(y.z) + bflo(x.w) * bflo(y.w) + bfhi(x.w) * bfhi(y.w);
+            part += __shfl_xor(part, 1, 64); part += __shfl_xor(part, 2, 64); part += __shfl_xor(part, 4, 64);
+            if ((lane & 7) == 0) tab[q] = q < sd.L ? make_float2(ls4[j] * kLog2e, part) : make_float2(0.f, 0.f);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    f32x16 dk0, dk1, dv0, dv1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk0[r] = 0.f; dk1[r] = 0.f; dv0[r] = 0.f; dv1[r] = 0.f; }
+    const int key = 32 * wave + l31;
+    // dQ phase (waves 0-7): output block = queries 16 qb .. +15 x channels 16 db .. +15 of the step's tile, as dQ^T (lane: query l & 15,
+    // channels 16 db + 4 (l >> 4) .. + 3).  Transpose-read addressing: in its 16-lane group lane 4 r + c supplies row r / 4-element quad c.
+    const int qb = (wave >> 2) & 1, db = wave & 3;
+    const int g4 = lane >> 4, tr = (lane & 15) >> 2, tc = lane & 3;
+    const int krow = 8 * g4 + tr;                                                        // key row inside a 32-key tile (second read: + 4)
+    const int kchunk = 2 * db + (tc >> 1);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(LDS_PTR(char))smem;
+    const uint32_t ka0 = lds0 + ONE_K + krow * 128 + ((kchunk ^ swz_g(krow)) << 4) + (tc & 1) * 8;
+    const uint32_t ka1 = lds0 + ONE_K + (krow + 4) * 128 + ((kchunk ^ swz_g(krow + 4)) << 4) + (tc & 1) * 8;
+    const uint32_t sa0 = lds0 + ONE_STRIP + krow * 64 + (((4 * qb + tc) ^ (krow & 7)) << 3);
+    const uint32_t sa1 = lds0 + ONE_STRIP + (krow + 4) * 64 + (((4 * qb + tc) ^ ((krow + 4) & 7)) << 3);
+    // strip write of this wave's dS block: lane (key l31, hi) holds queries 4 hi + {0..3}, 8 + .., 16 + .., 24 + ..: four 8-byte quads (slots
+    // hi, 2 + hi, 4 + hi, 6 + hi of the key's 64-byte row; slot s of key row k sits at s ^ (k & 7))
+    const uint32_t sw = lds0 + ONE_STRIP + (32 * wave + l31) * 64;
+    const int k7 = l31 & 7;
+
+    for (int i = 0; i < nt; ++i) {
+        const int buf = i & 1;
+        const char* qtile = smem + ONE_QDO + buf * (2 * TILE_B);
+        const char* dotile = qtile + TILE_B;
+        if (owner) {
+            bf16x8 kf[4], vf[4], dsb[2];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) { kf[ks] = frag_row(ktiles + wave * TILE_B, l31, ks, hi); vf[ks] = frag_row(vtiles + wave * TILE_B, l31, ks, hi); }
+            dkv_tile(sd, qtile, dotile, tab, i, key, kf, vf, l31, hi, lane, dk0, dk1, dv0, dv1, dsb);
+            typedef uint32_t u32x2_ __attribute__((ext_vector_type(2)));
+            typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
+            const u32x4_ w0 = __builtin_bit_cast(u32x4_, dsb[0]), w1 = __builtin_bit_cast(u32x4_, dsb[1]);
+            const uint32_t sb = sw + buf * ONE_STRIP_B;
+            asm volatile("ds_write_b64 %0, %1" :: "v"(sb + ((hi ^ k7) << 3)), "v"((u32x2_){w0.x, w0.y}) : "memory");
+            asm volatile("ds_write_b64 %0, %1" :: "v"(sb + (((2 + hi) ^ k7) << 3)), "v"((u32x2_){w0.z, w0.w}) : "memory");
+            asm volatile("ds_write_b64 %0, %1" :: "v"(sb + (((4 + hi) ^ k7) << 3)), "v"((u32x2_){w1.x, w1.y}) : "memory");
+            asm volatile("ds_write_b64 %0, %1" :: "v"(sb + (((6 + hi) ^ k7) << 3)), "v"((u32x2_){w1.z, w1.w}) : "memory");
+        }
+        // this wave's piece of tile i+1 has landed, its LDS traffic of this step is done: behind the barrier the strip of step i is complete,
+        // tile i+1 is visible and buffer `buf` may take tile i+2
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (i + 2 < nt) load_qdo(i + 2, buf);
+        if (wave < 8) {
+            // dQ^T block of step i: a chain of nt 16x16x32 MFMAs over all key tiles; the four transpose reads of key tile kt+1 are requested
+            // before the MFMA of key tile kt (two register sets, counted lgkmcnt).  The bf16 block goes to the step's staging tile
+            // ([32 q][64 d], 16-byte chunk c of row q at position c ^ (q & 7)); waves 8 / 9 write it out as whole rows one step later.
+            typedef uint32_t u32x2_ __attribute__((ext_vector_type(2)));
+            typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const uint32_t so = buf * ONE_STRIP_B;
+            u32x2_ fr[3][4];
+#define ONE_RD(set, kt_)                                                                                               \
+            do {                                                                                                       \
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(fr[set][0]) : "v"(ka0 + (kt_) * TILE_B));              \
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(fr[set][1]) : "v"(ka1 + (kt_) * TILE_B));              \
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(fr[set][2]) : "v"(sa0 + so + (kt_) * 2048));           \
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(fr[set][3]) : "v"(sa1 + so + (kt_) * 2048));           \
+            } while (0)
+#define ONE_MF(set)                                                                                                    \
+            acc = TCOW_MFMA_16x16x32_H16(__builtin_bit_cast(bf16x8, (u32x4_){fr[set][0].x, fr[set][0].y, fr[set][1].x, fr[set][1].y}), \
+                                         __builtin_bit_cast(bf16x8, (u32x4_){fr[set][2].x, fr[set][2].y, fr[set][3].x, fr[set][3].y}), acc, 0, 0, 0)
+#define ONE_WAIT(set, n) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(fr[set][0]), "+v"(fr[set][1]), "+v"(fr[set][2]), "+v"(fr[set][3]) :: "memory")
+            // (reads of key tiles past nt - 1 land in the neighbouring LDS regions: harmless, their MFMAs are skipped)
+            ONE_RD(0, 0); ONE_RD(1, 1);
+            for (int kt = 0; kt < nt; kt += 3) {
+                ONE_RD(2, kt + 2); ONE_WAIT(0, 8); ONE_MF(0);
+                if (kt + 1 < nt) { ONE_RD(0, kt + 3); ONE_WAIT(1, 8); ONE_MF(1); }
+                if (kt + 2 < nt) { ONE_RD(1, kt + 4); ONE_WAIT(2, 8); ONE_MF(2); }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#undef ONE_WAIT
+#undef ONE_RD
+#undef ONE_MF
+            const int ql = 16 * qb + (lane & 15);                       // row of the staging tile; channels 16 db + 4 g4 .. + 3 = 8-byte slot 4 db + g4
+            const uint32_t da = lds0 + ONE_DQ + buf * TILE_B + ql * 128 + ((((4 * db + g4) >> 1) ^ (ql & 7)) << 4) + ((g4 & 1) << 3);
+            const u32x2_ pk = {pack_bf2(acc[0] * kScale, acc[1] * kScale), pack_bf2(acc[2] * kScale, acc[3] * kScale)};
+            asm volatile("ds_write_b64 %0, %1" :: "v"(da), "v"(pk) : "memory");
+        } else if (i > 0) {
+            // the finished dQ tile of step i-1 (complete since this step's barrier) goes out as whole 128-byte rows: wave 8 rows 0-15, wave 9 rows 16-31
+            typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
+            const uint32_t st0 = lds0 + ONE_DQ + ((i - 1) & 1) * TILE_B;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int r = 16 * (wave - 8) + 8 * j + (lane >> 3);
+                u32x4_ v;
+                asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(st0 + r * 128 + (((lane & 7) ^ (r & 7)) << 4)) : "memory");
+                const int q = 32 * (i - 1) + r;
+                if (q < sd.L) *reinterpret_cast<u32x4_*>(dqkv + (base + (long)q * sd.pos_stride) * ld3 + head * ATT_HD + (lane & 7) * 8) = v;
+            }
+        }
+    }
+    // the last dQ tile, then dK / dV as whole rows through the waves' own (now dead) K / V tiles
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (wave >= 8) {
+        typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
+        const uint32_t st0 = lds0 + ONE_DQ + ((nt - 1) & 1) * TILE_B;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int r = 16 * (wave - 8) + 8 * j + (lane >> 3);
+            u32x4_ v;
+            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(st0 + r * 128 + (((lane & 7) ^ (r & 7)) << 4)) : "memory");
+            const int q = 32 * (nt - 1) + r;
+            if (q < sd.L) *reinterpret_cast<u32x4_*>(dqkv + (base + (long)q * sd.pos_stride) * ld3 + head * ATT_HD + (lane & 7) * 8) = v;
+        }
+    }
+    if (owner) {
+        bf16_t* drow0 = dqkv + (base + (long)(32 * wave) * sd.pos_stride) * ld3 + head * ATT_HD;
+        store_tile_staged(lds0 + ONE_K + wave * TILE_B, lane, kScale, dk0, dk1, drow0 + sd.D, pse, sd.L - 32 * wave);      // dS was accumulated without its 1/sqrt(d) factor
+        store_tile_staged(lds0 + ONE_V + wave * TILE_B, lane, 1.0f, dv0, dv1, drow0 + 2 * sd.D, pse, sd.L - 32 * wave);
+    }
+}
+
 template <typename K>
 static void set_lds_attr(K kernel, int bytes) {
     tcow_ensure_lds(reinterpret_cast<const void*>(kernel), bytes);
@@ -888,6 +1079,14 @@ int tcow_attn_mfma_bwd(hipStream_t st, const SeqDesc& d, bool shared, const void
     float2* ld = (float2*)ws;
     const long total = (long)pairs * nt * 32;
     int blocks = cdiv(total, 256); if (blocks > 8192) blocks = 8192;
+    // spatial sequences of up to ten tiles: the one-kernel backward (TCOW_ATTN_ONE=0: the two streaming kernels, A/B)
+    static const int one = [] { const char* e = getenv("TCOW_ATTN_ONE"); return e ? atoi(e) : 1; }();
+    if (shared && one && nt <= ONE_MAX_NT && nt >= 4) {
+        set_lds_attr(attn_bwd_one_kernel, ONE_LDS);
+        hipLaunchKernelGGL(attn_bwd_one_kernel, dim3(pairs), dim3(640), ONE_LDS, st, d, nt, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv);
+        TCOW_CHECK_LAUNCH();
+        return TCOW_OK;
+    }
     if (shared || nt > 2) {
         const dim3 sg(stream_grid(pairs, cdiv(nt, 4)));
         if (stream_ch5(nt)) {
