@@ -912,29 +912,31 @@ __device__ __forceinline__ void tn256_body(const TnParams& p, const int pid, cha
             glds16(xs, sx + q * 1024);
         }
     };
-    // Full stages of interior tiles (every stage but a slice's last, every tile of the path's weight shapes) take 32-bit lane offsets computed
-    // once + one uniform base per stage; the general form above (row / column guards through a zero page: 64-bit address arithmetic and a
-    // select per load) cost ~ a fifth of a stage in issue time.
-    uint32_t y_src[4], x_src[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int q = wave * 4 + j;
-        y_src[j] = (uint32_t)((q * 2 + lrow) * p.ldy + ycol[j & 1]);
-        x_src[j] = (uint32_t)((q * 2 + lrow) * p.ldx + xcol[j & 1]);
-    }
     const bool interior = n0 + T2 <= p.N && k0 + T2 <= p.K;
-    auto issue_fast = [&](int mt, int stage) {
-        char* sy = smem + stage * T2_STAGE;
-        char* sx = sy + T2_TILE;
-        const bf16_t* yb = p.dY + (size_t)mt * p.ldy;
-        const bf16_t* xb = p.X + (size_t)mt * p.ldx;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            glds16(yb + y_src[j], sy + (wave * 4 + j) * 1024);
-            glds16(xb + x_src[j], sx + (wave * 4 + j) * 1024);
-        }
+    // The fast path as buffer loads: descriptor + ONE per-lane byte offset per operand and row parity + a scalar row offset -- no vector
+    // arithmetic per load, rows past M read as zeros.  (inline asm: hipcc does not count these loads; every wait in the loop is explicit.)
+    typedef int i32x4_ __attribute__((ext_vector_type(4)));
+    auto make_srd = [](const void* base, long bytes) {
+        const uint64_t b = (uint64_t)(uintptr_t)base;
+        i32x4_ r; r[0] = (int)(uint32_t)b; r[1] = (int)(uint32_t)((b >> 32) & 0xffffu); r[2] = (int)(uint32_t)bytes; r[3] = 0x00020000;
+        return r;
     };
-
+    const i32x4_ srd_y = make_srd(p.dY, ((long)(p.M - 1) * p.ldy + p.N) * 2), srd_x = make_srd(p.X, ((long)(p.M - 1) * p.ldx + p.K) * 2);
+    const uint32_t yv0 = (uint32_t)(lrow * p.ldy + ycol[0]) * 2u, yv1 = (uint32_t)(lrow * p.ldy + ycol[1]) * 2u;
+    const uint32_t xv0 = (uint32_t)(lrow * p.ldx + xcol[0]) * 2u, xv1 = (uint32_t)(lrow * p.ldx + xcol[1]) * 2u;
+    const bool small32 = (long)p.M * p.ldy < (1L << 29) && (long)p.M * p.ldx < (1L << 29);
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(LDS_PTR(char))smem;
+#define TN_BLD(voff, srd, soff, ldsdst) \
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" :: "v"(voff), "s"(srd), "s"(soff), "s"(ldsdst) : "memory")
+    auto issue_fast = [&](int mt, int stage) {
+        const uint32_t dy = lds_base + stage * T2_STAGE + wave * 4096, dx = dy + T2_TILE;
+        const uint32_t sy = (uint32_t)((long)(mt + wave * 8) * p.ldy * 2), sx = (uint32_t)((long)(mt + wave * 8) * p.ldx * 2);
+        const uint32_t ry = (uint32_t)(2 * p.ldy * 2), rx = (uint32_t)(2 * p.ldx * 2);
+        TN_BLD(yv0, srd_y, sy, dy); TN_BLD(xv0, srd_x, sx, dx);
+        TN_BLD(yv1, srd_y, sy + ry, dy + 1024); TN_BLD(xv1, srd_x, sx + rx, dx + 1024);
+        TN_BLD(yv0, srd_y, sy + 2 * ry, dy + 2048); TN_BLD(xv0, srd_x, sx + 2 * rx, dx + 2048);
+        TN_BLD(yv1, srd_y, sy + 3 * ry, dy + 3072); TN_BLD(xv1, srd_x, sx + 3 * rx, dx + 3072);
+    };
     // transpose-read addressing (constant over the loop)
     const int q16 = lane & 15, g16 = (lane >> 4) & 1, hi = lane >> 5;
     const int rr = 8 * hi + (q16 >> 2);
@@ -962,9 +964,17 @@ __device__ __forceinline__ void tn256_body(const TnParams& p, const int pid, cha
     const int nmt = (mend - mbeg + T2_MC - 1) / T2_MC;
     auto issue_stage = [&](int st_, int buf_) {
         const int mt = mbeg + st_ * T2_MC;
-        if (interior && mt + T2_MC <= mend) issue_fast(mt, buf_); else issue(mt, buf_);
+        if (interior && small32 && (mt + T2_MC <= mend || mend == p.M)) issue_fast(mt, buf_); else issue(mt, buf_);
     };
-    if (nmt > 0) {
+    if constexpr (SCHED >= 2) {
+        // (every stage through the buffer loads: the host picks this variant for whole tiles and 32-bit offsets only)
+        if (nmt > 0) {
+            issue_fast(mbeg, 0);
+            if (nmt > 1) { issue_fast(mbeg + T2_MC, 1); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    } else if (nmt > 0) {
         issue(mbeg, 0);
         if (SCHED == 1 && nmt > 1) { issue_stage(1, 1); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }      // stage 1 (8 loads per wave) stays in flight
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -981,6 +991,32 @@ __device__ __forceinline__ void tn256_body(const TnParams& p, const int pid, cha
 #pragma unroll
     for (int j = 0; j < 2; ++j) xa[j] = lds0 + (uint32_t)x_off[j];
     u32x2 fyl[2][4], fyh[2][4], fxl[2][2], fxh[2][2];
+    u32x4 kfrag = (u32x4){1u, 2u, 3u, 4u};                             // (ablation 128: MFMA operands that do not depend on the reads)
+    if (AB & 128) asm volatile("" : "+v"(kfrag));
+    u32x4 kfy[2][4], kfx[2][2];                                        // (ablation 512: DISTINCT constant operands, 24 registers as the real ones)
+    if (AB & 512) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                kfy[b][i] = (u32x4){1u, 2u, 3u, 4u};
+                if (AB & 1024) {                                   // random bf16 pairs in (-1, 1) per lane: the data-dependent power of the MFMA pipe
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { uint32_t h = (uint32_t)(tid * 97 + b * 31 + i * 7 + c) * 2654435761u; kfy[b][i][c] = (h & 0x807f807fu) | 0x3f003f00u | ((h >> 3) & 0x00800080u); }
+                }
+                asm volatile("" : "+v"(kfy[b][i]));
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                kfx[b][j] = (u32x4){1u, 2u, 3u, 4u};
+                if (AB & 1024) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { uint32_t h = (uint32_t)(tid * 89 + b * 29 + j * 5 + c + 1000) * 2654435761u; kfx[b][j][c] = (h & 0x807f807fu) | 0x3f003f00u | ((h >> 3) & 0x00800080u); }
+                }
+                asm volatile("" : "+v"(kfx[b][j]));
+            }
+        }
+    }
 #define TCOW_TRR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
 #define TCOW_TN_READ(buf, ks, so)                                                                                          \
     do {                                                                                                                   \
@@ -994,7 +1030,7 @@ __device__ __forceinline__ void tn256_body(const TnParams& p, const int pid, cha
             TCOW_TRR(fyh[buf][i], ya[i] + (so), (ks) * 16 * T2_ROWB + 4 * T2_ROWB);                                        \
         }                                                                                                                  \
     } while (0)
-#define TCOW_TN_FRAG(lo, hi) __builtin_bit_cast(bf16x8, (u32x4){(lo).x, (lo).y, (hi).x, (hi).y})
+#define TCOW_TN_FRAG(lo, hi) ((AB & 128) ? __builtin_bit_cast(bf16x8, kfrag) : __builtin_bit_cast(bf16x8, (u32x4){(lo).x, (lo).y, (hi).x, (hi).y}))
 #define TCOW_TN_MFMA8(buf)                                                                                                 \
     if (!(AB & 32)) _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                          \
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                      \
@@ -1010,6 +1046,70 @@ __device__ __forceinline__ void tn256_body(const TnParams& p, const int pid, cha
             for (int i = 0; i < 4; ++i) { fyl[b][i] = (u32x2){5u, 6u}; fyh[b][i] = (u32x2){7u, 8u}; }
         }
     }
+    if constexpr (SCHED == 2) {
+        // Every k-step as ONE block: its 8 MFMAs with the NEXT k-step's 12 transpose reads behind the first six of them (two each), the waits
+        // counted per fragment -- issued as a burst before the MFMAs, the reads of all 8 waves queue up at the LDS while the MFMA pipe idles,
+        // and then the LDS idles under the MFMAs: reads-only 30 us + MFMAs-only 60 us = 92 us measured with the loads off, no overlap at all
+        // (profiles/r04_ubench_tn_ab.txt).  The fourth k-step also carries the 8 buffer loads of stage it+2, one behind each MFMA.
+#define TN_BLDA(...) do { if (!(AB & 2)) TN_BLD(__VA_ARGS__); } while (0)
+#define TN_RDA(...) do { if (!(AB & 16)) TCOW_TRR(__VA_ARGS__); } while (0)
+#define TN_NOP do { } while (0)
+#define TN_MF(cur, i, j) if (!(AB & 32)) acc[i][j] = TCOW_MFMA_32x32x16_H16((AB & 512) ? __builtin_bit_cast(bf16x8, kfy[cur][i]) : TCOW_TN_FRAG(fyl[cur][i], fyh[cur][i]), (AB & 512) ? __builtin_bit_cast(bf16x8, kfx[cur][j]) : TCOW_TN_FRAG(fxl[cur][j], fxh[cur][j]), acc[i][j], 0, 0, 0); \
+                    __builtin_amdgcn_sched_barrier(0)
+#define TN_BLK(cur, nxt, OFFK, son, W0, B0, B1, B2, B3, B4, B5, B6, B7)                                                                  \
+    do {                                                                                                                                 \
+        if (!(AB & 256)) asm volatile("s_waitcnt lgkmcnt(" #W0 ")" ::: "memory"); __builtin_amdgcn_sched_barrier(0);                     \
+        TN_MF(cur, 0, 0); TN_RDA(fxl[nxt][0], xa[0] + (son), T2_TILE + (OFFK)); TN_RDA(fxh[nxt][0], xa[0] + (son), T2_TILE + (OFFK) + 4 * T2_ROWB); B0; \
+        TN_MF(cur, 0, 1); TN_RDA(fxl[nxt][1], xa[1] + (son), T2_TILE + (OFFK)); TN_RDA(fxh[nxt][1], xa[1] + (son), T2_TILE + (OFFK) + 4 * T2_ROWB); B1; \
+        TN_MF(cur, 1, 0); TN_RDA(fyl[nxt][0], ya[0] + (son), (OFFK)); TN_RDA(fyh[nxt][0], ya[0] + (son), (OFFK) + 4 * T2_ROWB); B2;              \
+        TN_MF(cur, 1, 1); TN_RDA(fyl[nxt][1], ya[1] + (son), (OFFK)); TN_RDA(fyh[nxt][1], ya[1] + (son), (OFFK) + 4 * T2_ROWB); B3;              \
+        if (!(AB & 256)) asm volatile("s_waitcnt lgkmcnt(10)" ::: "memory"); __builtin_amdgcn_sched_barrier(0);    /* the previous block's fy[2] */ \
+        TN_MF(cur, 2, 0); TN_RDA(fyl[nxt][2], ya[2] + (son), (OFFK)); TN_RDA(fyh[nxt][2], ya[2] + (son), (OFFK) + 4 * T2_ROWB); B4;              \
+        TN_MF(cur, 2, 1); TN_RDA(fyl[nxt][3], ya[3] + (son), (OFFK)); TN_RDA(fyh[nxt][3], ya[3] + (son), (OFFK) + 4 * T2_ROWB); B5;              \
+        if (!(AB & 256)) asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory"); __builtin_amdgcn_sched_barrier(0);    /* ... and its fy[3] */  \
+        TN_MF(cur, 3, 0); B6;                                                                                                            \
+        TN_MF(cur, 3, 1); B7;                                                                                                            \
+    } while (0)
+        for (int it = 0; it < nmt; ++it) {
+            const int stage = it & 1;
+            const uint32_t so = (uint32_t)stage * T2_STAGE;
+            const char* sy = smem + stage * T2_STAGE;
+            TN_BLK(0, 1, 1 * 16 * T2_ROWB, so, 4, TN_NOP, TN_NOP, TN_NOP, TN_NOP, TN_NOP, TN_NOP, TN_NOP, TN_NOP);
+            TN_BLK(1, 0, 2 * 16 * T2_ROWB, so, 4, TN_NOP, TN_NOP, TN_NOP, TN_NOP, TN_NOP, TN_NOP, TN_NOP, TN_NOP);
+            TN_BLK(0, 1, 3 * 16 * T2_ROWB, so, 4, TN_NOP, TN_NOP, TN_NOP, TN_NOP, TN_NOP, TN_NOP, TN_NOP, TN_NOP);
+            if (p.bias_part && !(AB & 64)) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int r = cs_lo + cs_rg + 16 * u;
+                    if (r < cs_hi) {
+                        const uint4 v = *reinterpret_cast<const uint4*>(sy + r * T2_ROWB + ((cs_chunk ^ ((r & 3) << 2)) << 4));
+                        csum[0] += bflo(v.x); csum[1] += bfhi(v.x); csum[2] += bflo(v.y); csum[3] += bfhi(v.y);
+                        csum[4] += bflo(v.z); csum[5] += bfhi(v.z); csum[6] += bflo(v.w); csum[7] += bfhi(v.w);
+                    }
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            if (!(AB & 4)) __syncthreads();
+            {
+                const int mt2 = mbeg + (it + 2) * T2_MC;
+                const bool more = it + 2 < nmt;
+                const uint32_t dy = lds_base + so + wave * 4096, dx = dy + T2_TILE;
+                const uint32_t by = (uint32_t)((long)(mt2 + wave * 8) * p.ldy * 2), bx = (uint32_t)((long)(mt2 + wave * 8) * p.ldx * 2);
+                const uint32_t yw0 = more ? yv0 : 0x80000000u, yw1 = more ? yv1 : 0x80000000u;     // (the per-lane offset is the range-checked one)
+                const uint32_t xw0 = more ? xv0 : 0x80000000u, xw1 = more ? xv1 : 0x80000000u;
+                const uint32_t ry = (uint32_t)(2 * p.ldy * 2), rx = (uint32_t)(2 * p.ldx * 2);
+                const uint32_t sn = so ^ (uint32_t)T2_STAGE;
+                TN_BLK(1, 0, 0, sn, 0, TN_BLDA(yw0, srd_y, by, dy), TN_BLDA(xw0, srd_x, bx, dx), TN_BLDA(yw1, srd_y, by + ry, dy + 1024),
+                       TN_BLDA(xw1, srd_x, bx + rx, dx + 1024), TN_BLDA(yw0, srd_y, by + 2 * ry, dy + 2048), TN_BLDA(xw0, srd_x, bx + 2 * rx, dx + 2048),
+                       TN_BLDA(yw1, srd_y, by + 3 * ry, dy + 3072), TN_BLDA(xw1, srd_x, bx + 3 * rx, dx + 3072));
+            }
+        }
+#undef TN_BLK
+#undef TN_MF
+#undef TN_NOP
+#undef TN_BLDA
+#undef TN_RDA
+    } else
     if constexpr (SCHED == 1) {
         for (int it = 0; it < nmt; ++it) {
             const int stage = it & 1;
@@ -1054,7 +1154,7 @@ __device__ __forceinline__ void tn256_body(const TnParams& p, const int pid, cha
             TN_STAMP(0);
             if (it + 1 < nmt && !(AB & 2)) {
                 const int mt = mbeg + (it + 1) * T2_MC;
-                if (interior && mt + T2_MC <= mend) issue_fast(mt, stage ^ 1); else issue(mt, stage ^ 1);
+                if (interior && small32 && (mt + T2_MC <= mend || mend == p.M)) issue_fast(mt, stage ^ 1); else issue(mt, stage ^ 1);
             }
             TN_STAMP(1);
             const char* sy = smem + stage * T2_STAGE;
@@ -1186,7 +1286,10 @@ bool tcow_tn_use_256(int M, int N, int K) {
 }
 
 // TCOW_GEMM_TN_SCHED=0: the round-3 stage order of the 256-tile weight-gradient loop (A/B; default 1, see tn256_body)
-static int tn_sched() { static const int v = [] { const char* e = getenv("TCOW_GEMM_TN_SCHED"); return e ? atoi(e) : 1; }(); return v; }
+// 2 (default): as 1 with the transpose reads of the next k-step and the next stage's requests spread between the MFMAs of every k-step, the loads
+// as buffer loads with scalar row offsets -- whole 256-tiles and 32-bit byte offsets only (tn_whole), otherwise 1
+static int tn_sched() { static const int v = [] { const char* e = getenv("TCOW_GEMM_TN_SCHED"); return e ? atoi(e) : 2; }(); return v; }
+static bool tn_whole(int M, int N, int K, long ldy, long ldx) { return N % T2 == 0 && K % T2 == 0 && (long)M * ldy < (1L << 29) && (long)M * ldx < (1L << 29); }
 
 int tcow_gemm_tn_bf16(hipStream_t stream, int M, int N, int K, const bf16_t* dY, long ldy, const bf16_t* X, long ldx, float* slab, int splits,
                       int* nz_out, float* bias_part, int* bias_parts_out) {
@@ -1208,13 +1311,14 @@ int tcow_gemm_tn_bf16(hipStream_t stream, int M, int N, int K, const bf16_t* dY,
         p.tiles_n = cdiv(N, T2); p.tiles_k = cdiv(K, T2);
         p.rows_per_pk = cdiv(T2_MC, p.tiles_k);
         if (bias_parts_out) *bias_parts_out = nz * p.tiles_k * 2;
-        if (tn_sched()) {
-            tcow_ensure_lds(reinterpret_cast<const void*>(gemm_tn_bf16_256_kernel<1>), T2_LDS);
-            hipLaunchKernelGGL(gemm_tn_bf16_256_kernel<1>, dim3(nz * p.tiles_n * p.tiles_k), dim3(512), T2_LDS, stream, p);
-        } else {
-            tcow_ensure_lds(reinterpret_cast<const void*>(gemm_tn_bf16_256_kernel<0>), T2_LDS);
-            hipLaunchKernelGGL(gemm_tn_bf16_256_kernel<0>, dim3(nz * p.tiles_n * p.tiles_k), dim3(512), T2_LDS, stream, p);
-        }
+        const int sched = (tn_sched() >= 2 && !tn_whole(M, N, K, ldy, ldx)) ? 1 : tn_sched();
+#define TN_LAUNCH(S)                                                                                                       \
+    do {                                                                                                                   \
+        tcow_ensure_lds(reinterpret_cast<const void*>(gemm_tn_bf16_256_kernel<S>), T2_LDS);                                \
+        hipLaunchKernelGGL(gemm_tn_bf16_256_kernel<S>, dim3(nz * p.tiles_n * p.tiles_k), dim3(512), T2_LDS, stream, p);    \
+    } while (0)
+        if (sched == 2) TN_LAUNCH(2); else if (sched == 1) TN_LAUNCH(1); else TN_LAUNCH(0);
+#undef TN_LAUNCH
         TCOW_CHECK_LAUNCH();
         return TCOW_OK;
     }
@@ -1270,13 +1374,15 @@ int tcow_gemm_tn_bf16_group(hipStream_t stream, int n, const tcow_tn_problem* pr
     g.first[n] = first;
     for (int i = n + 1; i <= TN_GROUP_MAX; ++i) g.first[i] = first;
     *nz_out = nz;
-    if (tn_sched()) {
-        tcow_ensure_lds(reinterpret_cast<const void*>(gemm_tn_bf16_256_group_kernel<1>), T2_LDS);
-        hipLaunchKernelGGL(gemm_tn_bf16_256_group_kernel<1>, dim3(first), dim3(512), T2_LDS, stream, g);
-    } else {
-        tcow_ensure_lds(reinterpret_cast<const void*>(gemm_tn_bf16_256_group_kernel<0>), T2_LDS);
-        hipLaunchKernelGGL(gemm_tn_bf16_256_group_kernel<0>, dim3(first), dim3(512), T2_LDS, stream, g);
-    }
+    int sched = tn_sched();
+    for (int i = 0; i < n && sched >= 2; ++i) if (!tn_whole(pr[i].M, pr[i].N, pr[i].K, pr[i].ldy, pr[i].ldx)) sched = 1;
+#define TN_LAUNCH(S)                                                                                                       \
+    do {                                                                                                                   \
+        tcow_ensure_lds(reinterpret_cast<const void*>(gemm_tn_bf16_256_group_kernel<S>), T2_LDS);                          \
+        hipLaunchKernelGGL(gemm_tn_bf16_256_group_kernel<S>, dim3(first), dim3(512), T2_LDS, stream, g);                   \
+    } while (0)
+    if (sched == 2) TN_LAUNCH(2); else if (sched == 1) TN_LAUNCH(1); else TN_LAUNCH(0);
+#undef TN_LAUNCH
     TCOW_CHECK_LAUNCH();
     return TCOW_OK;
 }

@@ -86,8 +86,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_c2_kernel(NtParams p) {
     // (inline asm): every wait for them below is an explicit vmcnt.
 #define C2_GLDS(voff, srd, soff, ldsdst) \
     asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" :: "v"(voff), "s"(srd), "s"(soff), "s"(ldsdst) : "memory")
-#define C2_LDW(q, kb) do { if (!(AB & 64)) C2_GLDS(w_vo, srd_w, sW0 + (q) * sWs + (kb), dW0 + (q) * 1024); } while (0)
-#define C2_LDA(q, kb, bo) do { if (!(AB & 128)) C2_GLDS(a_vo, srd_a, sA0 + (q) * sAs + (kb), dA0 + (bo) + (q) * 4096); } while (0)
+#define C2_LDWV(q, kb, vo) do { if (!(AB & 64)) C2_GLDS(vo, srd_w, sW0 + (q) * sWs + (kb), dW0 + (q) * 1024); } while (0)
+#define C2_LDAV(q, kb, bo, vo) do { if (!(AB & 128)) C2_GLDS(vo, srd_a, sA0 + (q) * sAs + (kb), dA0 + (bo) + (q) * 4096); } while (0)
+#define C2_LDW(q, kb) C2_LDWV(q, kb, w_vo)
+#define C2_LDA(q, kb, bo) C2_LDAV(q, kb, bo, a_vo)
 
     // ---- fragment reads (inline asm: hipcc must neither merge nor move them; every address is one per-lane constant + an immediate)
     typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
@@ -146,8 +148,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_c2_kernel(NtParams p) {
 #define C2_TILE(kt, LOAD, LOAD2, PAR)                                                                                                           \
     do {                                                                                                                                  \
         const uint32_t bo_ = (PAR) * D_A;                                                                                                 \
-        const uint32_t kb_ = (LOAD) ? (uint32_t)((kt) + 1) * 128u : 0xC0000000u;   /* no next tile: out of range = zeros, no traffic */    \
-        const uint32_t kb2_ = (LOAD2) ? (uint32_t)((kt) + 2) * 128u : 0xC0000000u;                                                        \
+        const uint32_t kb_ = (uint32_t)((kt) + 1) * 128u, kb2_ = (uint32_t)((kt) + 2) * 128u;                                             \
+        /* no next tile: the PER-LANE offset (the one the range check covers) is sent past the descriptor = zeros, no traffic */          \
+        const uint32_t wv_ = (LOAD) ? w_vo : 0x80000000u, av_ = (LOAD2) ? a_vo : 0x80000000u;                                             \
         const bool ld_ = !(AB & 2);                                                                                                       \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); C2_PIN;                                                                        \
         C2_BLOCK(0, fa[0], fw[0],                                                                                                         \
@@ -155,8 +158,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_c2_kernel(NtParams p) {
                  C2_DSR(fa[1][0], a_adb0, (PAR) * D_A + 10240), C2_DSR(fa[1][1], a_adb0, (PAR) * D_A + 12288),                              \
                  C2_DSR(fa[1][2], a_adb0, (PAR) * D_A + 14336), C2_DSR(fa[1][3], a_adb0, (PAR) * D_A + 16384),                              \
                  C2_DSR(fa[1][4], a_adb0, (PAR) * D_A + 18432); asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory"),                         \
-                 if (ld_) { C2_LDW(0, kb_); C2_LDW(1, kb_); }, if (ld_) { C2_LDW(2, kb_); C2_LDW(3, kb_); },                                \
-                 if (ld_) { C2_LDW(4, kb_); C2_LDW(5, kb_); }, if (ld_) { C2_LDW(6, kb_); C2_LDW(7, kb_); });                               \
+                 if (ld_) { C2_LDWV(0, kb_, wv_); C2_LDWV(1, kb_, wv_); }, if (ld_) { C2_LDWV(2, kb_, wv_); C2_LDWV(3, kb_, wv_); },                                \
+                 if (ld_) { C2_LDWV(4, kb_, wv_); C2_LDWV(5, kb_, wv_); }, if (ld_) { C2_LDWV(6, kb_, wv_); C2_LDWV(7, kb_, wv_); });                               \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); C2_PIN;                                                                        \
         C2_BLOCK(1, fa[1], fw[0],                                                                                                         \
                  C2_DSR(fa[0][0], a_adb1, (PAR) * D_A), C2_DSR(fa[0][1], a_adb1, (PAR) * D_A + 2048), C2_DSR(fa[0][2], a_adb1, (PAR) * D_A + 4096), \
@@ -175,8 +178,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_c2_kernel(NtParams p) {
                  C2_DSR(fw[0][3], w_ad0, 6144), C2_DSR(fa[0][0], a_adb0, (1 - (PAR)) * D_A),                           \
                  C2_DSR(fa[0][1], a_adb0, (1 - (PAR)) * D_A + 2048), C2_DSR(fa[0][2], a_adb0, (1 - (PAR)) * D_A + 4096), \
                  C2_DSR(fa[0][3], a_adb0, (1 - (PAR)) * D_A + 6144), C2_DSR(fa[0][4], a_adb0, (1 - (PAR)) * D_A + 8192), \
-                 if (ld_) { C2_LDA(0, kb2_, bo_); C2_LDA(1, kb2_, bo_); }, if (ld_) { C2_LDA(2, kb2_, bo_); C2_LDA(3, kb2_, bo_); },        \
-                 if (ld_) C2_LDA(4, kb2_, bo_), C2_NONE);                                                                                 \
+                 if (ld_) { C2_LDAV(0, kb2_, bo_, av_); C2_LDAV(1, kb2_, bo_, av_); }, if (ld_) { C2_LDAV(2, kb2_, bo_, av_); C2_LDAV(3, kb2_, bo_, av_); },        \
+                 if (ld_) C2_LDAV(4, kb2_, bo_, av_), C2_NONE);                                                                                 \
     } while (0)
 
     // (two tiles per iteration: the A buffer of a tile is a literal, so every fragment address is ONE per-lane register + an immediate)
@@ -195,6 +198,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_c2_kernel(NtParams p) {
 #undef C2_DSR
 #undef C2_DSR0
 #undef C2_LDA
+#undef C2_LDAV
+#undef C2_LDWV
 #undef C2_LDW
 #undef C2_GLDS
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");

@@ -19,7 +19,7 @@ __global__ __launch_bounds__(512, 2) void tn_ab_kernel(TnParams p) {
     tn256_body<AB, SCHED>(p, xcd_remap(blockIdx.x, gridDim.x), smem);
 }
 
-template <int AB, int SCHED = 1>
+template <int AB, int SCHED = 2>
 static void run(const char* what, const TnParams& p, int grid, double flops) {
     auto k = tn_ab_kernel<AB, SCHED>;
     tcow_ensure_lds((const void*)k, T2_LDS);
@@ -46,7 +46,9 @@ int main() {
     const int grid = p.nz * p.tiles_n * p.tiles_k;
     const double fl = 2.0 * M * N * K;
     printf("TN 256 tile  dW[%d x %d] over %d token rows, %d slices = %d workgroups (%.2f rounds of 256 CUs), %d stages of 64 tokens each\n", N, K, M, p.nz, grid, grid / 256.0, mps / 64);
-    run<0>("as shipped (barrier between the third and fourth k-step)", p, grid, fl);
+    run<0>("as shipped (reads between the MFMAs in every k-step)", p, grid, fl);
+    run<0>("  (again)", p, grid, fl);
+    run<0, 1>("requests + reads in one burst behind the barrier", p, grid, fl);
     run<0, 0>("round-3 order (wait + barrier at the stage end)", p, grid, fl);
     run<8 + 64, 0>("round-3 order, no slab store, no column sums", p, grid, fl);
     run<64>("no bias column sums", p, grid, fl);
@@ -55,6 +57,16 @@ int main() {
     run<8 + 64 + 2>("  ... no loads after the first stage", p, grid, fl);
     run<8 + 64 + 4>("  ... no barriers (racy: timing only)", p, grid, fl);
     run<8 + 64 + 2 + 4>("  ... no loads, no barriers", p, grid, fl);
+    run<8 + 64 + 2 + 4 + 128, 1>("  ... no loads, no barriers, MFMAs on constant operands (reads still issued, burst)", p, grid, fl);
+    run<8 + 64 + 2 + 4 + 128, 2>("  ... no loads, no barriers, MFMAs on constant operands (reads between MFMAs)", p, grid, fl);
+    run<8 + 64 + 2 + 4, 2>("  ... no loads, no barriers (reads between MFMAs)", p, grid, fl);
+    run<8 + 64 + 2 + 4 + 512, 2>("  ... no loads, no barriers, MFMAs on 12 distinct constant operands (reads into the usual registers)", p, grid, fl);
+    run<8 + 64 + 2 + 4 + 512 + 16, 2>("  ... the same without the reads", p, grid, fl);
+    run<8 + 64 + 2 + 4 + 512 + 1024, 2>("  ... distinct constant operands holding RANDOM values in (-1, 1), reads issued", p, grid, fl);
+    run<8 + 64 + 2 + 4 + 512 + 1024 + 16, 2>("  ... the same without the reads (MFMAs only, random operand values)", p, grid, fl);
+    run<8 + 64 + 2 + 4 + 256, 2>("  ... no loads, no barriers, no waits for the reads (racy: timing only)", p, grid, fl);
+    run<8 + 64 + 2 + 4 + 16, 2>("  ... MFMAs only (reads between MFMAs)", p, grid, fl);
+    run<8 + 64 + 2 + 4 + 32, 2>("  ... reads only (reads between MFMAs)", p, grid, fl);
     run<8 + 64 + 16>("  ... no transpose reads", p, grid, fl);
     run<8 + 64 + 32>("  ... no MFMAs (loads + reads + barriers)", p, grid, fl);
     run<8 + 64 + 16 + 32>("  ... loads + barriers only", p, grid, fl);
