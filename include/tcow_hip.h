@@ -257,6 +257,10 @@ int tcow_flags_fwd(void* stream, int BT, int S, int D, int F, const float* x, co
  *   per-step operand copies of the f32 master weights (Wt feeds the input-gradient GEMMs). */
 int tcow_scale_cast(void* stream, int dtype, long rows, int D, const float* src, long ld_src, const float* row_scale,
                     void* dst, long ld_dst);
+/* DropPath row scales of all `depth` blocks of a divided space-time step (vit_utils.py:139-154 at vit.py:172-186) from uniform draws
+ * u [depth][B*(S-1) + B*T + B] (temporal: per clip and spatial position; spatial: per clip and frame; MLP: per clip) and keep_p [depth]:
+ * scale = floor(u + keep_p) / keep_p.  out f32 [4][depth][B*T*S]: temporal (1 on slot 0) | spatial | MLP | temporal x mask0. */
+int tcow_droppath_rows(void* stream, int depth, int B, int T, int S, const float* u, const float* keep_p, const float* mask0, float* out);
 int tcow_cast_transpose(void* stream, int dtype, int N, int K, const float* W, void* Wc, void* Wt);
 /* The same for many weights in one launch: `table` is a device array of n records {const float* W; void* Wc; void* Wt; int N;
  * int K; int tile_begin; int tile} (tcow_cast_desc_bytes() bytes each, 8-byte aligned), tile = tile edge E of the record: 64 (only
@@ -320,6 +324,27 @@ int tcow_iou_counts(void* stream, const float* logits, const float* target, long
 int tcow_build_masks(void* stream, int B, int Q, int M, int T, long HW, int query_time, const unsigned char* segm,
                      const unsigned char* div_segm, const int* query_idx, const int* front_idx, const int* cont_idx,
                      float* query_mask, float* target_mask, unsigned char* snitch_occl_by_ptr, int* counts);
+
+/* tcow_build_masks with the per-frame decisions made on the device as well (data/data_utils.py:455-492 + loss.py:55-83, 285-308): one
+ * launch over (b, q, t) picks the frontmost occluder (first maximum of the queried instance's occluded-by row, present when the query's
+ * occlusion fraction >= front_thres and that maximum >= front_half_thres) and the outermost container (among the instances containing the
+ * query at >= outer_thres the one least contained itself; one candidate or none: the strongest container) from occl_fracs (B,K,T,3) f32 and
+ * the containment DAG dag (B,T,M,M,3) f32 for the queried instances sel (B,Q) int64, then the mask pass of tcow_build_masks runs on them.
+ * Also written: idx_ws int32 [B*Q + 2*B*Q*T] (query | front | cont indices, -1 = none), ids (B,Q,T,2) u8 (index + 1, 0 = none: full_occl_cont_id),
+ * flags (B,Q,T,3) f32 {has occluder, has container, occlusion fraction}, sel_occl_fracs (B,Q,T,3) f32, frame_w [3][B*Q*T] f32: the snitch frame
+ * weights max(occl * occluded_weight, 1) with x0.2 at (B-1, :, query_time) (loss.py:55-83), and the occluder / container channel weights
+ * (has_weight where the frame has such a mask, zero_weight elsewhere: loss.py:285-308 with the caller's f32 roundings of 1-z+z and z).
+ * counts as in tcow_build_masks (zeroed here). */
+int tcow_build_query_masks(void* stream, int B, int Q, int K, int M, int T, long HW, int query_time, const unsigned char* segm,
+                           const unsigned char* div_segm, const float* occl_fracs, const float* dag, const long long* sel, float front_thres,
+                           float front_half_thres, float outer_thres, float occluded_weight, float zero_weight, float has_weight, int* idx_ws,
+                           unsigned char* ids, float* flags, float* sel_occl_fracs, float* frame_w, float* query_mask, float* target_mask,
+                           unsigned char* snitch_occl_by_ptr, int* counts);
+
+/* eval/metrics.py:55-113 from tcow_iou_counts' table counts (n_seq, C, T, 3) int32: mean[6] f32 / count[6] int32 in the order snitch_iou,
+ * occl_mask_iou, cont_mask_iou, snitch_during_vis_iou, snitch_during_occl_iou, snitch_during_cont_iou (float64 sums; mean -1 where count 0;
+ * channels beyond C count as absent). */
+int tcow_iou_means(void* stream, const int* counts, int n_seq, int C, int T, float* mean, int* count);
 
 /* Snitch pixel weights (loss.py:85-148) times the frame weights (loss.py:55-83): weights[f,i] = frame_w[f] * class-balance factor
  * (from *pos_count amodal pixels out of n_seq*T*H*W) * 2 on occluded snitch pixels * hard_negative_factor on the band between the

@@ -97,6 +97,7 @@ SIGNATURES = {
     'tcow_upsample_fwd': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'tcow_upsample_bwd': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'tcow_flags_fwd': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    'tcow_droppath_rows': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'tcow_scale_cast': (_i, [_vp, _i, _l, _i, _vp, _l, _vp, _vp, _l]),
     'tcow_cast_transpose': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     'tcow_cast_desc_bytes': (_l, []),
@@ -107,6 +108,8 @@ SIGNATURES = {
     'tcow_mask_loss': (_i, [_vp, ctypes.POINTER(MaskLossArgs)]),
     'tcow_iou_counts': (_i, [_vp, _vp, _vp, _l, _l, _vp]),
     'tcow_build_masks': (_i, [_vp, _i, _i, _i, _i, _l, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'tcow_build_query_masks': (_i, [_vp, _i, _i, _i, _i, _i, _l, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'tcow_iou_means': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     'tcow_snitch_weights_workspace_bytes': (ctypes.c_size_t, [_l, _i, _i]),
     'tcow_snitch_weights': (_i, [_vp, _l, _i, _i, _i, _vp, _l, _vp, _vp, _vp, _i, _f, _vp, _vp, ctypes.c_size_t]),
 }

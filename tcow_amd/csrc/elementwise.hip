@@ -436,6 +436,25 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(int N, int K, const
 
 static inline int gs_blocks(long total, int per_block = 256) { long b = (total + per_block - 1) / per_block; return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); }
 
+// DropPath row scales of every block of a divided space-time step (vit_utils.py:139-154 applied at vit.py:172-186): keep = floor(u + keep_p),
+// scale = keep / keep_p, one draw per (clip, spatial position) for the temporal branch, per (clip, frame) for the spatial one, per clip for the
+// MLP.  out [4][depth][B*T*S]: temporal | spatial | MLP | temporal x mask0 (the row scale of the folded temporal projection).
+__global__ void __launch_bounds__(256) droppath_rows_kernel(int depth, int B, int T, int S, const float* __restrict__ u, const float* __restrict__ keep_p,
+                                                            const float* __restrict__ mask0, float* __restrict__ out) {
+    const long M = (long)B * T * S, n = (long)depth * M;
+    const int N = S - 1, per = B * N + B * T + B;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int l = (int)(i / M); const long r = i - (long)l * M;
+        const int b = (int)(r / ((long)T * S)), ts = (int)(r - (long)b * T * S), t = ts / S, sp = ts - t * S;
+        const float kp = keep_p[l];
+        const float* ul = u + (long)l * per;
+        const float st = sp == 0 ? 1.0f : floorf(ul[b * N + sp - 1] + kp) / kp;
+        const float ss = floorf(ul[B * N + b * T + t] + kp) / kp;
+        const float sm = floorf(ul[B * N + B * T + b] + kp) / kp;
+        out[i] = st; out[n + i] = ss; out[2 * n + i] = sm; out[3 * n + i] = st * mask0[r];
+    }
+}
+
 extern "C" {
 
 int tcow_im2col(void* stream, int dtype, int B, int T_, int H, int W, int P, const float* rgb, const float* query, int pretrained_norm, void* out) {
@@ -593,6 +612,14 @@ int tcow_cast_transpose_batched(void* stream, int dtype, const void* table, int 
     if (dtype == TCOW_BF16) hipLaunchKernelGGL(cast_transpose_batched_kernel<bf16_t>, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, (const CastDesc*)table, n);
     else if (dtype == TCOW_F32) hipLaunchKernelGGL(cast_transpose_batched_kernel<float>, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, (const CastDesc*)table, n);
     else { tcow_set_error("tcow_cast_transpose_batched: unknown dtype %d", dtype); return TCOW_ERR_INVALID_ARG; }
+    TCOW_CHECK_LAUNCH();
+    return TCOW_OK;
+}
+
+int tcow_droppath_rows(void* stream, int depth, int B, int T, int S, const float* u, const float* keep_p, const float* mask0, float* out) {
+    TCOW_CHECK_ARG(depth > 0 && B > 0 && T > 0 && S > 1 && u && keep_p && mask0 && out, "tcow_droppath_rows: bad arguments");
+    const long n = (long)depth * B * T * S;
+    hipLaunchKernelGGL(droppath_rows_kernel, dim3(gs_blocks(n)), dim3(256), 0, (hipStream_t)stream, depth, B, T, S, u, keep_p, mask0, out);
     TCOW_CHECK_LAUNCH();
     return TCOW_OK;
 }

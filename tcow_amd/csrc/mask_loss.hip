@@ -430,6 +430,7 @@ struct BuildMasksArgs {
     const int* front; const int* cont;                 // [B*Q*T] instance index of the frontmost occluder / outermost container, -1 = none
     float* qmask; float* target; uint8_t* ptr;         // (B,Q,1,T,H,W), (B,Q,3,T,H,W), (B,Q,1,T,H,W)
     int* counts;                                       // [1 + 2*Q]: amodal pixels of channel 0; per query: any(query mask), any(target)
+    float* fw_occl; float* fw_cont; float has_weight;  // optional [B*Q*T] frame weights of channels 1 / 2 (preset to the empty-frame weight): has_weight where the frame has a mask
     int B, Q, M, T, HW16, qt;
 };
 __global__ void __launch_bounds__(256) build_masks_kernel(BuildMasksArgs a) {
@@ -446,7 +447,7 @@ __global__ void __launch_bounds__(256) build_masks_kernel(BuildMasksArgs a) {
     float4* t1 = reinterpret_cast<float4*>(a.target + (((size_t)bq * 3 + 1) * a.T + t) * plane);
     float4* t2 = reinterpret_cast<float4*>(a.target + (((size_t)bq * 3 + 2) * a.T + t) * plane);
     uint4* pt = reinterpret_cast<uint4*>(a.ptr + (size_t)f * plane);
-    int n_amodal = 0, any_q = 0, any_t = 0;
+    int n_amodal = 0, any_q = 0, any_t = 0, any_f = 0, any_c = 0;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < a.HW16; i += gridDim.x * 256) {
         const uint4 sv = seg[i], qv = dq[i];
         const uint4 fv = df ? df[i] : make_uint4(0, 0, 0, 0), cv = dc ? dc[i] : make_uint4(0, 0, 0, 0);
@@ -465,7 +466,7 @@ __global__ void __launch_bounds__(256) build_masks_kernel(BuildMasksArgs a) {
                 qo[e] = (t == a.qt && isq) ? 1.f : 0.f;
                 o0[e] = amodal ? 1.f : 0.f; o1[e] = fr ? 1.f : 0.f; o2[e] = co ? 1.f : 0.f;
                 if (amodal && !isq) pword |= s << (8 * e);
-                n_amodal += amodal; any_q |= (t == a.qt && isq); any_t |= amodal | fr | co;
+                n_amodal += amodal; any_q |= (t == a.qt && isq); any_t |= amodal | fr | co; any_f |= fr; any_c |= co;
             }
             pw[w] = pword;
             qm[i * 4 + w] = make_float4(qo[0], qo[1], qo[2], qo[3]);
@@ -475,11 +476,105 @@ __global__ void __launch_bounds__(256) build_masks_kernel(BuildMasksArgs a) {
         }
         pt[i] = make_uint4(pw[0], pw[1], pw[2], pw[3]);
     }
-    for (int o = 32; o > 0; o >>= 1) { n_amodal += __shfl_xor(n_amodal, o, 64); any_q |= __shfl_xor(any_q, o, 64); any_t |= __shfl_xor(any_t, o, 64); }
+    for (int o = 32; o > 0; o >>= 1) {
+        n_amodal += __shfl_xor(n_amodal, o, 64); any_q |= __shfl_xor(any_q, o, 64); any_t |= __shfl_xor(any_t, o, 64);
+        any_f |= __shfl_xor(any_f, o, 64); any_c |= __shfl_xor(any_c, o, 64);
+    }
     if ((threadIdx.x & 63) == 0) {
         if (n_amodal) atomicAdd(&a.counts[0], n_amodal);
         if (any_q) atomicOr(&a.counts[1 + 2 * q], 1);
         if (any_t) atomicOr(&a.counts[2 + 2 * q], 1);
+        // loss.py:285-292, 302-308: the frame weight of the occluder / container channel where the frame has a mask (every writer stores the same value)
+        if (any_f && a.fw_occl) a.fw_occl[f] = a.has_weight;
+        if (any_c && a.fw_cont) a.fw_cont[f] = a.has_weight;
+    }
+}
+
+// The per-frame decisions of data_utils.py:455-492 and the frame weights of loss.py:55-83 for all (b, q, t): which instance is the frontmost
+// occluder / outermost container of the queried instance in each frame, the ids and flags that go with it, the queried instances' occlusion
+// fractions, the snitch frame weights -- (B, Q, T)-sized tables that were ~40 tensor operations per step.  One thread per (b, q, t).
+struct QueryTablesArgs {
+    const float* occl_fracs; const float* dag; const long long* sel;     // (B,K,T,3), (B,T,M,M,3), (B,Q)
+    int B, Q, K, T, M, qt;
+    float front_thres, front_half_thres, outer_thres, occluded_weight, zero_weight;
+    int* query_idx; int* front; int* cont;                                // [B*Q], [B*Q*T] x 2
+    uint8_t* ids; float* flags; float* sel_occl; float* frame_w;          // (B,Q,T,2) u8, (B,Q,T,3), (B,Q,T,3), [3][B*Q*T] (snitch | occluder | container)
+    int* counts; int n_counts;
+};
+__global__ void __launch_bounds__(256) query_tables_kernel(QueryTablesArgs a) {
+    const int n = a.B * a.Q * a.T;
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f < a.n_counts) a.counts[f] = 0;                                  // (n_counts <= n: 1 + 2 Q <= B Q T checked by the caller)
+    if (f >= n) return;
+    const int t = f % a.T, bq = f / a.T, b = bq / a.Q;
+    const int s = (int)a.sel[bq];
+    if (t == 0) a.query_idx[bq] = s;
+    const float* of = a.occl_fracs + (((size_t)b * a.K + s) * a.T + t) * 3;
+    const float* frame = a.dag + ((size_t)b * a.T + t) * a.M * a.M * 3;
+    const float* row = frame + (size_t)s * a.M * 3;                       // the queried instance's row: [m][0] = contained by m, [m][2] = occluded by m
+    const float of0 = of[0];
+    float fmax = row[2]; int farg = 0;                                    // frontmost occluder: the first maximum (data_utils.py:455-458)
+    for (int m = 1; m < a.M; ++m) { const float v = row[m * 3 + 2]; if (v > fmax) { fmax = v; farg = m; } }
+    const bool has_front = of0 >= a.front_thres && fmax >= a.front_half_thres;
+    // outermost container (:468-492): among the instances that contain the query, the one least contained itself; a single candidate
+    // (or none) falls back to the strongest container
+    int n_cand = 0, outer = 0, amax_i = 0;
+    float best = __builtin_inff(), cmax = row[0];
+    for (int m = 0; m < a.M; ++m) {
+        const float c = row[m * 3];
+        if (m > 0 && c > cmax) { cmax = c; amax_i = m; }
+        if (c >= a.outer_thres) {
+            ++n_cand;
+            const float* rm = frame + (size_t)m * a.M * 3;
+            float sc = rm[0];
+            for (int j = 1; j < a.M; ++j) sc = fmaxf(sc, rm[j * 3]);
+            if (sc < best) { best = sc; outer = m; }
+        }
+    }
+    if (n_cand <= 1) outer = amax_i;
+    const bool has_cont = n_cand > 0;
+    a.front[f] = has_front ? farg : -1;
+    a.cont[f] = has_cont ? outer : -1;
+    a.ids[f * 2] = (uint8_t)(has_front ? farg + 1 : 0); a.ids[f * 2 + 1] = (uint8_t)(has_cont ? outer + 1 : 0);
+    a.flags[f * 3] = has_front ? 1.f : 0.f; a.flags[f * 3 + 1] = has_cont ? 1.f : 0.f; a.flags[f * 3 + 2] = of0;
+    a.sel_occl[f * 3] = of0; a.sel_occl[f * 3 + 1] = of[1]; a.sel_occl[f * 3 + 2] = of[2];
+    float fw = fmaxf(of0 * a.occluded_weight, 1.0f);                      // loss.py:55-83
+    if (b == a.B - 1 && t == a.qt) fw *= 0.2f;                            // (:79 indexes with the leaked loop variable b == B - 1: only the last clip)
+    a.frame_w[f] = fw; a.frame_w[n + f] = a.zero_weight; a.frame_w[2 * n + f] = a.zero_weight;
+}
+
+// eval/metrics.py:55-113 from the per-frame area tables of tcow_iou_counts: the six masked IoU means and their frame counts
+__global__ void __launch_bounds__(256) iou_means_kernel(const int* __restrict__ counts, int n_seq, int C, int T, float* __restrict__ mean, int* __restrict__ count) {
+    __shared__ double ssum[6][4];
+    __shared__ int scnt[6][4];
+    double sum[6] = {0., 0., 0., 0., 0., 0.};
+    int cnt[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = threadIdx.x; i < n_seq * T; i += 256) {
+        const int sq = i / T, t = i - sq * T;
+        double iou[3] = {0., 0., 0.}; bool has[3] = {false, false, false};
+        for (int c = 0; c < C && c < 3; ++c) {
+            const int* k = counts + (((size_t)sq * C + c) * T + t) * 3;
+            iou[c] = (double)k[1] / ((double)k[2] + 1e-7);                 // metrics.py:55-66
+            has[c] = k[0] > 0;
+        }
+        const bool sel[6] = {has[0], has[1], has[2], has[0] && !has[1] && C >= 2, has[0] && has[1], has[0] && has[2]};
+        const double val[6] = {iou[0], iou[1], iou[2], iou[0], iou[0], iou[0]};
+#pragma unroll
+        for (int k = 0; k < 6; ++k) if (sel[k]) { sum[k] += val[k]; ++cnt[k]; }
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        double s = sum[k]; int c = cnt[k];
+        for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); c += __shfl_xor(c, o, 64); }
+        if ((threadIdx.x & 63) == 0) { ssum[k][threadIdx.x >> 6] = s; scnt[k][threadIdx.x >> 6] = c; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int k = threadIdx.x;
+        const double s = (ssum[k][0] + ssum[k][1]) + (ssum[k][2] + ssum[k][3]);
+        const int c = scnt[k][0] + scnt[k][1] + scnt[k][2] + scnt[k][3];
+        mean[k] = c > 0 ? (float)(s / (double)c) : -1.0f;
+        count[k] = c;
     }
 }
 
@@ -556,8 +651,44 @@ extern "C" int tcow_build_masks(void* stream, int B, int Q, int M, int T, long H
     BuildMasksArgs a;
     a.segm = segm; a.div = div_segm; a.qidx = query_idx; a.front = front_idx; a.cont = cont_idx; a.qmask = query_mask; a.target = target_mask;
     a.ptr = snitch_occl_by_ptr; a.counts = counts; a.B = B; a.Q = Q; a.M = M; a.T = T; a.HW16 = (int)(HW / 16); a.qt = query_time;
+    a.fw_occl = nullptr; a.fw_cont = nullptr; a.has_weight = 1.0f;
     const int gx = cdiv(a.HW16, 256) < 8 ? cdiv(a.HW16, 256) : 8;
     hipLaunchKernelGGL(build_masks_kernel, dim3(gx, B * Q * T), dim3(256), 0, st, a);
+    TCOW_CHECK_LAUNCH();
+    return TCOW_OK;
+}
+
+extern "C" int tcow_build_query_masks(void* stream, int B, int Q, int K, int M, int T, long HW, int query_time, const uint8_t* segm, const uint8_t* div_segm,
+                                      const float* occl_fracs, const float* dag, const long long* sel, float front_thres, float front_half_thres,
+                                      float outer_thres, float occluded_weight, float zero_weight, float has_weight, int* idx_ws, uint8_t* ids, float* flags,
+                                      float* sel_occl_fracs, float* frame_w, float* query_mask, float* target_mask, uint8_t* snitch_occl_by_ptr, int* counts) {
+    TCOW_CHECK_ARG(B > 0 && Q > 0 && K > 0 && M > 0 && T > 0 && HW > 0 && HW % 16 == 0, "tcow_build_query_masks: bad shape (H*W must be a multiple of 16)");
+    TCOW_CHECK_ARG(segm && div_segm && occl_fracs && dag && sel && idx_ws && ids && flags && sel_occl_fracs && frame_w && query_mask && target_mask &&
+                   snitch_occl_by_ptr && counts, "tcow_build_query_masks: null pointer");
+    TCOW_CHECK_ARG((long)B * Q * T < 65536 && 1 + 2 * Q <= B * Q * T && M <= 255, "tcow_build_query_masks: B*Q*T must be in [1 + 2Q, 65536), M <= 255");
+    TCOW_CHECK_ARG(query_time >= 0 && query_time < T, "tcow_build_query_masks: query_time %d outside [0, %d)", query_time, T);
+    hipStream_t st = (hipStream_t)stream;
+    const int n = B * Q * T;
+    QueryTablesArgs qa;
+    qa.occl_fracs = occl_fracs; qa.dag = dag; qa.sel = sel; qa.B = B; qa.Q = Q; qa.K = K; qa.T = T; qa.M = M; qa.qt = query_time;
+    qa.front_thres = front_thres; qa.front_half_thres = front_half_thres; qa.outer_thres = outer_thres; qa.occluded_weight = occluded_weight; qa.zero_weight = zero_weight;
+    qa.query_idx = idx_ws; qa.front = idx_ws + B * Q; qa.cont = idx_ws + B * Q + n;
+    qa.ids = ids; qa.flags = flags; qa.sel_occl = sel_occl_fracs; qa.frame_w = frame_w; qa.counts = counts; qa.n_counts = 1 + 2 * Q;
+    hipLaunchKernelGGL(query_tables_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, qa);
+    TCOW_CHECK_LAUNCH();
+    BuildMasksArgs a;
+    a.segm = segm; a.div = div_segm; a.qidx = qa.query_idx; a.front = qa.front; a.cont = qa.cont; a.qmask = query_mask; a.target = target_mask;
+    a.ptr = snitch_occl_by_ptr; a.counts = counts; a.B = B; a.Q = Q; a.M = M; a.T = T; a.HW16 = (int)(HW / 16); a.qt = query_time;
+    a.fw_occl = frame_w + n; a.fw_cont = frame_w + 2 * n; a.has_weight = has_weight;
+    const int gx = cdiv(a.HW16, 256) < 8 ? cdiv(a.HW16, 256) : 8;
+    hipLaunchKernelGGL(build_masks_kernel, dim3(gx, n), dim3(256), 0, st, a);
+    TCOW_CHECK_LAUNCH();
+    return TCOW_OK;
+}
+
+extern "C" int tcow_iou_means(void* stream, const int* counts, int n_seq, int C, int T, float* mean, int* count) {
+    TCOW_CHECK_ARG(counts && mean && count && n_seq > 0 && C >= 1 && T > 0, "tcow_iou_means: bad arguments");
+    hipLaunchKernelGGL(iou_means_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, counts, n_seq, C, T, mean, count);
     TCOW_CHECK_LAUNCH();
     return TCOW_OK;
 }

@@ -202,16 +202,25 @@ def _row_vectors(module, g, train):
     if forced is None and train and max(rates) > 0.:
         # all DropPath draws of the step in one batch (vit_utils.py:150-152 per call: keep = floor(rand + 1 - r), x / (1 - r) * keep):
         # one rand and three broadcasts instead of ~15 tiny launches per block
-        keep_p = 1.0 - torch.tensor(rates, dtype=torch.float32, device=dev)[:, None]
+        kkey = ('keep_p', tuple(rates), str(dev))
+        keep_p = module._wcache.get(kkey)
+        if keep_p is None:
+            keep_p = (1.0 - torch.tensor(rates, dtype=torch.float32)).to(dev)
+            module._wcache[kkey] = keep_p
         u = torch.rand(depth, B * N + B * T + B, device=dev)
-        sc = (u + keep_p).floor_() / keep_p
-        kt = sc[:, :B * N].reshape(depth, B, 1, N); ks = sc[:, B * N:B * N + B * T].reshape(depth, B, T, 1); km = sc[:, B * N + B * T:].reshape(depth, B, 1)
-        rt = torch.ones(depth, B, T, S, dtype=torch.float32, device=dev)
-        rt[:, :, :, 1:] = kt
-        rt = rt.reshape(depth, -1)
-        rsp = ks.expand(depth, B, T, S).reshape(depth, -1)
-        rml = km.expand(depth, B, T * S).reshape(depth, -1)
-        rt0 = rt * mask0[None, :]               # mask0 * dp_t: row scale of the folded temporal projection
+        if u.is_cuda and N == S - 1:
+            from . import ops
+            rt, rsp, rml, rt0 = ops.droppath_rows(u, keep_p, mask0, B, T, S)       # the broadcasts below as one launch
+        else:
+            kp = keep_p[:, None]
+            sc = (u + kp).floor_() / kp
+            kt = sc[:, :B * N].reshape(depth, B, 1, N); ks = sc[:, B * N:B * N + B * T].reshape(depth, B, T, 1); km = sc[:, B * N + B * T:].reshape(depth, B, 1)
+            rt = torch.ones(depth, B, T, S, dtype=torch.float32, device=dev)
+            rt[:, :, :, 1:] = kt
+            rt = rt.reshape(depth, -1)
+            rsp = ks.expand(depth, B, T, S).reshape(depth, -1)
+            rml = km.expand(depth, B, T * S).reshape(depth, -1)
+            rt0 = rt * mask0[None, :]               # mask0 * dp_t: row scale of the folded temporal projection
         for i in range(depth):
             live = rates[i] > 0.
             scales.append({'t': rt[i] if live else None, 's': rsp[i] if live else None, 'm': rml[i] if live else None, 't0': rt0[i] if live else mask0})

@@ -14,8 +14,12 @@ def calculate_metrics_mask_track(output_mask, target_mask, plugin=False):
     Cmt = lead[2]
     if output_mask.is_cuda and output_mask.dtype == torch.float32 and target_mask.dtype == torch.float32 and (output_mask.shape[-1] * output_mask.shape[-2]) % 4 == 0:
         from . import ops                                                  # one pass over both tensors (tcow_iou_counts)
-        cnt = ops.iou_counts(output_mask.detach(), target_mask).reshape(lead + (3,)).to(torch.float64)
-        t_area, inter, union = cnt[..., 0], cnt[..., 1], cnt[..., 2]
+        cnt_i = ops.iou_counts(output_mask.detach(), target_mask).reshape(lead + (3,))
+        mean6, n6 = ops.iou_means(cnt_i.reshape((-1,) + tuple(cnt_i.shape[2:])))            # the masked means below as one launch (tcow_iou_means)
+        out = {}
+        for i, k in enumerate(('snitch_iou', 'occl_mask_iou', 'cont_mask_iou', 'snitch_during_vis_iou', 'snitch_during_occl_iou', 'snitch_during_cont_iou')):
+            out['mean_' + k] = mean6[i]; out['count_' + k] = n6[i]
+        return out
     else:
         out_b = (output_mask > 0.0).reshape(lead + tuple(output_mask.shape[-2:]))      # metrics.py:19
         tgt_b = (target_mask > 0.5).reshape(lead + tuple(target_mask.shape[-2:]))      # metrics.py:20

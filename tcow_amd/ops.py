@@ -6,6 +6,7 @@ failing library raises TcowError.
 """
 import ctypes
 
+import numpy as np
 import torch
 
 from . import _lib as L
@@ -277,6 +278,18 @@ def scale_cast(mode, src, row_scale, dst):
     return dst
 
 
+def droppath_rows(u, keep_p, mask0, B, T, S):
+    """u (depth, B*(S-1) + B*T + B) f32 uniform draws, keep_p (depth,) f32, mask0 [B*T*S] f32 -> (4, depth, B*T*S) f32 row scales
+    (temporal | spatial | MLP | temporal x mask0), see tcow_droppath_rows."""
+    _need_cuda(u, keep_p, mask0)
+    depth = u.shape[0]
+    if u.shape[1] != B * (S - 1) + B * T + B or u.dtype != torch.float32 or not u.is_contiguous() or mask0.numel() != B * T * S:
+        raise L.TcowError('droppath_rows: u must be contiguous f32 (depth, B*(S-1) + B*T + B), mask0 [B*T*S]')
+    out = torch.empty(4, depth, B * T * S, dtype=torch.float32, device=u.device)
+    L.check(L.lib().tcow_droppath_rows(_stream(), depth, B, T, S, u.data_ptr(), keep_p.data_ptr(), mask0.data_ptr(), out.data_ptr()), 'tcow_droppath_rows')
+    return out
+
+
 def cast_transpose(mode, W, Wc=None, Wt=None):
     N, K = W.shape
     L.check(_sel(mode)[0].tcow_cast_transpose(_stream(), _sel(mode)[1], N, K, W.data_ptr(), _p(Wc), _p(Wt)), 'tcow_cast_transpose', _sel(mode)[0])
@@ -341,6 +354,52 @@ def build_masks(segm, div_segm, query_idx, front_idx, cont_idx, query_time):
     L.check(L.lib().tcow_build_masks(_stream(), B, Q, M, T, H * W, int(query_time), segm.data_ptr(), div_segm.data_ptr(), qi.data_ptr(), fi.data_ptr(),
                                      ci.data_ptr(), qm.data_ptr(), tg.data_ptr(), pt.data_ptr(), counts.data_ptr()), 'tcow_build_masks')
     return qm, tg, pt, counts
+
+
+def build_query_masks(segm, div_segm, occl_fracs, dag, sel, query_time, front_occl_thres, outer_cont_thres, occluded_weight, occl_cont_zero_weight):
+    """data_utils.py:414-510 for every query of the batch, the per-frame occluder / container decisions included (tcow_build_query_masks):
+    segm (B,1,T,H,W) u8, div_segm (B,M,T,H,W) u8, occl_fracs (B,K,T,3) f32, dag (B,T,M,M,3) f32, sel (B,Q) int64 queried instances.
+    Returns a dict: query_mask (B,Q,1,T,H,W) f32, target (B,Q,3,T,H,W) f32, snitch_occl_by_ptr (B,Q,1,T,H,W) u8, counts int32 [1 + 2Q],
+    ids (B,Q,T,2) u8, flags (B,Q,T,3) f32, sel_occl_fracs (B,Q,T,3) f32, frame_w (3,B,Q,T) f32 (snitch | occluder | container frame
+    weights of loss.py:55-83, 285-308), front_idx / cont_idx (B,Q,T) int32."""
+    _need_cuda(segm, div_segm, occl_fracs, dag, sel)
+    B, _, T, H, W = segm.shape
+    M = div_segm.shape[1]; K = occl_fracs.shape[1]; Q = sel.shape[1]
+    if segm.dtype != torch.uint8 or div_segm.dtype != torch.uint8 or not segm.is_contiguous() or not div_segm.is_contiguous():
+        raise L.TcowError('build_query_masks: segmentation maps must be contiguous uint8 tensors')
+    if tuple(dag.shape) != (B, T, M, M, 3) or tuple(occl_fracs.shape[2:]) != (T, 3) or sel.dtype != torch.int64:
+        raise L.TcowError('build_query_masks: occl_fracs (B,K,T,3), dag (B,T,M,M,3) and int64 sel (B,Q) expected')
+    dev = segm.device
+    of = occl_fracs.to(torch.float32).contiguous(); dg = dag.to(torch.float32).contiguous(); sl = sel.contiguous()
+    n = B * Q * T
+    qm = torch.empty(B, Q, 1, T, H, W, dtype=torch.float32, device=dev); tg = torch.empty(B, Q, 3, T, H, W, dtype=torch.float32, device=dev)
+    pt = torch.empty(B, Q, 1, T, H, W, dtype=torch.uint8, device=dev); counts = torch.empty(1 + 2 * Q, dtype=torch.int32, device=dev)
+    idx = torch.empty(B * Q + 2 * n, dtype=torch.int32, device=dev)
+    ids = torch.empty(B, Q, T, 2, dtype=torch.uint8, device=dev)
+    fl = torch.empty(2, B, Q, T, 3, dtype=torch.float32, device=dev)         # flags | sel_occl_fracs (one allocation)
+    fw = torch.empty(3, B, Q, T, dtype=torch.float32, device=dev)
+    f32 = np.float32
+    z = f32(occl_cont_zero_weight)
+    has_w = f32(f32(1.0 - occl_cont_zero_weight) + z)                        # has * (1 - z) + z in f32, as the tensor expression rounds it
+    L.check(L.lib().tcow_build_query_masks(_stream(), B, Q, K, M, T, H * W, int(query_time), segm.data_ptr(), div_segm.data_ptr(), of.data_ptr(), dg.data_ptr(),
+                                           sl.data_ptr(), float(f32(front_occl_thres)), float(f32(front_occl_thres / 2.0)), float(f32(outer_cont_thres)),
+                                           float(f32(float(occluded_weight))), float(z), float(has_w), idx.data_ptr(), ids.data_ptr(), fl[0].data_ptr(),
+                                           fl[1].data_ptr(), fw.data_ptr(), qm.data_ptr(), tg.data_ptr(), pt.data_ptr(), counts.data_ptr()),
+            'tcow_build_query_masks')
+    return {'query_mask': qm, 'target': tg, 'snitch_occl_by_ptr': pt, 'counts': counts, 'ids': ids, 'flags': fl[0], 'sel_occl_fracs': fl[1], 'frame_w': fw,
+            'front_idx': idx[B * Q:B * Q + n].view(B, Q, T), 'cont_idx': idx[B * Q + n:].view(B, Q, T)}
+
+
+def iou_means(counts):
+    """counts (n_seq, C, T, 3) int32 from iou_counts -> (mean f32 [6], count int32 [6]): eval/metrics.py:55-113 (see tcow_iou_means)."""
+    _need_cuda(counts)
+    if counts.dtype != torch.int32 or counts.dim() != 4 or counts.shape[-1] != 3 or not counts.is_contiguous():
+        raise L.TcowError('iou_means: contiguous int32 (n_seq, C, T, 3) counts expected')
+    n_seq, C, T, _ = counts.shape
+    out = torch.empty(12, dtype=torch.float32, device=counts.device)
+    cnt = out[6:].view(torch.int32)
+    L.check(L.lib().tcow_iou_means(_stream(), counts.data_ptr(), n_seq, C, T, out.data_ptr(), cnt.data_ptr()), 'tcow_iou_means')
+    return out[:6], cnt
 
 
 def snitch_weights(target, snitch_occl_by_ptr, frame_w, pos_count, class_balancing=True, hard_negative_factor=3.0):

@@ -129,17 +129,19 @@ class SeekerPipeline:
         qt = int(tr['query_time'][0].item())                               # pipeline.py:140: only [0] is used
         if sel_query_inds is None:
             sel_query_inds = sample_query_inds(B, Qs, kr['pv_inst_count'], des, self.phase, self.rng)
-        pos_count = None
+        pos_count = None; tab = None
         if segm.is_cuda and segm.dtype == torch.uint8 and div.dtype == torch.uint8 and (H * W) % 16 == 0:
             # one HIP pass over the segmentation maps for all queries (tcow_build_masks); the per-frame occluder / container choice
             # stays a handful of tensor ops on (B,Qs,T,M)-sized data
             from . import ops
             sel_d = to_dev(sel_query_inds, dev)
-            front_idx, cont_idx, ids_all, _ = frame_decisions(occl_fracs, dag, sel_d, self.args)
-            query_mask, target, ptr_all, counts = ops.build_masks(segm.contiguous(), div.contiguous(), sel_d, front_idx, cont_idx, qt)
-            nonzero = counts[1:] != 0
+            a = self.args
+            tab = ops.build_query_masks(segm.contiguous(), div.contiguous(), occl_fracs, dag, sel_d, qt, a.front_occl_thres, a.outer_cont_thres,
+                                        a.occluded_weight, a.occl_cont_zero_weight)
+            query_mask, target, counts = tab['query_mask'], tab['target'], tab['counts']
+            nonzero = counts                                                # [1 + 2q], [2 + 2q] != 0: inspected on the host below
             pos_count = counts[0:1]
-            snitch_ptr, ids_stack = ptr_all, ids_all
+            snitch_ptr, ids_stack = tab['snitch_occl_by_ptr'], tab['ids']
         else:
             qms, ptrs, idss, tgts, nonzero = [], [], [], [], []
             for q in range(Qs):                                            # cheap tensor ops; the model call below is batched
@@ -153,11 +155,12 @@ class SeekerPipeline:
         # mask kernels and are inspected after the model call has been queued: same error, before any loss / update, but the
         # host never waits on an empty stream.
         if nonzero.is_cuda:
-            host_flags = torch.empty(nonzero.shape, dtype=torch.bool, pin_memory=True)
+            host_flags = torch.empty(nonzero.shape, dtype=nonzero.dtype, pin_memory=True)
             host_flags.copy_(nonzero, non_blocking=True)
             flags_ready = torch.cuda.Event(); flags_ready.record()
         else:
             host_flags, flags_ready = nonzero, None
+        f0 = 1 if tab is not None else 0                                    # (the table's first entry is the positive-pixel count)
         if getattr(self.seeker, 'shares_rgb', False):                          # tcow_amd Seeker: the clip's frames go in once for its Qs queries
             out_mask, _ = self.seeker(rgb, query_mask.reshape(B * Qs, 1, T, H, W))
         else:
@@ -166,16 +169,25 @@ class SeekerPipeline:
         if flags_ready is not None:
             flags_ready.synchronize()
         for q in range(Qs):
-            if not bool(host_flags[2 * q]):
+            if not bool(host_flags[f0 + 2 * q]):
                 raise RuntimeError(f'seeker_query_mask all zero? q: {q} query_idx: {sel_query_inds[:, q]} qt_idx: {qt}')   # pipeline.py:149-151
-            if not bool(host_flags[2 * q + 1]):
+            if not bool(host_flags[f0 + 2 * q + 1]):
                 raise RuntimeError(f'target_mask all zero? q: {q}')        # pipeline.py:152-154
         bi = torch.arange(B)
-        sel_dev = to_dev(sel_query_inds, dev); bi_dev = to_dev(bi, dev); des_dev = to_dev(des, dev)
+        sel_des = to_dev(torch.stack([des[bi, sel_query_inds[:, q], 0] for q in range(Qs)], 1), dev)       # (a host-side gather: desirability arrives on the host)
+        if tab is not None:
+            sel_dev, sel_of = sel_d, tab['sel_occl_fracs']
+        else:
+            sel_dev = to_dev(sel_query_inds, dev); bi_dev = to_dev(bi, dev)
+            sel_of = torch.stack([occl_fracs[bi_dev, sel_dev[:, q]] for q in range(Qs)], 1)
+        extra = {}
+        if tab is not None:                                                  # frame weights of loss.py:55-83, 285-308 from the table kernel, with what they were made from
+            extra = {'_frame_w': tab['frame_w'], '_frame_w_key': (float(self.args.occluded_weight), float(self.args.occl_cont_zero_weight), qt)}
         return {
+            **extra,
             'sel_query_inds': sel_dev,
-            'sel_occl_fracs': torch.stack([occl_fracs[bi_dev, sel_dev[:, q]] for q in range(Qs)], 1),         # (B,Qs,T,3)
-            'sel_desirability': torch.stack([des_dev[bi_dev, sel_dev[:, q], 0] for q in range(Qs)], 1),
+            'sel_occl_fracs': sel_of,                                                                     # (B,Qs,T,3)
+            'sel_desirability': sel_des,
             'seeker_input': rgb, 'seeker_query_mask': query_mask,
             'snitch_occl_by_ptr': snitch_ptr, 'full_occl_cont_id': ids_stack, '_target_pos_count': pos_count,
             'target_mask': target, 'output_mask': out_mask.reshape(B, Qs, 3, T, H, W),

@@ -61,7 +61,8 @@ class FusedMaskObjective(torch.autograd.Function):
         from . import ops
         B, Q, C, T, H, W = logits.shape
         lo = logits.detach().reshape(B * Q, C, T, H, W).contiguous(); tg = target.reshape(B * Q, C, T, H, W).contiguous()
-        terms = torch.zeros(3, dtype=torch.float32, device=lo.device); total = torch.zeros((), dtype=torch.float32, device=lo.device)
+        acc = torch.zeros(4, dtype=torch.float32, device=lo.device)
+        terms = acc[:3]; total = acc[3]
         need_grad = logits.requires_grad
         dl = torch.empty_like(lo) if need_grad else None
         for c, (pw, fw, weighted) in enumerate(((snitch_w, None, False), (None, occl_fw, True), (None, cont_fw, True))):
@@ -175,8 +176,11 @@ class TcowLosses:
         a = self.args
         B, Q, C, T, H, W = out.shape
         sw = None; fws = [None, None]
+        pre = model_retval.get('_frame_w')                                  # (3,B,Q,T) from tcow_build_query_masks, valid for the arguments it was made with
+        if pre is not None and model_retval.get('_frame_w_key') != (float(a.occluded_weight), float(a.occl_cont_zero_weight), query_time):
+            pre = None
         if a.track_lw > 0.0:
-            fw = self.frame_weights(model_retval['sel_occl_fracs'], query_time)
+            fw = pre[0] if pre is not None else self.frame_weights(model_retval['sel_occl_fracs'], query_time)
             pos_count = model_retval.get('_target_pos_count')
             if pos_count is not None and tgt.is_contiguous():
                 from . import ops                                           # class balancing, x2 occluded, dilation band and frame weights in two passes
@@ -186,7 +190,9 @@ class TcowLosses:
                 sw = (fw[..., None, None] * pw).contiguous()
             model_retval['snitch_weights'] = sw
         for i, (ch, lw) in enumerate(((1, a.occl_mask_lw), (2, a.cont_mask_lw))):
-            if lw > 0.0:
+            if lw > 0.0 and pre is not None:
+                fws[i] = pre[ch]
+            elif lw > 0.0:
                 has = tgt[:, :, ch].flatten(-2).any(dim=-1).to(torch.float32)                       # (B,Q,T)
                 fws[i] = (has * (1.0 - a.occl_cont_zero_weight) + a.occl_cont_zero_weight).contiguous()
         topk_frac = min(max(1.0 - progress * 8.5, 0.15), 1.0)
@@ -201,7 +207,7 @@ class TcowLosses:
         """Scalars are returned as detached 0-dim tensors (float() them to log): no host synchronisation here."""
         a = self.args
         fused_total = loss_retval.get('_fused_total')
-        terms = {k: (torch.mean(v) if torch.is_tensor(v) else -1.0) for k, v in loss_retval.items() if k not in ('metrics', '_fused_total')}
+        terms = {k: ((v if v.dim() == 0 else torch.mean(v)) if torch.is_tensor(v) else -1.0) for k, v in loss_retval.items() if k not in ('metrics', '_fused_total')}
         if fused_total is not None:
             total = fused_total            # (terms are 0-dim per replica: their mean over replicas is the value itself)
         else:

@@ -270,3 +270,66 @@ def test_snitch_weight_kernel_options(cuda, class_balancing, factor):
     pos = (tgt[:, :, 0] == 1).sum().to(torch.int32).reshape(1)
     got = ops.snitch_weights(tgt.cuda(), ptr.cuda(), fw.cuda(), pos.cuda(), class_balancing, factor).cpu()
     assert got.shape == want.shape and float((got - want).abs().max()) < 1e-5 * float(want.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('seed', [0, 1, 2])
+def test_query_table_kernel_matches_frame_decisions(cuda, seed):
+    """tcow_build_query_masks' table pass vs the tensor restatement of data_utils.py:455-492 (frame_decisions) and of the frame weights
+    (loss.py:55-83, 285-308) on random occlusion fractions / containment DAGs: frames with no, one and several container candidates, with and
+    without a frontmost occluder.  Indices, ids, flags bit-exact; weights equal to the tensor expressions' f32 results."""
+    from tcow_amd import ops
+    from tcow_amd.pipeline import frame_decisions
+    from tcow_amd.tcow_loss import TcowLosses
+    g = torch.Generator().manual_seed(seed)
+    Bn, Kn, Tn, Qn, Hn, Wn = 2, 7, 5, 3, 16, 32
+    occl = torch.rand(Bn, Kn, Tn, 3, generator=g)
+    occl[:, :, 1, 0] = 0.99                                                  # a frame above the occlusion threshold for everyone
+    dag = torch.rand(Bn, Tn, Kn, Kn, 3, generator=g)
+    dag[:, 0, :, :, 0] *= 0.5                                                # frame 0: no container candidate at all
+    dag[:, 2, :, 3, 0] = 0.9; dag[:, 2, :, :3, 0] *= 0.5; dag[:, 2, :, 4:, 0] *= 0.5      # frame 2: exactly one candidate
+    dag[:, 3, :, :, 2] *= 0.3                                                # frame 3: occluded-by maxima below thres / 2
+    sel = torch.stack([torch.randperm(Kn, generator=g)[:Qn] for _ in range(Bn)])
+    segm = torch.randint(0, Kn + 1, (Bn, 1, Tn, Hn, Wn), generator=g, dtype=torch.uint8)
+    div = (torch.rand(Bn, Kn, Tn, Hn, Wn, generator=g) > 0.5).to(torch.uint8)
+    div[:, 3, 4] = 0                                                         # instance 3 has no pixels in frame 4: a chosen but empty occluder / container
+    args = default_args(); qt = 1
+    tab = ops.build_query_masks(segm.cuda(), div.cuda(), occl.cuda(), dag.cuda(), sel.cuda(), qt, args.front_occl_thres, args.outer_cont_thres,
+                                args.occluded_weight, args.occl_cont_zero_weight)
+    fi, ci, ids, flags = frame_decisions(occl, dag, sel, args)
+    assert torch.equal(tab['front_idx'].cpu().long(), fi) and torch.equal(tab['cont_idx'].cpu().long(), ci)
+    assert torch.equal(tab['ids'].cpu(), ids) and torch.equal(tab['flags'].cpu(), flags)
+    assert int((fi >= 0).sum()) > 0 and int((fi < 0).sum()) > 0 and int((ci >= 0).sum()) > 0 and int((ci < 0).sum()) > 0
+    bi = torch.arange(Bn)[:, None].expand(Bn, Qn)
+    sel_of = occl[bi, sel]
+    assert torch.equal(tab['sel_occl_fracs'].cpu(), sel_of)
+    qm, tg, pt, counts = ops.build_masks(segm.cuda(), div.cuda(), sel.cuda(), fi.cuda(), ci.cuda(), qt)
+    assert torch.equal(tab['query_mask'], qm) and torch.equal(tab['target'], tg) and torch.equal(tab['snitch_occl_by_ptr'], pt) and torch.equal(tab['counts'], counts)
+    L = TcowLosses(args)
+    fw = tab['frame_w'].cpu()
+    assert torch.equal(fw[0], L.frame_weights(sel_of, qt))
+    tgc = tg.cpu()
+    for ch in (1, 2):
+        has = tgc[:, :, ch].flatten(-2).any(dim=-1).to(torch.float32)
+        assert torch.equal(fw[ch], has * (1.0 - args.occl_cont_zero_weight) + args.occl_cont_zero_weight), ch
+        assert 0 < int(has.sum()) < has.numel()
+
+
+@pytest.mark.gpu
+def test_droppath_rows_kernel(cuda):
+    """tcow_droppath_rows vs the broadcast expressions of engine._row_vectors (vit_utils.py:139-154): bit-exact."""
+    from tcow_amd import ops
+    torch.manual_seed(5)
+    depth, Bn, Tn, Sn = 4, 3, 5, 9
+    N = Sn - 1
+    keep_p = 1.0 - torch.linspace(0, 0.3, depth)
+    u = torch.rand(depth, Bn * N + Bn * Tn + Bn)
+    mask0 = torch.ones(Bn, Tn, Sn); mask0[:, :, 0] = 0; mask0 = mask0.reshape(-1)
+    kp = keep_p[:, None]
+    sc = (u + kp).floor() / kp
+    kt = sc[:, :Bn * N].reshape(depth, Bn, 1, N); ks = sc[:, Bn * N:Bn * N + Bn * Tn].reshape(depth, Bn, Tn, 1); km = sc[:, Bn * N + Bn * Tn:].reshape(depth, Bn, 1)
+    rt = torch.ones(depth, Bn, Tn, Sn); rt[:, :, :, 1:] = kt; rt = rt.reshape(depth, -1)
+    want = torch.stack([rt, ks.expand(depth, Bn, Tn, Sn).reshape(depth, -1), km.expand(depth, Bn, Tn * Sn).reshape(depth, -1), rt * mask0[None]])
+    got = ops.droppath_rows(u.cuda(), keep_p.cuda(), mask0.cuda(), Bn, Tn, Sn).cpu()
+    assert torch.equal(got, want)
+    assert 0 < int((got == 0).sum()) < got.numel()

@@ -8,7 +8,8 @@ def calls(path):
     return {n: c for n, c in cur.execute('select name, total_calls from top_kernels').fetchall()}
 
 a, na, b, nb = calls(sys.argv[1]), int(sys.argv[2]), calls(sys.argv[3]), int(sys.argv[4])
-dn = na - nb
+# bench.py runs every step count twice: the timed pass and an untimed pass of the same length with per-launch events (roofline.achieved)
+dn = 2 * (na - nb)
 rows = []
 for k in sorted(set(a) | set(b)):
     d = (a.get(k, 0) - b.get(k, 0)) / dn
@@ -18,7 +19,7 @@ rows.sort(reverse=True)
 tot = sum(r[0] for r in rows)
 ours = sum(r[0] for r in rows if not (r[1].startswith('at::') or 'rocclr' in r[1] or r[1].startswith('void at::')))
 print(f'kernel launches per training step in steady state: {tot:.1f}  (library kernels {ours:.1f}, torch / runtime kernels {tot - ours:.1f})')
-print(f'traces: {na} and {nb} steps of `python3 bench.py --steps K --warmup 2 --no-cpu-baseline --no-parity`, per-step = difference / {dn}')
+print(f'traces: {na} and {nb} steps of `python3 bench.py --steps K --warmup 2 --no-cpu-baseline --no-parity`, per-step = difference / {dn} (timed + untimed event pass)')
 print(f'all launches of the traces: {sum(a.values())} and {sum(b.values())}\n')
 for d, k in rows:
     print(f'{d:7.1f}  {k}')
