@@ -114,12 +114,12 @@ def pmc_traffic():
     """roofline.traffic: HBM bytes per launch of the dominant kernel family from the rocprofv3 --pmc passes of this command (FETCH_SIZE
     with the gfx950 x2 correction + WRITE_SIZE, tools/pmc_bench.sh -> profiles/rNN_pmc_gemm_nt.json).  Counters cannot be read
     inside the timed run, so the committed measurement is used ONLY while it still describes the kernel source that is running: the JSON
-    records the sha256 of gemm_bf16.hip it was taken with; any difference reports null rather than a stale number."""
+    records the sha256 of gemm_bf16.hip + gemm_nt_common.h it was taken with; any difference reports null rather than a stale number."""
     import glob
     import hashlib
     root = os.path.dirname(os.path.abspath(__file__))
-    src = os.path.join(root, 'tcow_amd', 'csrc', 'gemm_bf16.hip')
-    sha = hashlib.sha256(open(src, 'rb').read()).hexdigest() if os.path.exists(src) else None
+    srcs = [os.path.join(root, 'tcow_amd', 'csrc', f) for f in ('gemm_bf16.hip', 'gemm_nt_common.h')]      # the NT kernels: loop + shared epilogue
+    sha = hashlib.sha256(b''.join(open(f, 'rb').read() for f in srcs)).hexdigest() if all(os.path.exists(f) for f in srcs) else None
     for path in sorted(glob.glob(os.path.join(root, 'profiles', 'r*_pmc_gemm_nt.json')), reverse=True):     # newest round first
         rec = json.load(open(path))
         if sha is not None and rec.get('gemm_bf16_sha256') == sha:
@@ -299,6 +299,12 @@ def main():
         step()
     torch.cuda.synchronize()
     timer.end()
+    # host time to enqueue ONE step into an empty stream (the loop above is throttled by the queue depth: the host runs ahead of the GPU)
+    enq = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        te = time.perf_counter(); step(); enq.append((time.perf_counter() - te) * 1e3)
+    torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
     rank_ms = None
@@ -330,7 +336,7 @@ def main():
                                clips_per_gpu=1, num_queries=Qs, parallelism=f'dp{world}', optimizer='AdamW lr 1e-4, clip 0.3',
                                loss='TCOW mask losses (loss.py:238-421): class-balanced BCE + bootstrapped BCE + soft Jaccard on 3 channels'),
                    query_forwards_per_s=clips_per_s * Qs, step_model_tflops=step_tflops, step_mfma_frac=step_tflops / peak,
-                   final_loss=float(loss.detach()), roofline=roof)
+                   final_loss=float(loss.detach()), host_enqueue_ms=round(sorted(enq)[1], 2), roofline=roof)
         if world > 1:
             # what the scaling curve needs to explain itself: how long the compute stream stood still for the gradient all-reduce (rank 0),
             # how much went over xGMI per step in how many collectives, and the spread of the per-rank step times

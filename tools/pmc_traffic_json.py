@@ -34,7 +34,7 @@ for k, (v, c) in fetch.items():
         tag = f'<{m.group(1)},{m.group(2)}>' if m else k[:40]
         per[tag] = dict(fetch_kib=v / c, dispatches=c, write_kib=(write[k][0] / write[k][1] if k in write and write[k][1] else None))
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sha = hashlib.sha256(open(os.path.join(root, 'tcow_amd', 'csrc', 'gemm_bf16.hip'), 'rb').read()).hexdigest()
+sha = hashlib.sha256(b''.join(open(os.path.join(root, 'tcow_amd', 'csrc', f), 'rb').read() for f in ('gemm_bf16.hip', 'gemm_nt_common.h'))).hexdigest()     # (as bench.py pmc_traffic)
 rec = dict(kernel='gemm_nt_bf16_*_kernel (every NT-GEMM launch of the timed steps at M = 27090, dispatch-weighted)',
            command='rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE --kernel-trace -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-parity (tools/pmc_bench.sh)',
            dispatches_fetch=n_f, dispatches_write=n_w, fetch_size_kib_mean=f_nt, write_size_kib_mean=w_nt,
