@@ -32,7 +32,15 @@ def _sel(mode):
     return (L.lib('fp16'), BF16) if mode == FP16 else (L.lib(), mode)
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+_cur_device = getattr(torch._C, '_cuda_getDevice', None)
+
+
 def _stream():
+    """Raw hipStream_t of torch's current stream on the current device.  (torch.cuda.current_stream() builds a Python Stream object through
+    four layers of device-index helpers: 8 us per call, ~430 calls per training step = 3.5 ms of the host's enqueue time.)"""
+    if _raw_stream is not None and _cur_device is not None:
+        return _raw_stream(_cur_device())
     return torch.cuda.current_stream().cuda_stream
 
 
