@@ -72,3 +72,7 @@ build/ubench_glds: tools/ubench_glds.hip
 build/ubench_tn_ab: tools/ubench_tn_ab.hip $(CSRC)/gemm_bf16.hip $(CSRC)/gemm_nt_common.h $(CSRC)/common.h
 	@mkdir -p build
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -Wno-unused-result -x hip $< -o $@
+
+build/ubench_mfma: tools/ubench_mfma.hip
+	@mkdir -p build
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -x hip $< -o $@
