@@ -247,6 +247,10 @@ int tcow_upsample_fwd(void* stream, int B, int T, int C, int h, int w, int st, i
                       float* out);
 int tcow_upsample_bwd(void* stream, int B, int T, int C, int h, int w, int st, int bilinear, const float* dout,
                       float* dpooled);
+/* tcow_upsample_bwd for the bilinear stride-4 head (h, w > 4) that also leaves max |dout| in *amax_bits as a float bit pattern (atomic maximum: the
+ * caller zeroes it) -- the statistic the binary16 mode's power-of-two loss scale is chosen from, taken in the pass that reads dout anyway. */
+int tcow_upsample_bwd_amax(void* stream, int B, int T, int C, int h, int w, int st, const float* dout, float* dpooled,
+                           unsigned* amax_bits);
 int tcow_flags_fwd(void* stream, int BT, int S, int D, int F, const float* x, const float* Wf, const float* bf,
                    float* flags);
 

@@ -96,6 +96,7 @@ SIGNATURES = {
     'tcow_unpatchify_pool_bwd': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'tcow_upsample_fwd': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'tcow_upsample_bwd': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    'tcow_upsample_bwd_amax': (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     'tcow_flags_fwd': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'tcow_droppath_rows': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'tcow_scale_cast': (_i, [_vp, _i, _l, _i, _vp, _l, _vp, _vp, _l]),

@@ -292,9 +292,13 @@ __global__ void upsample_fwd_kernel(int B, int T_, int C, int h, int w, int st, 
     }
 }
 // gather-form backward: one thread per pooled pixel sums the output pixels that read it
-__global__ void upsample_bwd_kernel(int B, int T_, int C, int h, int w, int st, int bilinear, const float* __restrict__ dout, float* __restrict__ dpooled) {
+// amax_bits (may be NULL): atomic maximum of the bit patterns of |dout| over everything the fast path reads = max |dout| (every pixel is read by some
+// window; the maximum is idempotent) -- the statistic the binary16 mode's loss scale needs, without two more passes over dout.
+__global__ void upsample_bwd_kernel(int B, int T_, int C, int h, int w, int st, int bilinear, const float* __restrict__ dout, float* __restrict__ dpooled,
+                                    unsigned* __restrict__ amax_bits) {
     const int H = h * st, W = w * st;
     const long total = (long)B * T_ * C * h * w;
+    float amax = 0.f;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int X = (int)(i % w); const int Y = (int)((i / w) % h); const int c = (int)((i / ((long)w * h)) % C); const long bt = i / ((long)w * h * C);
         const int b = (int)(bt / T_), t = (int)(bt - (long)b * T_);
@@ -325,6 +329,7 @@ __global__ void upsample_bwd_kernel(int B, int T_, int C, int h, int w, int st, 
                     if (xa + 4 * q >= 0 && xa + 4 * q + 3 < W) {
                         const float4 v = ld4(row + 4 * q);
                         r += wx[4 * q] * v.x + wx[4 * q + 1] * v.y + wx[4 * q + 2] * v.z + wx[4 * q + 3] * v.w;
+                        if (amax_bits && q == 1) amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));   // (columns 4X .. 4X+3: each pixel once per row window)
                     }
                 }
                 a += wy * r;
@@ -353,6 +358,10 @@ __global__ void upsample_bwd_kernel(int B, int T_, int C, int h, int w, int st, 
                 for (int dx = 0; dx < st; ++dx) a += g[(size_t)(Y * st + dy) * W + X * st + dx];
         }
         dpooled[i] = a;
+    }
+    if (amax_bits) {
+        for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+        if ((threadIdx.x & 63) == 0 && amax > 0.f) atomicMax(amax_bits, __builtin_bit_cast(unsigned, amax));      // (non-negative floats order as their bit patterns)
     }
 }
 
@@ -619,7 +628,14 @@ int tcow_upsample_fwd(void* stream, int B, int T_, int C, int h, int w, int st, 
 
 int tcow_upsample_bwd(void* stream, int B, int T_, int C, int h, int w, int st, int bilinear, const float* dout, float* dpooled) {
     TCOW_CHECK_ARG(B > 0 && T_ > 0 && C > 0 && h > 0 && w > 0 && st > 0 && dout && dpooled, "tcow_upsample_bwd: bad arguments");
-    hipLaunchKernelGGL(upsample_bwd_kernel, dim3(gs_blocks((long)B * C * T_ * h * w)), dim3(256), 0, (hipStream_t)stream, B, T_, C, h, w, st, bilinear, dout, dpooled);
+    hipLaunchKernelGGL(upsample_bwd_kernel, dim3(gs_blocks((long)B * C * T_ * h * w)), dim3(256), 0, (hipStream_t)stream, B, T_, C, h, w, st, bilinear, dout, dpooled, (unsigned*)nullptr);
+    TCOW_CHECK_LAUNCH();
+    return TCOW_OK;
+}
+
+int tcow_upsample_bwd_amax(void* stream, int B, int T_, int C, int h, int w, int st, const float* dout, float* dpooled, unsigned* amax_bits) {
+    TCOW_CHECK_ARG(B > 0 && T_ > 0 && C > 0 && h > 4 && w > 4 && st == 4 && dout && dpooled && amax_bits, "tcow_upsample_bwd_amax: bilinear stride 4 with h, w > 4 only");
+    hipLaunchKernelGGL(upsample_bwd_kernel, dim3(gs_blocks((long)B * C * T_ * h * w)), dim3(256), 0, (hipStream_t)stream, B, T_, C, h, w, st, 1, dout, dpooled, amax_bits);
     TCOW_CHECK_LAUNCH();
     return TCOW_OK;
 }

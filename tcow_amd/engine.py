@@ -467,26 +467,32 @@ def run_backward(module, sv, params, d_mask, d_flags):
     # times the seed maximum (median 240), i.e. at <= 6 000 of binary16's 65 504, with their median near 1e-3 (normal range).  An overflow
     # all the same shows up as a non-finite gradient norm: FusedAdamWClip then skips the update and lowers t by 4 (optim.py).
     # A number instead of 'dynamic' = static scale.
+    # binary16: the backward runs on gradients multiplied by a power of two (exact), chosen from max |seed gradient| so that the seed's largest
+    # entry lands on 2^ls_log2.  The mask head's first two steps (bilinear x4 adjoint, un-patchify) are f32 and linear, so the scale is applied to
+    # the POOLED gradient (5 MB) behind them, not to d_mask (83 MB) -- bit-identical, a power of two commutes with the sums -- and max |d_mask| comes
+    # out of the adjoint's own pass over d_mask (tcow_upsample_bwd_amax) instead of an abs + amax pair of passes.
     gscale = inv_gscale = None
-    if mode == ops.FP16:
-        ls = getattr(module, 'loss_scale', 'dynamic')
-        if ls == 'dynamic':
-            amax = torch.zeros((), dtype=f32, device=dev)
-            for t in (d_mask, d_flags):
-                if t is not None and t.numel():
-                    amax = torch.maximum(amax, t.detach().abs().amax().to(f32))
-            if not module.__dict__.get('_optim_attached') and not module.__dict__.get('_warned_ls'):
-                import warnings
-                module.__dict__['_warned_ls'] = True
-                warnings.warn("precision='fp16' with the dynamic loss scale but no FusedAdamWClip(..., module=net) attached: nothing lowers the scale "
-                              "after an overflow or skips the poisoned step -- pass module= to the optimizer or set net.seeker.loss_scale to a number")
-            gscale = torch.exp2(torch.floor(module.ls_log2 - torch.log2(amax.clamp_min(1e-37)))).clamp(2.0 ** -20, 2.0 ** 60)     # no host sync
-        elif float(ls) != 1.0:
-            gscale = torch.tensor(float(ls), dtype=f32, device=dev)
-        if gscale is not None:
-            inv_gscale = 1.0 / gscale
-            d_mask = None if d_mask is None else d_mask * gscale
-            d_flags = None if d_flags is None else d_flags * gscale
+    ls_mode = getattr(module, 'loss_scale', 'dynamic') if mode == ops.FP16 else None
+    if ls_mode == 'dynamic' and not module.__dict__.get('_optim_attached') and not module.__dict__.get('_warned_ls'):
+        import warnings
+        module.__dict__['_warned_ls'] = True
+        warnings.warn("precision='fp16' with the dynamic loss scale but no FusedAdamWClip(..., module=net) attached: nothing lowers the scale "
+                      "after an overflow or skips the poisoned step -- pass module= to the optimizer or set net.seeker.loss_scale to a number")
+
+    def choose_scale(mask_amax):
+        """-> (gscale, 1 / gscale) device scalars or (None, None); mask_amax = max |d_mask| (device scalar or None)."""
+        if ls_mode is None:
+            return None, None
+        if ls_mode == 'dynamic':
+            amax = mask_amax if mask_amax is not None else torch.zeros((), dtype=f32, device=dev)
+            if d_flags is not None and d_flags.numel():
+                amax = torch.maximum(amax, d_flags.detach().abs().amax().to(f32))
+            gs = torch.exp2(torch.floor(module.ls_log2 - torch.log2(amax.clamp_min(1e-37)))).clamp(2.0 ** -20, 2.0 ** 60)     # no host sync
+        elif float(ls_mode) != 1.0:
+            gs = torch.tensor(float(ls_mode), dtype=f32, device=dev)
+        else:
+            return None, None
+        return gs, 1.0 / gs
 
     def E(*shape, dtype=dt):
         return torch.empty(*shape, dtype=dtype, device=dev)
@@ -598,7 +604,17 @@ def run_backward(module, sv, params, d_mask, d_flags):
         d_mask = torch.zeros(B, Co, T, module.frame_height, module.frame_width, dtype=f32, device=dev)
     d_mask = d_mask.to(f32).contiguous()
     dpooled = E(B * T, Co, sv['h'], sv['w'], dtype=f32)
-    ops.upsample_bwd(d_mask, B, T, Co, sv['h'], sv['w'], sv['stp'], sv['bilinear'], dpooled)
+    mask_amax = None
+    if ls_mode == 'dynamic' and sv['bilinear'] and sv['stp'] == 4 and sv['h'] > 4 and sv['w'] > 4:
+        _, mask_amax = ops.upsample_bwd_amax(d_mask, B, T, Co, sv['h'], sv['w'], sv['stp'], dpooled)
+    else:
+        if ls_mode == 'dynamic' and d_mask.numel():
+            mask_amax = d_mask.abs().amax()
+        ops.upsample_bwd(d_mask, B, T, Co, sv['h'], sv['w'], sv['stp'], sv['bilinear'], dpooled)
+    gscale, inv_gscale = choose_scale(mask_amax)
+    if gscale is not None:
+        dpooled.mul_(gscale)
+        d_flags = None if d_flags is None else d_flags * gscale
     dPm = E(M, Co * P * P)
     ops.unpatchify_pool_bwd(mode, dpooled, B * T, g['Hp'], g['Wp'], P, Co, sv['stp'], dPm)
     linear_bwd(nb + 2, dPm, sv['Fm'])

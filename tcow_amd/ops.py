@@ -275,6 +275,13 @@ def upsample_bwd(dout, B, T, C, h, w, st, bilinear, dpooled):
     return dpooled
 
 
+def upsample_bwd_amax(dout, B, T, C, h, w, st, dpooled):
+    """upsample_bwd (bilinear, stride 4, h, w > 4) that also returns max |dout| as a 0-dim f32 device tensor (see tcow_upsample_bwd_amax)."""
+    bits = torch.zeros(1, dtype=torch.int32, device=dout.device)
+    L.check(L.lib().tcow_upsample_bwd_amax(_stream(), B, T, C, h, w, st, dout.data_ptr(), dpooled.data_ptr(), bits.data_ptr()), 'tcow_upsample_bwd_amax')
+    return dpooled, bits.view(torch.float32)[0]
+
+
 def flags_fwd(x, BT, S, Wf, bf, flags):
     L.check(L.lib().tcow_flags_fwd(_stream(), BT, S, x.shape[1], Wf.shape[0], x.data_ptr(), Wf.data_ptr(), bf.data_ptr(), flags.data_ptr()), 'tcow_flags_fwd')
     return flags

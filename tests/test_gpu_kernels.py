@@ -401,6 +401,9 @@ def test_mask_head_pool_upsample(ops, cuda, st, bilinear):
     (up * gout.permute(0, 2, 1, 3, 4).reshape_as(up).double()).sum().backward()
     dpooled = torch.empty_like(pooled)
     ops.upsample_bwd(gout, B, T, C, Hp * P // st, Wp * P // st, st, bilinear and st > 1, dpooled)
+    if st == 4 and bilinear:          # the variant that also returns max |dout| (the binary16 mode's loss-scale statistic): same gradient, exact maximum
+        dp2, amax = ops.upsample_bwd_amax(gout, B, T, C, Hp * P // st, Wp * P // st, st, torch.empty_like(pooled))
+        assert torch.equal(dp2, dpooled) and float(amax) == float(gout.abs().max())
     dpm = torch.empty_like(pm)
     ops.unpatchify_pool_bwd(ops.F32, dpooled, B * T, Hp, Wp, P, C, st, dpm)
     gx = xf.grad.reshape(B, T, C, Hp, P, Wp, P).permute(0, 1, 3, 5, 2, 4, 6).reshape(B, T, Hp * Wp, C * P * P)
