@@ -149,6 +149,10 @@ __device__ __forceinline__ float4 ldnt4(const float* p) {
     const f32x4_nt v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(p));
     return make_float4(v[0], v[1], v[2], v[3]);
 }
+// (measured equal: non-temporal vs plain loads, one vs two float4 columns per thread, 64-bit vs 32-bit row / column split: the launch moves its
+// 198-226 MB at 4.1-4.4 TB/s either way)
+#define FOLD_LD ld4
+#define FOLD_BLK 512
 struct FoldJob { const float* slab; long slab_stride, n4, cols4, ldo; float* out; const float* part; float* bias_out; int nz, accumulate, slab_blocks, nparts, N, blocks; };
 struct FoldGroup { int n; int first[9]; FoldJob j[8]; };
 __global__ __launch_bounds__(256) void slab_reduce4_group_kernel(FoldGroup g) {
@@ -172,8 +176,8 @@ __global__ __launch_bounds__(256) void slab_reduce4_group_kernel(FoldGroup g) {
         }
         return;
     }
-    const long i0 = (long)bx * 512 + tid, i1 = i0 + 256;
-    const bool ok0 = i0 < j.n4, ok1 = i1 < j.n4;
+    const long i0 = (long)bx * FOLD_BLK + tid, i1 = i0 + 256;
+    const bool ok0 = i0 < j.n4, ok1 = FOLD_BLK > 256 && i1 < j.n4;
     const int nz = j.nz;
     float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
     for (int z0 = 0; z0 < nz; z0 += 8) {
@@ -182,8 +186,8 @@ __global__ __launch_bounds__(256) void slab_reduce4_group_kernel(FoldGroup g) {
         for (int u = 0; u < 8; ++u) {
             if (z0 + u < nz) {                  // (uniform: no load is issued for an absent slice)
                 const float* b = j.slab + (size_t)(z0 + u) * j.slab_stride;
-                v0[u] = ok0 ? ldnt4(b + i0 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-                v1[u] = ok1 ? ldnt4(b + i1 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                v0[u] = ok0 ? FOLD_LD(b + i0 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                v1[u] = ok1 ? FOLD_LD(b + i1 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
             } else {
                 v0[u] = make_float4(0.f, 0.f, 0.f, 0.f); v1[u] = v0[u];
             }
@@ -194,15 +198,17 @@ __global__ __launch_bounds__(256) void slab_reduce4_group_kernel(FoldGroup g) {
             s1.x += v1[u].x; s1.y += v1[u].y; s1.z += v1[u].z; s1.w += v1[u].w;
         }
     }
+    // (dense outputs need no row / column split; otherwise 32-bit division: the 64-bit one is ~100 instructions, twice per thread = 9 us of a 49 us launch)
+    const bool dense = j.ldo == j.cols4 * 4;
     if (ok0) {
-        const long r = i0 / j.cols4, c = (i0 - r * j.cols4) * 4;
-        float* o = j.out + r * j.ldo + c;
+        const unsigned r = dense ? 0u : (unsigned)i0 / (unsigned)j.cols4;
+        float* o = dense ? j.out + i0 * 4 : j.out + (long)r * j.ldo + ((unsigned)i0 - r * (unsigned)j.cols4) * 4;
         if (j.accumulate) { const float4 p = ld4(o); s0.x += p.x; s0.y += p.y; s0.z += p.z; s0.w += p.w; }
         st4(o, s0);
     }
     if (ok1) {
-        const long r = i1 / j.cols4, c = (i1 - r * j.cols4) * 4;
-        float* o = j.out + r * j.ldo + c;
+        const unsigned r = dense ? 0u : (unsigned)i1 / (unsigned)j.cols4;
+        float* o = dense ? j.out + i1 * 4 : j.out + (long)r * j.ldo + ((unsigned)i1 - r * (unsigned)j.cols4) * 4;
         if (j.accumulate) { const float4 p = ld4(o); s1.x += p.x; s1.y += p.y; s1.z += p.z; s1.w += p.w; }
         st4(o, s1);
     }
@@ -322,7 +328,7 @@ int tcow_launch_slab_reduce_group(hipStream_t stream, int n, const float* const*
         const long nel = rows[i] * cols[i];
         j.slab = slab[i]; j.slab_stride = nel; j.n4 = nel / 4; j.cols4 = cols[i] / 4; j.ldo = ldo[i]; j.out = out[i];
         j.part = bias_part[i]; j.bias_out = bias_out[i]; j.nz = nz; j.accumulate = accumulate[i];
-        j.slab_blocks = (int)cdiv(nel / 4, 512); j.nparts = bias_nparts[i]; j.N = (int)rows[i];
+        j.slab_blocks = (int)cdiv(nel / 4, FOLD_BLK); j.nparts = bias_nparts[i]; j.N = (int)rows[i];
         j.blocks = j.slab_blocks + (bias_part[i] ? cdiv(rows[i], 16) : 0);
         g.first[i] = first;
         first += j.blocks;
