@@ -909,15 +909,18 @@ __global__ __launch_bounds__(640) void attn_bwd_one_kernel(SeqDesc sd, int nt, c
     const int key = 32 * wave + l31;
     // dQ phase (waves 0-7): output block = queries 16 qb .. +15 x channels 16 db .. +15 of the step's tile, as dQ^T (lane: query l & 15,
     // channels 16 db + 4 (l >> 4) .. + 3).  Transpose-read addressing: in its 16-lane group lane 4 r + c supplies row r / 4-element quad c.
-    const int qb = (wave >> 2) & 1, db = wave & 3;
+    // (the chains run on waves 2, 3, 6, 7 -- the two SIMDs that host two key-tile waves, not three: SIMD w % 4 -- each with BOTH query halves of one
+    // channel block: the K fragments are read once for two independent accumulate chains)
+    const bool dq_wave = wave < 8 && (wave & 2);
+    const int db = (wave & 1) | ((wave >> 1) & 2);
     const int g4 = lane >> 4, tr = (lane & 15) >> 2, tc = lane & 3;
     const int krow = 8 * g4 + tr;                                                        // key row inside a 32-key tile (second read: + 4)
     const int kchunk = 2 * db + (tc >> 1);
     const uint32_t lds0 = (uint32_t)(uintptr_t)(LDS_PTR(char))smem;
     const uint32_t ka0 = lds0 + ONE_K + krow * 128 + ((kchunk ^ swz_g(krow)) << 4) + (tc & 1) * 8;
     const uint32_t ka1 = lds0 + ONE_K + (krow + 4) * 128 + ((kchunk ^ swz_g(krow + 4)) << 4) + (tc & 1) * 8;
-    const uint32_t sa0 = lds0 + ONE_STRIP + krow * 64 + (((4 * qb + tc) ^ (krow & 7)) << 3);
-    const uint32_t sa1 = lds0 + ONE_STRIP + (krow + 4) * 64 + (((4 * qb + tc) ^ ((krow + 4) & 7)) << 3);
+    const uint32_t sa0 = lds0 + ONE_STRIP + krow * 64 + ((tc ^ (krow & 7)) << 3);               // query half 0; half 1 = slot ^ 4 = address ^ 32
+    const uint32_t sa1 = lds0 + ONE_STRIP + (krow + 4) * 64 + ((tc ^ ((krow + 4) & 7)) << 3);
     // strip write of this wave's dS block: lane (key l31, hi) holds queries 4 hi + {0..3}, 8 + .., 16 + .., 24 + ..: four 8-byte quads (slots
     // hi, 2 + hi, 4 + hi, 6 + hi of the key's 64-byte row; slot s of key row k sits at s ^ (k & 7))
     const uint32_t sw = lds0 + ONE_STRIP + (32 * wave + l31) * 64;
@@ -946,42 +949,51 @@ __global__ __launch_bounds__(640) void attn_bwd_one_kernel(SeqDesc sd, int nt, c
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();
         if (i + 2 < nt) load_qdo(i + 2, buf);
-        if (wave < 8) {
-            // dQ^T block of step i: a chain of nt 16x16x32 MFMAs over all key tiles; the four transpose reads of key tile kt+1 are requested
-            // before the MFMA of key tile kt (two register sets, counted lgkmcnt).  The bf16 block goes to the step's staging tile
-            // ([32 q][64 d], 16-byte chunk c of row q at position c ^ (q & 7)); waves 8 / 9 write it out as whole rows one step later.
+        if (dq_wave) {
+            // dQ^T blocks of step i (channels 16 db .. + 15, both query halves): two chains of nt 16x16x32 MFMAs over all key tiles; the six transpose
+            // reads of key tile kt+2 are requested before the MFMAs of key tile kt (three register sets, counted lgkmcnt).  The bf16 blocks go to the
+            // step's staging tile ([32 q][64 d], 16-byte chunk c of row q at position c ^ (q & 7)); waves 8 / 9 write it out as whole rows one step later.
             typedef uint32_t u32x2_ __attribute__((ext_vector_type(2)));
             typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
             const uint32_t so = buf * ONE_STRIP_B;
-            u32x2_ fr[3][4];
+            u32x2_ fr[3][6];
 #define ONE_RD(set, kt_)                                                                                               \
             do {                                                                                                       \
                 asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(fr[set][0]) : "v"(ka0 + (kt_) * TILE_B));              \
                 asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(fr[set][1]) : "v"(ka1 + (kt_) * TILE_B));              \
                 asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(fr[set][2]) : "v"(sa0 + so + (kt_) * 2048));           \
                 asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(fr[set][3]) : "v"(sa1 + so + (kt_) * 2048));           \
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(fr[set][4]) : "v"((sa0 ^ 32u) + so + (kt_) * 2048));   \
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(fr[set][5]) : "v"((sa1 ^ 32u) + so + (kt_) * 2048));   \
             } while (0)
 #define ONE_MF(set)                                                                                                    \
-            acc = TCOW_MFMA_16x16x32_H16(__builtin_bit_cast(bf16x8, (u32x4_){fr[set][0].x, fr[set][0].y, fr[set][1].x, fr[set][1].y}), \
-                                         __builtin_bit_cast(bf16x8, (u32x4_){fr[set][2].x, fr[set][2].y, fr[set][3].x, fr[set][3].y}), acc, 0, 0, 0)
-#define ONE_WAIT(set, n) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(fr[set][0]), "+v"(fr[set][1]), "+v"(fr[set][2]), "+v"(fr[set][3]) :: "memory")
+            do {                                                                                                       \
+                const bf16x8 kfr = __builtin_bit_cast(bf16x8, (u32x4_){fr[set][0].x, fr[set][0].y, fr[set][1].x, fr[set][1].y}); \
+                acc0 = TCOW_MFMA_16x16x32_H16(kfr, __builtin_bit_cast(bf16x8, (u32x4_){fr[set][2].x, fr[set][2].y, fr[set][3].x, fr[set][3].y}), acc0, 0, 0, 0); \
+                acc1 = TCOW_MFMA_16x16x32_H16(kfr, __builtin_bit_cast(bf16x8, (u32x4_){fr[set][4].x, fr[set][4].y, fr[set][5].x, fr[set][5].y}), acc1, 0, 0, 0); \
+            } while (0)
+#define ONE_WAIT(set, n) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(fr[set][0]), "+v"(fr[set][1]), "+v"(fr[set][2]), "+v"(fr[set][3]), "+v"(fr[set][4]), "+v"(fr[set][5]) :: "memory")
             // (reads of key tiles past nt - 1 land in the neighbouring LDS regions: harmless, their MFMAs are skipped)
             ONE_RD(0, 0); ONE_RD(1, 1);
             for (int kt = 0; kt < nt; kt += 3) {
-                ONE_RD(2, kt + 2); ONE_WAIT(0, 8); ONE_MF(0);
-                if (kt + 1 < nt) { ONE_RD(0, kt + 3); ONE_WAIT(1, 8); ONE_MF(1); }
-                if (kt + 2 < nt) { ONE_RD(1, kt + 4); ONE_WAIT(2, 8); ONE_MF(2); }
+                ONE_RD(2, kt + 2); ONE_WAIT(0, 12); ONE_MF(0);
+                if (kt + 1 < nt) { ONE_RD(0, kt + 3); ONE_WAIT(1, 12); ONE_MF(1); }
+                if (kt + 2 < nt) { ONE_RD(1, kt + 4); ONE_WAIT(2, 12); ONE_MF(2); }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #undef ONE_WAIT
 #undef ONE_RD
 #undef ONE_MF
-            const int ql = 16 * qb + (lane & 15);                       // row of the staging tile; channels 16 db + 4 g4 .. + 3 = 8-byte slot 4 db + g4
-            const uint32_t da = lds0 + ONE_DQ + buf * TILE_B + ql * 128 + ((((4 * db + g4) >> 1) ^ (ql & 7)) << 4) + ((g4 & 1) << 3);
-            const u32x2_ pk = {pack_bf2(acc[0] * kScale, acc[1] * kScale), pack_bf2(acc[2] * kScale, acc[3] * kScale)};
-            asm volatile("ds_write_b64 %0, %1" :: "v"(da), "v"(pk) : "memory");
-        } else if (i > 0) {
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                const f32x4 acc = qb ? acc1 : acc0;
+                const int ql = 16 * qb + (lane & 15);                   // row of the staging tile; channels 16 db + 4 g4 .. + 3 = 8-byte slot 4 db + g4
+                const uint32_t da = lds0 + ONE_DQ + buf * TILE_B + ql * 128 + ((((4 * db + g4) >> 1) ^ (ql & 7)) << 4) + ((g4 & 1) << 3);
+                const u32x2_ pk = {pack_bf2(acc[0] * kScale, acc[1] * kScale), pack_bf2(acc[2] * kScale, acc[3] * kScale)};
+                asm volatile("ds_write_b64 %0, %1" :: "v"(da), "v"(pk) : "memory");
+            }
+        } else if (wave >= 8 && i > 0) {
             // the finished dQ tile of step i-1 (complete since this step's barrier) goes out as whole 128-byte rows: wave 8 rows 0-15, wave 9 rows 16-31
             typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
             const uint32_t st0 = lds0 + ONE_DQ + ((i - 1) & 1) * TILE_B;
