@@ -423,10 +423,17 @@ __device__ __forceinline__ void dkv_tile(const SeqDesc& sd, const char* qtile, c
     const bool need_mask = (32 * i + 31 >= sd.L) || (key - l31 + 31 >= sd.L) || ((long)(key - l31) + 31 > (long)32 * i + sd.diag);
     if (need_mask) {
         TCOW_NO_IFCVT();
+        if ((32 * i + 31 < sd.L) && ((long)(key - l31) + 31 <= (long)32 * i + sd.diag)) {
+            // only key padding (the last key tile of a sequence, every step of its wave): one lane-constant test instead of three per element
+            const bool kv = key < sd.L;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int q = 32 * i + crow32(r, hi);
-            if (!(q < sd.L && key < sd.L && (long)key <= (long)q + sd.diag)) s[r] = -1e30f;
+            for (int r = 0; r < 16; ++r) s[r] = kv ? s[r] : -1e30f;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int q = 32 * i + crow32(r, hi);
+                if (!(q < sd.L && key < sd.L && (long)key <= (long)q + sd.diag)) s[r] = -1e30f;
+            }
         }
     }
     float pv[16], dsv[16];
@@ -851,7 +858,7 @@ constexpr int ONE_K = 0, ONE_V = ONE_MAX_NT * TILE_B, ONE_QDO = 2 * ONE_MAX_NT *
 constexpr int ONE_STRIP_B = ONE_MAX_NT * 32 * 64;                       // [320 keys][32 queries] bf16
 constexpr int ONE_TAB = ONE_STRIP + 2 * ONE_STRIP_B, ONE_DQ = ONE_TAB + ONE_MAX_NT * 32 * 8, ONE_LDS = ONE_DQ + 2 * TILE_B;      // + two dQ staging tiles
 
-__global__ __launch_bounds__(640) void attn_bwd_one_kernel(SeqDesc sd, int nt, const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
+__global__ __launch_bounds__(768) void attn_bwd_one_kernel(SeqDesc sd, int nt, const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
                                                            const float* __restrict__ lse, bf16_t* __restrict__ dqkv) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -867,6 +874,12 @@ __global__ __launch_bounds__(640) void attn_bwd_one_kernel(SeqDesc sd, int nt, c
     char* ktiles = smem + ONE_K; char* vtiles = smem + ONE_V;
     float2* tab = reinterpret_cast<float2*>(smem + ONE_TAB);
     const bool owner = wave < nt;
+#ifdef UBENCH_ATTN          // phase stamps of tools/ubench_valu.hip (part F): compiled into the micro-benchmark only
+#define ONE_STAMP(i) do { if (g_attn_dbg && lane == 0) g_attn_dbg[((long)blockIdx.x * 12 + wave) * 40 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define ONE_STAMP(i) do { } while (0)
+#endif
+    ONE_STAMP(0);
     // ---- prologue: K_w / V_w tiles, the first two Q / dO tiles (a 1 KiB quarter per wave 0-7), the (lse, delta) table of query tile w
     if (owner) {
         load_tile(qh + sd.D, pse, 32 * wave, sd.L, ktiles + wave * TILE_B, lane);
@@ -902,6 +915,7 @@ __global__ __launch_bounds__(640) void attn_bwd_one_kernel(SeqDesc sd, int nt, c
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
+    ONE_STAMP(1);
 
     f32x16 dk0, dk1, dv0, dv1;
 #pragma unroll
@@ -909,22 +923,114 @@ __global__ __launch_bounds__(640) void attn_bwd_one_kernel(SeqDesc sd, int nt, c
     const int key = 32 * wave + l31;
     // dQ phase (waves 0-7): output block = queries 16 qb .. +15 x channels 16 db .. +15 of the step's tile, as dQ^T (lane: query l & 15,
     // channels 16 db + 4 (l >> 4) .. + 3).  Transpose-read addressing: in its 16-lane group lane 4 r + c supplies row r / 4-element quad c.
-    // (the chains run on waves 2, 3, 6, 7 -- the two SIMDs that host two key-tile waves, not three: SIMD w % 4 -- each with BOTH query halves of one
-    // channel block: the K fragments are read once for two independent accumulate chains)
-    const bool dq_wave = wave < 8 && (wave & 2);
-    const int db = (wave & 1) | ((wave >> 1) & 2);
-    const int g4 = lane >> 4, tr = (lane & 15) >> 2, tc = lane & 3;
-    const int krow = 8 * g4 + tr;                                                        // key row inside a 32-key tile (second read: + 4)
-    const int kchunk = 2 * db + (tc >> 1);
+    // dQ phase: TWO MORE WAVES (10, 11 -- they land on the two SIMDs that host two key-tile waves, wave w sits on SIMD w % 4) do nothing else: behind
+    // the barrier of step i they turn the strip into dQ_i^T while waves 0-9 are already in step i+1 -- the chains no longer sit between two tile
+    // steps of the same wave (timeline in profiles/r04_ubench_valu.txt part F: a step cost tile arithmetic 2 700 + chains 2 600 + barrier wait).
+    // Chain wave c = wave - 10 owns channel blocks 2c, 2c + 1 (16 channels each) x both query halves: four independent accumulate chains of nt
+    // 16x16x32 MFMAs over all key tiles; K and strip fragments by transpose reads (in its 16-lane group lane 4 r + q supplies row r / quad q).
+    // Output lane: query l & 15 (+ 16 for the second half), channels 16 db + 4 (l >> 4) .. + 3.
+    const bool chain_wave = wave >= 10;
+    const int cw = wave - 10;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(LDS_PTR(char))smem;
-    const uint32_t ka0 = lds0 + ONE_K + krow * 128 + ((kchunk ^ swz_g(krow)) << 4) + (tc & 1) * 8;
-    const uint32_t ka1 = lds0 + ONE_K + (krow + 4) * 128 + ((kchunk ^ swz_g(krow + 4)) << 4) + (tc & 1) * 8;
-    const uint32_t sa0 = lds0 + ONE_STRIP + krow * 64 + ((tc ^ (krow & 7)) << 3);               // query half 0; half 1 = slot ^ 4 = address ^ 32
-    const uint32_t sa1 = lds0 + ONE_STRIP + (krow + 4) * 64 + ((tc ^ ((krow + 4) & 7)) << 3);
     // strip write of this wave's dS block: lane (key l31, hi) holds queries 4 hi + {0..3}, 8 + .., 16 + .., 24 + ..: four 8-byte quads (slots
     // hi, 2 + hi, 4 + hi, 6 + hi of the key's 64-byte row; slot s of key row k sits at s ^ (k & 7))
     const uint32_t sw = lds0 + ONE_STRIP + (32 * wave + l31) * 64;
     const int k7 = l31 & 7;
+
+    if (chain_wave) {
+        // ---- the chain waves' own loop (a separate one: their 80 registers of K^T fragments must not be live across the tile-step code)
+        typedef uint32_t u32x2_ __attribute__((ext_vector_type(2)));
+        typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
+        const int g4 = lane >> 4, tr = (lane & 15) >> 2, tc = lane & 3;
+        const int krow = 8 * g4 + tr;                                                        // key row inside a 32-key tile (second read: + 4)
+        const int kchunk = 4 * cw + (tc >> 1);                                               // channel block 2 cw; block 2 cw + 1 = chunk + 2 = offset ^ 32
+        const uint32_t ko0 = ONE_K + krow * 128 + ((kchunk ^ swz_g(krow)) << 4) + (tc & 1) * 8, ko1 = ONE_K + (krow + 4) * 128 + ((kchunk ^ swz_g(krow + 4)) << 4) + (tc & 1) * 8;
+        const uint32_t so0 = ONE_STRIP + krow * 64 + ((tc ^ (krow & 7)) << 3);               // query half 0; half 1 = slot ^ 4 = offset ^ 32
+        const uint32_t so1 = ONE_STRIP + (krow + 4) * 64 + ((tc ^ ((krow + 4) & 7)) << 3);
+        // K^T fragments of ALL key tiles, once: they are the same in every step (80 registers the tile-step waves do not have to spare)
+        u32x2_ kfr[ONE_MAX_NT][4];
+#pragma unroll
+        for (int kt = 0; kt < ONE_MAX_NT; ++kt) {
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(kfr[kt][0]) : "v"(lds0 + ko0 + kt * TILE_B));
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(kfr[kt][1]) : "v"(lds0 + ko1 + kt * TILE_B));
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(kfr[kt][2]) : "v"(lds0 + (ko0 ^ 32u) + kt * TILE_B));
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(kfr[kt][3]) : "v"(lds0 + (ko1 ^ 32u) + kt * TILE_B));
+            if ((kt & 1) == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const uint32_t stg = lds0 + ONE_DQ + cw * TILE_B;
+        for (int i = 0; i < nt; ++i) {
+            const int buf = i & 1;
+            ONE_STAMP(2 + 3 * i);
+            __syncthreads();                                            // barrier of step i: the strip of step i is complete
+            ONE_STAMP(3 + 3 * i);
+            f32x4 acc[2][2];                                            // [channel block][query half]
+#pragma unroll
+            for (int a_ = 0; a_ < 2; ++a_)
+#pragma unroll
+                for (int b_ = 0; b_ < 2; ++b_) acc[a_][b_] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const uint32_t sa0 = lds0 + so0 + buf * ONE_STRIP_B, sa1 = lds0 + so1 + buf * ONE_STRIP_B;
+            const uint32_t sb0 = lds0 + (so0 ^ 32u) + buf * ONE_STRIP_B, sb1 = lds0 + (so1 ^ 32u) + buf * ONE_STRIP_B;
+            u32x2_ fr[3][4];                                            // per set: strip half 0 (2 reads), half 1 (2)
+#define ONE_RD(set, kt_)                                                                                               \
+            do {                                                                                                       \
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(fr[set][0]) : "v"(sa0 + (kt_) * 2048));                \
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(fr[set][1]) : "v"(sa1 + (kt_) * 2048));                \
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(fr[set][2]) : "v"(sb0 + (kt_) * 2048));                \
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(fr[set][3]) : "v"(sb1 + (kt_) * 2048));                \
+            } while (0)
+#define ONE_KF(kt_, j) __builtin_bit_cast(bf16x8, (u32x4_){kfr[kt_][2 * (j)].x, kfr[kt_][2 * (j)].y, kfr[kt_][2 * (j) + 1].x, kfr[kt_][2 * (j) + 1].y})
+#define ONE_SF(set, j) __builtin_bit_cast(bf16x8, (u32x4_){fr[set][2 * (j)].x, fr[set][2 * (j)].y, fr[set][2 * (j) + 1].x, fr[set][2 * (j) + 1].y})
+#define ONE_MF(set, kt_)                                                                                               \
+            do {                                                                                                       \
+                acc[0][0] = TCOW_MFMA_16x16x32_H16(ONE_KF(kt_, 0), ONE_SF(set, 0), acc[0][0], 0, 0, 0);                \
+                acc[1][0] = TCOW_MFMA_16x16x32_H16(ONE_KF(kt_, 1), ONE_SF(set, 0), acc[1][0], 0, 0, 0);                \
+                acc[0][1] = TCOW_MFMA_16x16x32_H16(ONE_KF(kt_, 0), ONE_SF(set, 1), acc[0][1], 0, 0, 0);                \
+                acc[1][1] = TCOW_MFMA_16x16x32_H16(ONE_KF(kt_, 1), ONE_SF(set, 1), acc[1][1], 0, 0, 0);                \
+            } while (0)
+#define ONE_WAIT(set, n) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(fr[set][0]), "+v"(fr[set][1]), "+v"(fr[set][2]), "+v"(fr[set][3]) :: "memory")
+            // (fully unrolled over the ten key tiles: the K fragments are register arrays; tiles past nt - 1 are skipped)
+            ONE_RD(0, 0); ONE_RD(1, 1);
+#pragma unroll
+            for (int kt = 0; kt < ONE_MAX_NT; ++kt) {
+                if (kt < nt) {
+                    if (kt % 3 == 0) { ONE_RD(2, kt + 2); ONE_WAIT(0, 8); ONE_MF(0, kt); }
+                    else if (kt % 3 == 1) { ONE_RD(0, kt + 2); ONE_WAIT(1, 8); ONE_MF(1, kt); }
+                    else { ONE_RD(1, kt + 2); ONE_WAIT(2, 8); ONE_MF(2, kt); }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#undef ONE_WAIT
+#undef ONE_RD
+#undef ONE_MF
+#undef ONE_KF
+#undef ONE_SF
+            // the wave's half of the dQ tile ([32 q][channels 32 cw .. + 31]) through its PRIVATE staging tile (a wave's LDS operations complete in
+            // order: no barrier), then out as 64-byte row pieces: 16-byte chunk c of row q sits at position c ^ (q & 7) of the row's 128 bytes
+#pragma unroll
+            for (int a_ = 0; a_ < 2; ++a_)
+#pragma unroll
+                for (int b_ = 0; b_ < 2; ++b_) {
+                    const int ql = 16 * b_ + (lane & 15), slot = 4 * (2 * cw + a_) + g4;      // 8-byte slot of the row: channels 4 slot .. + 3
+                    const uint32_t da = stg + ql * 128 + (((slot >> 1) ^ (ql & 7)) << 4) + ((slot & 1) << 3);
+                    const u32x2_ pk = {pack_bf2(acc[a_][b_][0] * kScale, acc[a_][b_][1] * kScale), pack_bf2(acc[a_][b_][2] * kScale, acc[a_][b_][3] * kScale)};
+                    asm volatile("ds_write_b64 %0, %1" :: "v"(da), "v"(pk) : "memory");
+                }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int r = 16 * j + (lane >> 2), c = 4 * cw + (lane & 3);
+                u32x4_ v;
+                asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(stg + r * 128 + ((c ^ (r & 7)) << 4)) : "memory");
+                const int q = 32 * i + r;
+                if (q < sd.L) *reinterpret_cast<u32x4_*>(dqkv + (base + (long)q * sd.pos_stride) * ld3 + head * ATT_HD + c * 8) = v;
+            }
+            ONE_STAMP(4 + 3 * i);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();                                                // (the owners' final barrier: the K / V tiles become their staging space)
+        ONE_STAMP(32); ONE_STAMP(33);
+        return;
+    }
 
     for (int i = 0; i < nt; ++i) {
         const int buf = i & 1;
@@ -946,87 +1052,24 @@ __global__ __launch_bounds__(640) void attn_bwd_one_kernel(SeqDesc sd, int nt, c
         }
         // this wave's piece of tile i+1 has landed, its LDS traffic of this step is done: behind the barrier the strip of step i is complete,
         // tile i+1 is visible and buffer `buf` may take tile i+2
+        ONE_STAMP(2 + 3 * i);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();
+        ONE_STAMP(3 + 3 * i);
         if (i + 2 < nt) load_qdo(i + 2, buf);
-        if (dq_wave) {
-            // dQ^T blocks of step i (channels 16 db .. + 15, both query halves): two chains of nt 16x16x32 MFMAs over all key tiles; the six transpose
-            // reads of key tile kt+2 are requested before the MFMAs of key tile kt (three register sets, counted lgkmcnt).  The bf16 blocks go to the
-            // step's staging tile ([32 q][64 d], 16-byte chunk c of row q at position c ^ (q & 7)); waves 8 / 9 write it out as whole rows one step later.
-            typedef uint32_t u32x2_ __attribute__((ext_vector_type(2)));
-            typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
-            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-            const uint32_t so = buf * ONE_STRIP_B;
-            u32x2_ fr[3][6];
-#define ONE_RD(set, kt_)                                                                                               \
-            do {                                                                                                       \
-                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(fr[set][0]) : "v"(ka0 + (kt_) * TILE_B));              \
-                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(fr[set][1]) : "v"(ka1 + (kt_) * TILE_B));              \
-                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(fr[set][2]) : "v"(sa0 + so + (kt_) * 2048));           \
-                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(fr[set][3]) : "v"(sa1 + so + (kt_) * 2048));           \
-                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(fr[set][4]) : "v"((sa0 ^ 32u) + so + (kt_) * 2048));   \
-                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(fr[set][5]) : "v"((sa1 ^ 32u) + so + (kt_) * 2048));   \
-            } while (0)
-#define ONE_MF(set)                                                                                                    \
-            do {                                                                                                       \
-                const bf16x8 kfr = __builtin_bit_cast(bf16x8, (u32x4_){fr[set][0].x, fr[set][0].y, fr[set][1].x, fr[set][1].y}); \
-                acc0 = TCOW_MFMA_16x16x32_H16(kfr, __builtin_bit_cast(bf16x8, (u32x4_){fr[set][2].x, fr[set][2].y, fr[set][3].x, fr[set][3].y}), acc0, 0, 0, 0); \
-                acc1 = TCOW_MFMA_16x16x32_H16(kfr, __builtin_bit_cast(bf16x8, (u32x4_){fr[set][4].x, fr[set][4].y, fr[set][5].x, fr[set][5].y}), acc1, 0, 0, 0); \
-            } while (0)
-#define ONE_WAIT(set, n) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(fr[set][0]), "+v"(fr[set][1]), "+v"(fr[set][2]), "+v"(fr[set][3]), "+v"(fr[set][4]), "+v"(fr[set][5]) :: "memory")
-            // (reads of key tiles past nt - 1 land in the neighbouring LDS regions: harmless, their MFMAs are skipped)
-            ONE_RD(0, 0); ONE_RD(1, 1);
-            for (int kt = 0; kt < nt; kt += 3) {
-                ONE_RD(2, kt + 2); ONE_WAIT(0, 12); ONE_MF(0);
-                if (kt + 1 < nt) { ONE_RD(0, kt + 3); ONE_WAIT(1, 12); ONE_MF(1); }
-                if (kt + 2 < nt) { ONE_RD(1, kt + 4); ONE_WAIT(2, 12); ONE_MF(2); }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#undef ONE_WAIT
-#undef ONE_RD
-#undef ONE_MF
-#pragma unroll
-            for (int qb = 0; qb < 2; ++qb) {
-                const f32x4 acc = qb ? acc1 : acc0;
-                const int ql = 16 * qb + (lane & 15);                   // row of the staging tile; channels 16 db + 4 g4 .. + 3 = 8-byte slot 4 db + g4
-                const uint32_t da = lds0 + ONE_DQ + buf * TILE_B + ql * 128 + ((((4 * db + g4) >> 1) ^ (ql & 7)) << 4) + ((g4 & 1) << 3);
-                const u32x2_ pk = {pack_bf2(acc[0] * kScale, acc[1] * kScale), pack_bf2(acc[2] * kScale, acc[3] * kScale)};
-                asm volatile("ds_write_b64 %0, %1" :: "v"(da), "v"(pk) : "memory");
-            }
-        } else if (wave >= 8 && i > 0) {
-            // the finished dQ tile of step i-1 (complete since this step's barrier) goes out as whole 128-byte rows: wave 8 rows 0-15, wave 9 rows 16-31
-            typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
-            const uint32_t st0 = lds0 + ONE_DQ + ((i - 1) & 1) * TILE_B;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int r = 16 * (wave - 8) + 8 * j + (lane >> 3);
-                u32x4_ v;
-                asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(st0 + r * 128 + (((lane & 7) ^ (r & 7)) << 4)) : "memory");
-                const int q = 32 * (i - 1) + r;
-                if (q < sd.L) *reinterpret_cast<u32x4_*>(dqkv + (base + (long)q * sd.pos_stride) * ld3 + head * ATT_HD + (lane & 7) * 8) = v;
-            }
-        }
+        ONE_STAMP(4 + 3 * i);
     }
-    // the last dQ tile, then dK / dV as whole rows through the waves' own (now dead) K / V tiles
+    // dK / dV as whole rows through the waves' own K / V tiles (dead once the chain waves have passed this barrier)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
-    if (wave >= 8) {
-        typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
-        const uint32_t st0 = lds0 + ONE_DQ + ((nt - 1) & 1) * TILE_B;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int r = 16 * (wave - 8) + 8 * j + (lane >> 3);
-            u32x4_ v;
-            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(st0 + r * 128 + (((lane & 7) ^ (r & 7)) << 4)) : "memory");
-            const int q = 32 * (nt - 1) + r;
-            if (q < sd.L) *reinterpret_cast<u32x4_*>(dqkv + (base + (long)q * sd.pos_stride) * ld3 + head * ATT_HD + (lane & 7) * 8) = v;
-        }
-    }
+    ONE_STAMP(32);
     if (owner) {
         bf16_t* drow0 = dqkv + (base + (long)(32 * wave) * sd.pos_stride) * ld3 + head * ATT_HD;
         store_tile_staged(lds0 + ONE_K + wave * TILE_B, lane, kScale, dk0, dk1, drow0 + sd.D, pse, sd.L - 32 * wave);      // dS was accumulated without its 1/sqrt(d) factor
         store_tile_staged(lds0 + ONE_V + wave * TILE_B, lane, 1.0f, dv0, dv1, drow0 + 2 * sd.D, pse, sd.L - 32 * wave);
     }
+    ONE_STAMP(33);
+#undef ONE_STAMP
 }
 
 template <typename K>
@@ -1095,7 +1138,7 @@ int tcow_attn_mfma_bwd(hipStream_t st, const SeqDesc& d, bool shared, const void
     static const int one = [] { const char* e = getenv("TCOW_ATTN_ONE"); return e ? atoi(e) : 1; }();
     if (shared && one && nt <= ONE_MAX_NT && nt >= 4) {
         set_lds_attr(attn_bwd_one_kernel, ONE_LDS);
-        hipLaunchKernelGGL(attn_bwd_one_kernel, dim3(pairs), dim3(640), ONE_LDS, st, d, nt, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv);
+        hipLaunchKernelGGL(attn_bwd_one_kernel, dim3(pairs), dim3(768), ONE_LDS, st, d, nt, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv);
         TCOW_CHECK_LAUNCH();
         return TCOW_OK;
     }

@@ -482,6 +482,38 @@ int main(int argc, char** argv) {
                 }
             }
         }
+        // F: phase timeline of the one-kernel spatial backward (round 4): per wave index, mean shader cycles
+        {
+            bf16_t *dout, *dqkv; long long* dbg4;
+            CK(hipMalloc(&dout, M * D * 2)); CK(hipMalloc(&dqkv, M * 3 * D * 2));
+            CK(hipMemcpy(dout, qkv, M * D * 2, hipMemcpyDeviceToDevice));
+            CK(hipMalloc(&dbg4, (size_t)pairs * 12 * 40 * 8));
+            CK(hipFuncSetAttribute((const void*)attn_bwd_one_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ONE_LDS));
+            auto launch = [&](long long* d) {
+                CK(hipMemcpyToSymbol(HIP_SYMBOL(g_attn_dbg), &d, sizeof(d)));
+                hipLaunchKernelGGL(attn_bwd_one_kernel, dim3(pairs), dim3(768), ONE_LDS, 0, sd, 10, qkv, o, dout, lse, dqkv);
+            };
+            for (int rep = 0; rep < 3; ++rep) launch(nullptr);
+            CK(hipEventRecord(e0)); for (int rep = 0; rep < 20; ++rep) launch(nullptr);
+            CK(hipEventRecord(e1)); CK(hipDeviceSynchronize()); CK(hipEventElapsedTime(&ms, e0, e1));
+            fprintf(f, "F  attn_bwd_one_kernel at B*Qs=3 T=30 S=301 h=12: %.1f us per launch\n", ms * 1000 / 20);
+            CK(hipMemset(dbg4, 0, (size_t)pairs * 12 * 40 * 8));
+            launch(dbg4); CK(hipDeviceSynchronize());
+            std::vector<long long> h4((size_t)pairs * 12 * 40); CK(hipMemcpy(h4.data(), dbg4, h4.size() * 8, hipMemcpyDeviceToHost));
+            fprintf(f, "F  mean shader cycles per phase over %d workgroups, per wave index 0..11 (10, 11 = the dQ chain waves):\n", pairs);
+            auto row = [&](const char* name, auto get) {
+                fprintf(f, "F    %-44s", name);
+                for (int w = 0; w < 12; ++w) { double sm = 0; for (int b = 0; b < pairs; ++b) sm += get(&h4[((size_t)b * 12 + w) * 40]); fprintf(f, " %7.0f", sm / pairs); }
+                fprintf(f, "\n");
+            };
+            row("prologue (loads, table, first barrier)", [](const long long* t) { return (double)(t[1] - t[0]); });
+            row("step: tile arithmetic + strip write (mean of 10)", [](const long long* t) { double s = 0; for (int i = 0; i < 10; ++i) s += (double)(t[2 + 3 * i] - (i ? t[4 + 3 * (i - 1)] : t[1])); return s / 10; });
+            row("step: wait for own loads + barrier (mean of 10)", [](const long long* t) { double s = 0; for (int i = 0; i < 10; ++i) s += (double)(t[3 + 3 * i] - t[2 + 3 * i]); return s / 10; });
+            row("step: requests + dQ chains / dQ stores (mean of 10)", [](const long long* t) { double s = 0; for (int i = 0; i < 10; ++i) s += (double)(t[4 + 3 * i] - t[3 + 3 * i]); return s / 10; });
+            row("final barrier", [](const long long* t) { return (double)(t[32] - t[31]); });
+            row("last dQ tile + dK / dV stores", [](const long long* t) { return (double)(t[33] - t[32]); });
+            row("workgroup lifetime", [](const long long* t) { return (double)(t[33] - t[0]); });
+        }
         hipLaunchKernelGGL(attn_fwd_res, dim3(pairs), dim3(256), RES_LDS, 0, sd, 10, qkv, o, lse, dbg); CK(hipDeviceSynchronize());
         std::vector<long long> h((size_t)pairs * 16); CK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
         const char* nm[12] = {"issue loads", "wait group 0 (Q + tiles 0-3)", "steps 0-3", "wait group 1", "steps 4-7", "issue qx", "wait group 2", "steps 8-9", "store 2 tiles", "5 single steps", "barrier", "merge + store"};
