@@ -31,7 +31,7 @@ c, t = fam('gemm_nt_bf16'); row('NT GEMM (forward + input gradients, fused epilo
 c, t = fam('gemm_tn_bf16'); c2, t2 = fam('slab_reduce4'); row('weight-gradient GEMM (grouped) + folds', c + c2, t + t2, tn_flops, None, 'a real-data MFMA stream tops out at 1.8-1.9 PFLOP/s (power-managed clock, profiles/r04_ubench_mfma.txt); loads + barriers 14 %, slab store + column sums 16 %')
 c, t = fam('attn_fwd_stream'); row('spatial attention forward', c, t, sp_f, L * (qkv_b + o_b), 'latency-bound: 2.0 x its HBM floor, traffic at the algorithmic minimum (profiles/r03_attention.md)')
 c, t = fam('attn_bwd_one_kernel', 'attn_bwd_dq_stream', 'attn_bwd_dkv_stream')
-row('spatial attention backward (one kernel: dK/dV tiles + dQ^T from the dS strip in LDS)', c, t, 2.5 * sp_f, L * (2 * qkv_b + 2 * o_b), 'VALU / latency-bound (10 waves per CU, softmax recompute + dS arithmetic); no score recompute for dQ any more')
+row('spatial attention backward (one kernel: dK/dV tiles + dQ^T from the dS strip in LDS)', c, t, 2.5 * sp_f, L * (2 * qkv_b + 2 * o_b), 'VALU / LDS-traffic bound tile steps (10 tile waves + 2 dQ chain waves per CU); prologue at the one-CU miss rate')
 c, t = fam('attn_fwd_mfma<false>'); row('temporal attention forward', c, t, tp_f, L * (qkv_b + o_b), 'HBM-bound (81 % of a float4 copy)')
 c, t = fam('attn_bwd_one_tile'); row('temporal attention backward', c, t, 2.5 * tp_f, L * (2 * qkv_b + o_b), 'HBM-bound (84 % of a float4 copy)')
 c, t = fam('ln_fwd_kernel'); row('LayerNorm forward', c, t, None, c * M * D * 6.0, 'HBM-bound')
