@@ -178,7 +178,9 @@ def parity_leg(make_trainer, bf16_net, ref_mask, args, bf16_rate=None):
                                   ('bf16x3_mode', 'bf16x3', 'f32 storage, bf16 x 3 GEMM products'), ('fp32_parity_mode', 'fp32', 'f32')):
         net, step = make_trainer(precision)
         nsteps = args.steps if precision == 'fp16' else max(args.parity_steps, 10)   # fp16 (the at-parity throughput): the headline's step count
-        step(); step(); torch.cuda.synchronize()
+        for _ in range(max(args.warmup, 2) if precision == 'fp16' else 2):      # (the at-parity leg warms up like the headline: first steps build optimizer state and allocator pools)
+            step()
+        torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(nsteps):
             step()
