@@ -343,7 +343,7 @@ def main():
             # what the scaling curve needs to explain itself: how long the compute stream stood still for the gradient all-reduce (rank 0),
             # how much went over xGMI per step in how many collectives, and the spread of the per-rank step times
             res['ddp'] = dict(ddp_stats, ms_per_step_min=min(rank_ms), ms_per_step_max=max(rank_ms), ranks=world,
-                              group_blocks=int(os.environ.get('TCOW_DDP_GROUP', '3')),
+                              group_blocks=int(os.environ.get('TCOW_DDP_GROUP', '4')),
                               cpu_baseline='reported at N = 1 only (rank 0 of a single-GPU run)')
         ref_mask = None
         if not args.no_cpu_baseline and world == 1:

@@ -111,7 +111,8 @@ int tcow_gemm_tn(void* stream, int dtype, int M, int N, int K, const void* dY, l
 
 /* The same for several Linear layers at once (the weight gradients of one transformer block, train.py:98's backward through
  * vit.py:50-61,74-76,146): in bf16 mode, problems that share M run as ONE grid with a common, much smaller number of token slices
- * (see gemm_bf16.hip: gemm_tn_bf16_256_group_kernel); otherwise the call is a loop over tcow_gemm_tn.  Results are identical in
+ * (see gemm_bf16.hip: gemm_tn_bf16_256_group_kernel; the more tiles a group has, the fewer slices fill the chip: five for one ViT-B block,
+ * two for four blocks -- tcow_tn_group_slices); otherwise the call is a loop over tcow_gemm_tn.  Results are identical in
  * meaning to n calls of tcow_gemm_tn (f32 summation order over the token slices differs). */
 typedef struct {
     int M, N, K;
@@ -123,6 +124,8 @@ typedef struct {
 } tcow_tn_problem;
 long tcow_gemm_tn_grouped_workspace_bytes(int dtype, int n, const tcow_tn_problem* problems);
 int tcow_gemm_tn_grouped(void* stream, int dtype, int n, const tcow_tn_problem* problems, void* workspace, long workspace_bytes);
+/* most problems that run as one grid (more are accepted and run one by one): 32 = the weight gradients of four divided space-time blocks */
+int tcow_gemm_tn_group_max(void);
 
 /* Small f32 products C[M,N] = A B for the folded temporal projection (W' = W_fc W_proj after every optimizer step;
  * dW_fc = dW' W_proj^T + db' b_proj^T, dW_proj = W_fc^T dW', db_proj = W_fc^T db' in the backward): up to 24 problems per launch on the split-bf16 arithmetic of TCOW_F32X3

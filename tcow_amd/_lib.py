@@ -72,6 +72,7 @@ SIGNATURES = {
     'tcow_gemm_tn': (_i, [_vp, _i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _vp, _i, _vp, _l]),
     'tcow_gemm_tn_grouped_workspace_bytes': (_l, [_i, _i, _vp]),
     'tcow_gemm_tn_grouped': (_i, [_vp, _i, _i, _vp, _vp, _l]),
+    'tcow_gemm_tn_group_max': (_i, []),
     'tcow_sgemm_x3_batched': (_i, [_vp, _i, _vp]),
     'tcow_layernorm_fwd': (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _vp, _f, _vp, _l, _vp, _vp]),
     'tcow_layernorm_bwd_workspace_bytes': (_l, [_i]),

@@ -1254,7 +1254,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_bf16_256_kernel(TnParams p) {
 // one by one, a 768 x 768 weight has 9 tiles and needs 28 token slices to fill the chip -- 66 MB of f32 partials written and read back per
 // GEMM (11.5 GB per training step), a fold launch each, and a ramp / tail per launch.  Together the tiles fill three rounds with FIVE slices:
 // every workgroup walks 5 418 token rows, the partials shrink 5x and one launch replaces seven.
-constexpr int TN_GROUP_MAX = 8;
+constexpr int TN_GROUP_MAX = 32;          // (four divided space-time blocks: 28-32 problems; TnGroup stays below the 4 KiB kernel-argument limit)
 struct TnGroup { int n; int first[TN_GROUP_MAX + 1]; TnParams p[TN_GROUP_MAX]; };
 template <int SCHED>
 __global__ __launch_bounds__(512, 2) void gemm_tn_bf16_256_group_kernel(TnGroup g) {
@@ -1339,17 +1339,21 @@ bool tcow_tn_group_ok(int n, const tcow_tn_problem* pr) {
     }
     return true;
 }
-// common slice count: the smallest one whose tiles x slices fill whole rounds of 256 workgroups best (>= 256 token rows per slice)
+// common slice count: the cheapest one under  cost(s) = 1 / (fill of whole rounds of 256 workgroups) + 0.044 s  -- every slice writes and re-reads
+// one f32 image of all the group's weights: slab store + fold measured at 22 % of the loop time with five slices (profiles/r04_ubench_tn_ab.txt,
+// r04_step_kernel_stats.txt).  One ViT-B block (153 tiles): 5 slices (765 workgroups = 2.99 rounds); four blocks (612 tiles): 2 slices
+// (1224 workgroups = 4.78 rounds, 60 % less slab traffic for 4 % more tail).  >= 256 token rows per slice.
 int tcow_tn_group_slices(int n, const tcow_tn_problem* pr) {
     int tiles = 0;
     for (int i = 0; i < n; ++i) tiles += cdiv(pr[i].N, T2) * cdiv(pr[i].K, T2);
     int max_s = pr[0].M / 256; if (max_s > 64) max_s = 64; if (max_s < 1) max_s = 1;
-    int best = 1; double best_eff = -1.0;
+    static const int forced = [] { const char* e = getenv("TCOW_GEMM_TN_SLICES"); return e ? atoi(e) : 0; }();       // (A/B)
+    if (forced > 0) return forced < max_s ? forced : max_s;
+    int best = 1; double best_cost = 1e30;
     for (int s = 1; s <= max_s; ++s) {
         const int wg = s * tiles, rounds = cdiv(wg, 256);
-        const double eff = (double)wg / (rounds * 256.0);
-        // (every slice writes and re-reads one f32 image of all the group's weights: beyond 8 slices a finer fill of the last round must buy >= 5 %)
-        if (eff > best_eff + (s > 8 ? 0.05 : 0.01)) { best_eff = eff; best = s; }
+        const double cost = (rounds * 256.0) / (double)wg + 0.044 * s;
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = s; }
     }
     return best;
 }

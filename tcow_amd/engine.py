@@ -540,6 +540,8 @@ def run_backward(module, sv, params, d_mask, d_flags):
         else:
             ops.gemm_tn(gmode, dY, Xin, dW.reshape(dW.shape[0], -1), bias_grad=db)
 
+    tn_group_max = ops.tn_group_max()
+
     def flush_pending():
         if pending:
             ops.gemm_tn_grouped(gmode, pending)
@@ -553,11 +555,14 @@ def run_backward(module, sv, params, d_mask, d_flags):
     Co = module.output_channels
     have_flags = module.flag_channels > 0 and d_flags is not None and d_flags.numel() > 0
     head_idx = ([nb, nb + 1] if module.norm_embeddings else []) + [nb + 2, nb + 3] + ([nb + 4, nb + 5] if have_flags else [])
-    # Gradient buckets = GROUPS of transformer blocks (TCOW_DDP_GROUP blocks each, default 3; the top group also carries the output heads, the
-    # bottom one the embeddings): 4 all-reduces of ~115-150 MB at depth 12 instead of 14 of ~38 MB -- each collective is a window in which
+    # Gradient buckets = GROUPS of transformer blocks (TCOW_DDP_GROUP blocks each, default 4; the top group also carries the output heads, the
+    # bottom one the embeddings): 3 all-reduces of ~150-190 MB at depth 12 instead of 14 of ~38 MB -- each collective is a window in which
     # resident RCCL workgroups push the one-workgroup-per-CU GEMMs into an extra round (profiles/r02_cu_contention.txt), so fewer, larger
-    # ones; and the folded projection's small products (below) run once per group.
-    gs = max(1, int(os.environ.get('TCOW_DDP_GROUP', '3')))
+    # ones.  The WEIGHT-GRADIENT GEMMs of a group are issued together at its end as well (one grouped launch over 28 problems = 612 tiles of
+    # 256 x 256 at ViT-B): so many tiles fill whole rounds of the chip with TWO token slices instead of five, i.e. 60 % less f32 partial-sum
+    # traffic in the GEMM and in the fold (tcow_tn_group_slices); nothing in the backward chain waits for a weight gradient, and the bucket
+    # is not published before the group's end anyway.  Their operands (a block's activations and output gradients) stay alive that long.
+    gs = max(1, int(os.environ.get('TCOW_DDP_GROUP', '4')))
     group_lo = {}                                   # block index -> first block of its group
     for hi_ in range(depth, 0, -gs):
         for j in range(max(0, hi_ - gs), hi_):
@@ -724,8 +729,9 @@ def run_backward(module, sv, params, d_mask, d_flags):
             ops.layernorm_bwd(mode, dU, st['R0'], st['mu0'], st['rs0'], q[ix['tn']].detach(), dR1, dR0, galloc(o + ix['tn']), galloc(o + ix['tn'] + 1),
                               dx_cast=G3_next, cast_scale=next_scale)
             dR3 = dR0
-        flush_pending()          # the block's six or seven (joint: four) weight-gradient GEMMs as one grouped launch
-        sv['blocks'][i] = None   # free this block's activations
+        if group_lo[i] == i or len(pending) + 8 > tn_group_max:
+            flush_pending()      # the group's weight-gradient GEMMs (six or seven per block; joint: four) as one grouped launch
+        sv['blocks'][i] = None   # free this block's activations (the queued weight-gradient operands keep theirs)
         if i > 0 and group_lo[i] == i:                                 # last (bottom) block of a group that is not the bottom group: done
             publish('g%d' % i, flat_cur)
 

@@ -93,6 +93,11 @@ def gemm_tn(mode, dY, X, dW, bias_grad=None, accumulate=False):
     return dW
 
 
+def tn_group_max():
+    """Most problems one grouped weight-gradient launch takes (tcow_gemm_tn_group_max)."""
+    return int(L.lib().tcow_gemm_tn_group_max())
+
+
 def gemm_tn_grouped(mode, problems):
     """Weight / bias gradients of several Linear layers in one call: problems = [(dY [M,N], X [M,K], dW [N,K] f32, bias_grad [N] or None), ...].
     In bf16 mode problems that share M run as one grid (tcow_gemm_tn_grouped); the other modes loop inside the library."""

@@ -87,7 +87,8 @@ def _worker(rank, world, port, precision, q):
 
 
 @pytest.mark.parametrize('precision', ['fp32', 'fp16'])
-def test_two_ranks_on_one_gpu_average_the_engine_gradients(cuda, precision):
+def test_two_ranks_on_one_gpu_average_the_engine_gradients(cuda, precision, monkeypatch):
+    monkeypatch.setenv('TCOW_DDP_GROUP', '2')      # two gradient groups in the 4-block test model (inherited by the spawned ranks)
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
@@ -102,11 +103,12 @@ def test_two_ranks_on_one_gpu_average_the_engine_gradients(cuda, precision):
     assert res[0][5:] == res[1][5:]
 
 
-def test_rccl_world_of_one_runs_the_real_buckets(cuda):
+def test_rccl_world_of_one_runs_the_real_buckets(cuda, monkeypatch):
     """backend 'nccl' IS RCCL on ROCm: never initialised by any other test.  A group of one rank leaves the values unchanged, but the collective
     kernels run: ReduceOp.AVG, async work handles, wait() stream semantics and the event pair around the drain."""
     import torch.distributed as dist
     from tcow_amd import ddp
+    monkeypatch.setenv('TCOW_DDP_GROUP', '2')      # the 4-block test model in two gradient groups (the default, 4 blocks per group, makes it one bucket)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
     if dist.is_initialized():
         dist.destroy_process_group()
