@@ -124,7 +124,7 @@ typedef struct {
 } tcow_tn_problem;
 long tcow_gemm_tn_grouped_workspace_bytes(int dtype, int n, const tcow_tn_problem* problems);
 int tcow_gemm_tn_grouped(void* stream, int dtype, int n, const tcow_tn_problem* problems, void* workspace, long workspace_bytes);
-/* most problems that run as one grid (more are accepted and run one by one): 32 = the weight gradients of four divided space-time blocks */
+/* most problems that run as one grid (more are accepted and run one by one): 40 = the weight gradients of five divided space-time blocks */
 int tcow_gemm_tn_group_max(void);
 
 /* Small f32 products C[M,N] = A B for the folded temporal projection (W' = W_fc W_proj after every optimizer step;

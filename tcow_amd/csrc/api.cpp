@@ -206,7 +206,7 @@ int tcow_gemm_tn_grouped(void* stream, int dtype, int n, const tcow_tn_problem* 
         return TCOW_OK;
     }
     const int nz_req = tcow_tn_group_slices(n, pr);
-    float* slabs[32]; float* parts[32]; int nparts[32];          // (tcow_tn_group_ok: n <= tcow_tn_group_max() = 32)
+    float* slabs[40]; float* parts[40]; int nparts[40];          // (tcow_tn_group_ok: n <= tcow_tn_group_max() = 40)
     char* w = (char*)workspace;
     for (int i = 0; i < n; ++i) {
         slabs[i] = (float*)w; w += (long)(nz_req + 1) * pr[i].N * pr[i].K * 4;
@@ -218,7 +218,7 @@ int tcow_gemm_tn_grouped(void* stream, int dtype, int n, const tcow_tn_problem* 
     bool vec = true;
     for (int i = 0; i < n; ++i) vec = vec && tcow_fold_vec_ok(slabs[i], (long)pr[i].N * pr[i].K, pr[i].K, pr[i].dW, pr[i].lddw);
     if (vec) {       // one fold launch for the whole group
-        long rows[32], cols[32], ldo[32]; int acc[32]; float* outs[32]; float* bouts[32]; const float* cparts[32]; const float* cslabs[32];
+        long rows[40], cols[40], ldo[40]; int acc[40]; float* outs[40]; float* bouts[40]; const float* cparts[40]; const float* cslabs[40];
         for (int i = 0; i < n; ++i) {
             rows[i] = pr[i].N; cols[i] = pr[i].K; ldo[i] = pr[i].lddw; acc[i] = pr[i].accumulate; outs[i] = pr[i].dW; bouts[i] = pr[i].bias_grad;
             cparts[i] = parts[i]; cslabs[i] = slabs[i]; if (!parts[i]) nparts[i] = 0;

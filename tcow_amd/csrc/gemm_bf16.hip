@@ -1254,7 +1254,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_bf16_256_kernel(TnParams p) {
 // one by one, a 768 x 768 weight has 9 tiles and needs 28 token slices to fill the chip -- 66 MB of f32 partials written and read back per
 // GEMM (11.5 GB per training step), a fold launch each, and a ramp / tail per launch.  Together the tiles fill three rounds with FIVE slices:
 // every workgroup walks 5 418 token rows, the partials shrink 5x and one launch replaces seven.
-constexpr int TN_GROUP_MAX = 32;          // (four divided space-time blocks: 28-32 problems; TnGroup stays below the 4 KiB kernel-argument limit)
+constexpr int TN_GROUP_MAX = 40;          // (five divided space-time blocks: 35-40 problems; TnGroup = 3.7 KiB, below the 4 KiB kernel-argument limit)
 struct TnGroup { int n; int first[TN_GROUP_MAX + 1]; TnParams p[TN_GROUP_MAX]; };
 template <int SCHED>
 __global__ __launch_bounds__(512, 2) void gemm_tn_bf16_256_group_kernel(TnGroup g) {

@@ -154,7 +154,7 @@ __device__ __forceinline__ float4 ldnt4(const float* p) {
 #define FOLD_LD ld4
 #define FOLD_BLK 512
 struct FoldJob { const float* slab; long slab_stride, n4, cols4, ldo; float* out; const float* part; float* bias_out; int nz, accumulate, slab_blocks, nparts, N, blocks; };
-struct FoldGroup { int n; int first[33]; FoldJob j[32]; };       // (as many jobs as a grouped weight-gradient launch has problems: TN_GROUP_MAX)
+struct FoldGroup { int n; int first[41]; FoldJob j[40]; };       // (as many jobs as a grouped weight-gradient launch has problems: TN_GROUP_MAX)
 __global__ __launch_bounds__(256) void slab_reduce4_group_kernel(FoldGroup g) {
     int k = 0;
     while (k + 1 < g.n && (int)blockIdx.x >= g.first[k + 1]) ++k;          // workgroup-uniform
@@ -333,8 +333,8 @@ int tcow_launch_slab_reduce_group(hipStream_t stream, int n, const float* const*
         g.first[i] = first;
         first += j.blocks;
     }
-    for (int i = n; i < 32; ++i) { g.j[i] = g.j[0]; }
-    for (int i = n; i <= 32; ++i) g.first[i] = first;
+    for (int i = n; i < 40; ++i) { g.j[i] = g.j[0]; }
+    for (int i = n; i <= 40; ++i) g.first[i] = first;
     hipLaunchKernelGGL(slab_reduce4_group_kernel, dim3(first), dim3(256), 0, stream, g);
     TCOW_CHECK_LAUNCH();
     return TCOW_OK;
