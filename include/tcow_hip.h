@@ -158,6 +158,17 @@ int tcow_layernorm_bwd(void* stream, int dtype, int rows, int D, const void* dy,
                        float* dx, long lddx, float* dgamma, float* dbeta, int accumulate, void* workspace,
                        long workspace_bytes, void* dx_cast, long lddx_cast, const float* cast_row_scale,
                        const float* colsum_row_scale, float* colsum_out);
+/* Deferred parameter-gradient fold: with bit 1 of `accumulate` set, tcow_layernorm_bwd leaves its partial table
+ * [tcow_layernorm_bwd_parts(rows, colsum_out != NULL)][2 or 3][D] f32 in `workspace` (the caller keeps one workspace per pending call) and
+ * tcow_layernorm_fold later folds up to 16 such tables in ONE launch (the LayerNorm calls of a group of transformer blocks: three per
+ * block, each fold a 5 us latency-bound launch on its own). */
+typedef struct {
+    const float* part; int parts, D;
+    float* dgamma; float* dbeta; float* colsum_out;      /* colsum_out NULL: the table has two sections */
+    int accumulate;
+} tcow_ln_fold_job;
+int tcow_layernorm_bwd_parts(int rows, int with_colsum);
+int tcow_layernorm_fold(void* stream, int n, const tcow_ln_fold_job* jobs);
 
 /* ------------------------------------------------------------------------------------------- attention
  * softmax(q k^T / 8 [mask]) v per head (head_dim 64) straight on the qkv GEMM output [rows, 3D]

@@ -45,6 +45,11 @@ class TnProblem(ctypes.Structure):
                 ('dW', ctypes.c_void_p), ('lddw', ctypes.c_long), ('bias_grad', ctypes.c_void_p), ('accumulate', ctypes.c_int)]
 
 
+class LnFoldJob(ctypes.Structure):
+    _fields_ = [('part', ctypes.c_void_p), ('parts', ctypes.c_int), ('D', ctypes.c_int), ('dgamma', ctypes.c_void_p), ('dbeta', ctypes.c_void_p),
+                ('colsum_out', ctypes.c_void_p), ('accumulate', ctypes.c_int)]
+
+
 class MaskLossArgs(ctypes.Structure):
     _fields_ = [('n_frames', ctypes.c_long), ('frame_len', ctypes.c_long), ('frames_per_seq', ctypes.c_long),
                 ('logits', ctypes.c_void_p), ('logits_seq_stride', ctypes.c_long),
@@ -77,6 +82,8 @@ SIGNATURES = {
     'tcow_layernorm_fwd': (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _vp, _f, _vp, _l, _vp, _vp]),
     'tcow_layernorm_bwd_workspace_bytes': (_l, [_i]),
     'tcow_layernorm_bwd': (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _l, _vp, _vp, _vp, _vp, _l, _vp, _l, _vp, _vp, _i, _vp, _l, _vp, _l, _vp, _vp, _vp]),
+    'tcow_layernorm_bwd_parts': (_i, [_i, _i]),
+    'tcow_layernorm_fold': (_i, [_vp, _i, _vp]),
     'tcow_attn_temporal_fwd': (_i, [_vp, _ash, _vp, _vp, _vp]),
     'tcow_attn_spatial_fwd': (_i, [_vp, _ash, _vp, _vp, _vp]),
     'tcow_attn_bwd_workspace_bytes': (_l, [_ash]),

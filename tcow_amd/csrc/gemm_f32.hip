@@ -216,10 +216,24 @@ __global__ __launch_bounds__(256) void slab_reduce4_group_kernel(FoldGroup g) {
 
 // out[c] (+)= sum_r part[r][c] for a tall-skinny partial table (many rows, few columns): 16 columns x 16 row groups per block
 // (columns >= N1 go to out2[c - N1]: LayerNorm's dgamma | dbeta table is folded by one launch)
+__device__ __forceinline__ void row_reduce_body(int bx, const float* __restrict__ part, int nrows, long ld, int N, float* __restrict__ out, int accumulate,
+                                                int N1, float* __restrict__ out2, int N12, float* __restrict__ out3);
 __global__ __launch_bounds__(256) void row_reduce_kernel(const float* __restrict__ part, int nrows, long ld, int N, float* __restrict__ out, int accumulate,
                                                          int N1, float* __restrict__ out2, int N12 = 1 << 30, float* __restrict__ out3 = nullptr) {
+    row_reduce_body(blockIdx.x, part, nrows, ld, N, out, accumulate, N1, out2, N12, out3);
+}
+// several such folds in one launch (blockIdx.y = job): the dgamma | dbeta (| bias) tables of all LayerNorm backward calls of a group of blocks
+struct RowReduceJob { const float* part; float* out; float* out2; float* out3; long ld; int nrows, N, N1, N12, accumulate; };
+struct RowReduceGroup { RowReduceJob j[16]; };
+__global__ __launch_bounds__(256) void row_reduce_group_kernel(RowReduceGroup g) {
+    const RowReduceJob& j = g.j[blockIdx.y];
+    if ((int)blockIdx.x * 16 >= j.N) return;
+    row_reduce_body(blockIdx.x, j.part, j.nrows, j.ld, j.N, j.out, j.accumulate, j.N1, j.out2, j.N12, j.out3);
+}
+__device__ __forceinline__ void row_reduce_body(int bx, const float* __restrict__ part, int nrows, long ld, int N, float* __restrict__ out, int accumulate,
+                                                int N1, float* __restrict__ out2, int N12, float* __restrict__ out3) {
     __shared__ float red[16][17];
-    const int c = blockIdx.x * 16 + (threadIdx.x & 15), g = threadIdx.x >> 4;
+    const int c = bx * 16 + (threadIdx.x & 15), g = threadIdx.x >> 4;
     float s = 0.f;
     if (c < N) {
         // 8 independent loads in flight per thread: the table is small (a few MB), the kernel is pure load latency
@@ -336,6 +350,23 @@ int tcow_launch_slab_reduce_group(hipStream_t stream, int n, const float* const*
     for (int i = n; i < 40; ++i) { g.j[i] = g.j[0]; }
     for (int i = n; i <= 40; ++i) g.first[i] = first;
     hipLaunchKernelGGL(slab_reduce4_group_kernel, dim3(first), dim3(256), 0, stream, g);
+    TCOW_CHECK_LAUNCH();
+    return TCOW_OK;
+}
+
+// n <= 16 three-way folds (out | out2 | out3 = columns [0, N1) | [N1, N12) | [N12, N)) in one launch
+int tcow_launch_row_reduce_group(hipStream_t stream, int n, const float* const* part, const int* nrows, const long* ld, const int* N1, float* const* out1, const int* N2,
+                                 float* const* out2, const int* N3, float* const* out3, const int* accumulate) {
+    RowReduceGroup g;
+    int gx = 0;
+    for (int i = 0; i < n; ++i) {
+        RowReduceJob& j = g.j[i];
+        j.part = part[i]; j.out = out1[i]; j.out2 = out2[i]; j.out3 = out3[i]; j.ld = ld[i]; j.nrows = nrows[i];
+        j.N = N1[i] + N2[i] + (out3[i] ? N3[i] : 0); j.N1 = N1[i]; j.N12 = out3[i] ? N1[i] + N2[i] : (1 << 30); j.accumulate = accumulate[i];
+        const int b = cdiv(j.N, 16); if (b > gx) gx = b;
+    }
+    for (int i = n; i < 16; ++i) g.j[i] = g.j[0];
+    hipLaunchKernelGGL(row_reduce_group_kernel, dim3(gx, n), dim3(256), 0, stream, g);
     TCOW_CHECK_LAUNCH();
     return TCOW_OK;
 }

@@ -190,6 +190,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int D, const T* _
 }  // namespace
 
 int tcow_launch_row_reduce2(hipStream_t stream, const float* part, int nrows, long ld, int N1, float* out1, int N2, float* out2, int accumulate);
+int tcow_launch_row_reduce_group(hipStream_t stream, int n, const float* const* part, const int* nrows, const long* ld, const int* N1, float* const* out1, const int* N2,
+                                 float* const* out2, const int* N3, float* const* out3, const int* accumulate);
 int tcow_launch_row_reduce3(hipStream_t stream, const float* part, int nrows, long ld, int N1, float* out1, int N2, float* out2, int N3, float* out3, int accumulate);
 
 static const int kLnBwdBlocks = [] { const char* e = getenv("TCOW_LN_BWD_BLOCKS"); const int v = e ? atoi(e) : 768; return v >= 1 ? v : 768; }();
@@ -253,12 +255,30 @@ int tcow_layernorm_bwd(void* stream, int dtype, int rows, int D, const void* dy,
     else if (nvl <= 1) LN_BWD(1, false); else if (nvl == 2) LN_BWD(2, false); else if (nvl == 3) LN_BWD(3, false); else if (nvl == 4) LN_BWD(4, false); else LN_BWD(8, false);
 #undef LN_BWD
     TCOW_CHECK_LAUNCH();
-    if (want_param_grads) {
+    if (want_param_grads && !(accumulate & 2)) {
         // part is [blocks][2 or 3][D]: dgamma partials first, dbeta partials at +D, the fused bias gradient at +2D
-        if (csum) return tcow_launch_row_reduce3((hipStream_t)stream, part, blocks, 3L * D, D, dgamma, D, dbeta, D, colsum_out, accumulate);
-        return tcow_launch_row_reduce2((hipStream_t)stream, part, blocks, 2L * D, D, dgamma, D, dbeta, accumulate);
+        if (csum) return tcow_launch_row_reduce3((hipStream_t)stream, part, blocks, 3L * D, D, dgamma, D, dbeta, D, colsum_out, accumulate & 1);
+        return tcow_launch_row_reduce2((hipStream_t)stream, part, blocks, 2L * D, D, dgamma, D, dbeta, accumulate & 1);
     }
-    return TCOW_OK;
+    return TCOW_OK;            // (accumulate & 2: the partial table stays in `workspace` for tcow_layernorm_fold)
+}
+
+int tcow_layernorm_bwd_parts(int rows, int with_colsum) {
+    const int max_blocks = with_colsum ? kLnBwdBlocksCsum : kLnBwdBlocks;
+    int blocks = cdiv(rows, 4); if (blocks > max_blocks) blocks = max_blocks;
+    return blocks;
+}
+
+int tcow_layernorm_fold(void* stream, int n, const tcow_ln_fold_job* jobs) {
+    TCOW_CHECK_ARG(n > 0 && n <= 16 && jobs, "tcow_layernorm_fold: 1..16 jobs");
+    const float* part[16]; int nrows[16]; long ld[16]; int N1[16], N2[16], N3[16], acc[16]; float* o1[16]; float* o2[16]; float* o3[16];
+    for (int i = 0; i < n; ++i) {
+        const tcow_ln_fold_job& j = jobs[i];
+        TCOW_CHECK_ARG(j.part && j.dgamma && j.dbeta && j.parts > 0 && j.D > 0, "tcow_layernorm_fold: bad job %d", i);
+        part[i] = j.part; nrows[i] = j.parts; ld[i] = (j.colsum_out ? 3L : 2L) * j.D; N1[i] = N2[i] = N3[i] = j.D; acc[i] = j.accumulate;
+        o1[i] = j.dgamma; o2[i] = j.dbeta; o3[i] = j.colsum_out;
+    }
+    return tcow_launch_row_reduce_group((hipStream_t)stream, n, part, nrows, ld, N1, o1, N2, o2, N3, o3, acc);
 }
 
 }  // extern "C"

@@ -542,10 +542,14 @@ def run_backward(module, sv, params, d_mask, d_flags):
 
     tn_group_max = ops.tn_group_max()
 
+    ln_jobs = []          # LayerNorm parameter-gradient folds of the current group of blocks, one launch at its end (ops.layernorm_fold)
+
     def flush_pending():
         if pending:
             ops.gemm_tn_grouped(gmode, pending)
             pending.clear()
+        if ln_jobs:
+            ops.layernorm_fold(ln_jobs)
 
     BP, ix = _layout(module)
     joint = module.attention_type != 'divided_space_time'
@@ -673,7 +677,7 @@ def run_backward(module, sv, params, d_mask, d_flags):
         dR2 = E(M, D, dtype=f32)
         G2 = E(M, D)                           # operand copy of dR2 * row scale: written by the LayerNorm backward, its slot-0 rows redone by the cls adjoint
         ops.layernorm_bwd(mode, dWn, st['R2'], st['mu2'], st['rs2'], q[ix['n2']].detach(), dR3, dR2, galloc(o + ix['n2']), galloc(o + ix['n2'] + 1),
-                          dx_cast=G2, cast_scale=st['rs_s'])
+                          dx_cast=G2, cast_scale=st['rs_s'], defer=ln_jobs)
         del G3, dpre, dWn
         # ---- spatial / joint attention
         if use_cls and not joint:
@@ -697,10 +701,10 @@ def run_backward(module, sv, params, d_mask, d_flags):
         if fold:
             # G1 = bf16(dR1 * mask0 * dp_t) = dY' of the folded projection; its bias b_fc sees dR1 * mask0: summed here, in f32
             ops.layernorm_bwd(mode, dV, st['R1'], st['mu1'], st['rs1'], q[ix['n1']].detach(), dR2, dR1, galloc(o + ix['n1']), galloc(o + ix['n1'] + 1), dx_cast=G1,
-                              cast_scale=dp['t0'], colsum_out=galloc(o + ix['tfc'] + 1), colsum_scale=mask0)
+                              cast_scale=dp['t0'], colsum_out=galloc(o + ix['tfc'] + 1), colsum_scale=mask0, defer=ln_jobs)
         else:
             ops.layernorm_bwd(mode, dV, st['R1'], st['mu1'], st['rs1'], q[ix['n1']].detach(), dR2, dR1, galloc(o + ix['n1']), galloc(o + ix['n1'] + 1), dx_cast=G1,
-                              cast_scale=(next_scale if joint else mask0))
+                              cast_scale=(next_scale if joint else mask0), defer=ln_jobs)
         del G2, dO2, dQKV2, dV
         if joint:
             G3_next = G1                       # a joint block has no temporal half: its input gradient is complete here
@@ -727,7 +731,7 @@ def run_backward(module, sv, params, d_mask, d_flags):
             dR0 = E(M, D, dtype=f32)
             G3_next = E(M, D)                  # operand of the next (lower) block's MLP backward, or of the patch-embed weight gradient
             ops.layernorm_bwd(mode, dU, st['R0'], st['mu0'], st['rs0'], q[ix['tn']].detach(), dR1, dR0, galloc(o + ix['tn']), galloc(o + ix['tn'] + 1),
-                              dx_cast=G3_next, cast_scale=next_scale)
+                              dx_cast=G3_next, cast_scale=next_scale, defer=ln_jobs)
             dR3 = dR0
         if group_lo[i] == i or len(pending) + 8 > tn_group_max:
             flush_pending()      # the group's weight-gradient GEMMs (six or seven per block; joint: four) as one grouped launch

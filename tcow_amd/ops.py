@@ -134,17 +134,36 @@ def layernorm_fwd(mode, x, gamma, beta, out, mean=None, rstd=None, eps=1e-6):
 
 
 def layernorm_bwd(mode, dy, x, mean, rstd, gamma, dres, dx, dgamma=None, dbeta=None, accumulate=False, dx_cast=None, cast_scale=None,
-                  colsum_out=None, colsum_scale=None):
+                  colsum_out=None, colsum_scale=None, defer=None):
     """dx = dres + dLN(dy); dx_cast (mode dtype, optional) = dx * cast_scale[row]: the next input-gradient GEMM's operand;
-    colsum_out [D] (optional) = sum over rows of colsum_scale[row] * dx[row]."""
+    colsum_out [D] (optional) = sum over rows of colsum_scale[row] * dx[row].
+    defer: a list -> the fold of the dgamma / dbeta (/ colsum) partial table is NOT launched; a job for layernorm_fold is appended instead (the
+    table lives in its own workspace until then)."""
     rows, D = x.shape
     lib, dm = _sel(mode)
-    ws = workspace(lib.tcow_layernorm_bwd_workspace_bytes(D), x.device, 'ln')
+    if defer is not None and dgamma is not None:
+        ws = workspace(lib.tcow_layernorm_bwd_workspace_bytes(D), x.device, 'ln_defer%d' % len(defer))
+        defer.append((lib, ws, int(lib.tcow_layernorm_bwd_parts(rows, 1 if colsum_out is not None else 0)), D, dgamma, dbeta, colsum_out, bool(accumulate)))
+        accumulate = int(accumulate) | 2
+    else:
+        ws = workspace(lib.tcow_layernorm_bwd_workspace_bytes(D), x.device, 'ln')
     L.check(lib.tcow_layernorm_bwd(_stream(), dm, rows, D, dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), mean.data_ptr(),
                                    rstd.data_ptr(), gamma.data_ptr(), _p(dres), dres.stride(0) if dres is not None else 0, dx.data_ptr(),
                                    dx.stride(0), _p(dgamma), _p(dbeta), int(accumulate), ws.data_ptr(), ws.numel(),
                                    _p(dx_cast), dx_cast.stride(0) if dx_cast is not None else 0, _p(cast_scale), _p(colsum_scale), _p(colsum_out)), 'tcow_layernorm_bwd', lib)
     return dx
+
+
+def layernorm_fold(jobs):
+    """The deferred dgamma / dbeta (/ colsum) folds of layernorm_bwd(..., defer=jobs): up to 16 per launch (tcow_layernorm_fold)."""
+    for c0 in range(0, len(jobs), 16):
+        chunk = jobs[c0:c0 + 16]
+        lib = chunk[0][0]
+        arr = (L.LnFoldJob * len(chunk))()
+        for i, (_, ws, parts, D, dg, db, cs, acc) in enumerate(chunk):
+            arr[i] = L.LnFoldJob(ws.data_ptr(), parts, D, dg.data_ptr(), db.data_ptr(), _p(cs), 1 if acc else 0)
+        L.check(lib.tcow_layernorm_fold(_stream(), len(chunk), arr), 'tcow_layernorm_fold', lib)
+    jobs.clear()
 
 
 def attn_shape(mode, B, T, S, D, heads, causal):

@@ -431,3 +431,28 @@ def test_flags_casts(ops, cuda):
     dh = torch.empty(50, 64, device=cuda, dtype=torch.float16)
     ops.scale_cast(ops.FP16, src, rs, dh)
     assert torch.equal(dh, (src * rs[:, None]).half())
+
+
+def test_layernorm_deferred_fold_is_bit_identical(ops, cuda):
+    """layernorm_bwd(..., defer=jobs) + layernorm_fold(jobs) (one launch for several LayerNorm calls: tcow_layernorm_fold) vs the immediate fold:
+    the same partial tables through the same reduction -- dgamma, dbeta and the fused column sum bit for bit; with and without accumulation."""
+    torch.manual_seed(3)
+    rows, D = 1000, 768
+    jobs, want = [], []
+    for k in range(3):
+        x = torch.randn(rows, D, device=cuda); dy = torch.randn(rows, D, device=cuda).bfloat16(); g = torch.randn(D, device=cuda); dres = torch.randn(rows, D, device=cuda)
+        mu = x.mean(1); rs = (x.var(1, unbiased=False) + 1e-6).rsqrt(); sc = torch.rand(rows, device=cuda)
+        acc = k == 2
+        outs = []
+        for defer in (None, jobs):
+            dg = torch.full((D,), 0.5, device=cuda); db = torch.full((D,), -0.25, device=cuda); cs = torch.zeros(D, device=cuda) if k != 1 else None
+            dx = torch.empty(rows, D, device=cuda)
+            ops.layernorm_bwd(ops.BF16, dy, x, mu, rs, g, dres, dx, dg, db, accumulate=acc, colsum_out=cs, colsum_scale=sc if cs is not None else None, defer=defer)
+            outs.append((dg, db, cs, dx))
+        want.append(outs)
+    assert len(jobs) == 3
+    ops.layernorm_fold(jobs)
+    assert not jobs
+    for (a, b) in want:
+        for u, v in zip(a, b):
+            assert (u is None and v is None) or torch.equal(u, v)
