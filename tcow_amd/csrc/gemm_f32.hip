@@ -144,11 +144,6 @@ __global__ __launch_bounds__(64) void slab_reduce4_kernel(const float* __restric
 // slabs read once and not kept in cache) followed by its bias-table workgroups (16 columns x 16 row groups each).
 // (The first version was a (max blocks, jobs) grid of one-wave workgroups with one float4 per thread: 52 us for the 170 MB of a ViT-B block's
 // seven weights = 3.3 TB/s, a third of its workgroups empty.)
-typedef float f32x4_nt __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float4 ldnt4(const float* p) {
-    const f32x4_nt v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(p));
-    return make_float4(v[0], v[1], v[2], v[3]);
-}
 // (measured equal: non-temporal vs plain loads, one vs two float4 columns per thread, 64-bit vs 32-bit row / column split: the launch moves its
 // 198-226 MB at 4.1-4.4 TB/s either way)
 #define FOLD_LD ld4
