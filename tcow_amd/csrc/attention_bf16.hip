@@ -874,6 +874,9 @@ __global__ __launch_bounds__(768) void attn_bwd_one_kernel(SeqDesc sd, int nt, c
     char* ktiles = smem + ONE_K; char* vtiles = smem + ONE_V;
     float2* tab = reinterpret_cast<float2*>(smem + ONE_TAB);
     const bool owner = wave < nt;
+    // (the third tile wave of a SIMD -- waves 8, 9 -- gets the issue slots last and is the one everybody waits for at the step barrier: priorities 2 / 1 / 0 for
+    // waves 8-9 / 4-7 / 0-3 and the chain waves)
+    if (wave >= 8 && wave < 10) __builtin_amdgcn_s_setprio(2); else if (wave >= 4 && wave < 8) __builtin_amdgcn_s_setprio(1);
 #ifdef UBENCH_ATTN          // phase stamps of tools/ubench_valu.hip (part F): compiled into the micro-benchmark only
 #define ONE_STAMP(i) do { if (g_attn_dbg && lane == 0) g_attn_dbg[((long)blockIdx.x * 12 + wave) * 40 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
 #else
