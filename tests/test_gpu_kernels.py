@@ -295,6 +295,7 @@ def _ref_attn(qkv, B, T, S, D, heads, ca, spatial):
 @pytest.mark.parametrize('spatial,B,T,S,heads,ca', [
     (False, 1, 4, 17, 4, 1), (False, 2, 30, 21, 2, 1), (False, 1, 30, 9, 2, 0), (False, 1, 7, 9, 2, 3), (False, 1, 40, 9, 2, 1), (False, 1, 70, 5, 1, 2),
     (True, 1, 2, 17, 4, 1), (True, 2, 3, 301, 2, 1), (True, 1, 2, 77, 2, 2), (True, 1, 1, 2, 1, 0), (True, 1, 1, 333, 1, 1),
+    (True, 1, 2, 100, 2, 1), (True, 1, 1, 161, 1, 1), (True, 2, 1, 256, 2, 1), (True, 1, 1, 289, 3, 1),      # the one-kernel backward's range (4..10 key tiles): ragged / exact / one valid key in the last tile
     (True, 1, 2, 1201, 12, 1)])          # last: the spatial sequence of BASELINE configs[3] (480x640: 1200 patches + cls)
 def test_attention_fwd_bwd(ops, cuda, mname, tol, spatial, B, T, S, heads, ca):
     """Empty / ragged cases included: S=2 (one patch), T not a multiple of 32, sequences longer than the MFMA limits
