@@ -91,6 +91,7 @@ struct EpiRow { float4 ext; float rs, rs2; };
 template <int ACT, int ROWS> struct EpiCfg {
     static constexpr bool kStatic = ACT >= 0 && ROWS >= 0;
     static constexpr bool kRowOps = ROWS > 0 || ACT == TCOW_ACT_DGELU || ACT == TCOW_ACT_MUL_AUX;
+    static constexpr bool kAuxOnly = ROWS == 0 && ACT == TCOW_ACT_MUL_AUX;     // the only row operand is the 16-bit aux tile (fc2's input gradient x GELU')
     static __device__ __forceinline__ int act(const NtParams& p) { return ACT < 0 ? p.act : ACT; }
     static __device__ __forceinline__ bool rs(const NtParams& p) { return ROWS < 0 ? p.row_scale != nullptr : (ROWS & 1) != 0; }
     static __device__ __forceinline__ bool res(const NtParams& p) { return ROWS < 0 ? p.resid != nullptr : (ROWS & 2) != 0; }
@@ -259,6 +260,56 @@ __device__ __forceinline__ void wave_tile_epilogue_160x64(const NtParams& p, cha
                 }
             }
         };
+        if constexpr (E::kAuxOnly) {
+            // The aux tile is requested THREE bands ahead, 16 bytes (8 packed columns) per row group and lane (48 registers; all five bands = 80
+            // spilled).  It is a first-touch HBM stream (166 MB per launch): one band ahead, every band waited for its own miss latency behind
+            // the previous band's stores.
+            uint4 ax[3][4];
+            auto fetch_ax = [&](uint4 (&a)[4], int u) {
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int gm = mrow8 + u * 32 + it * 8;
+                    a[it] = (ok8 && gm < p.M) ? *reinterpret_cast<const uint4*>(p.aux + (size_t)gm * p.ldaux + gn8) : make_uint4(0u, 0u, 0u, 0u);
+                }
+            };
+            fetch_ax(ax[0], 0); fetch_ax(ax[1], 1); fetch_ax(ax[2], 2);
+            auto apply_ax = [&](const uint4 (&a)[4], int u, int half) {
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int gm = mrow8 + u * 32 + it * 8;
+                    if (!(ok8 && gm < p.M)) continue;
+                    const float* cr = ct + (half * 32 + r8 + it * 8) * CT_LD + c8;
+                    float4 v0 = *reinterpret_cast<const float4*>(cr), v1 = *reinterpret_cast<const float4*>(cr + 4);
+                    const uint4 e = a[it];
+                    v0.x = (v0.x + b40.x) * bflo(e.x); v0.y = (v0.y + b40.y) * bfhi(e.x); v0.z = (v0.z + b40.z) * bflo(e.y); v0.w = (v0.w + b40.w) * bfhi(e.y);
+                    v1.x = (v1.x + b41.x) * bflo(e.z); v1.y = (v1.y + b41.y) * bfhi(e.z); v1.z = (v1.z + b41.z) * bflo(e.w); v1.w = (v1.w + b41.w) * bfhi(e.w);
+                    if (p.out_f32) {
+                        float* d = reinterpret_cast<float*>(p.C) + (size_t)gm * p.ldc + gn8;
+                        st4(d, v0); st4(d + 4, v1);
+                    } else {
+                        uint4 w; w.x = pack_bf2(v0.x, v0.y); w.y = pack_bf2(v0.z, v0.w); w.z = pack_bf2(v1.x, v1.y); w.w = pack_bf2(v1.z, v1.w);
+                        *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)gm * p.ldc + gn8) = w;
+                    }
+                }
+            };
+            TCOW_STAGE(0, 0); TCOW_STAGE(1, 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            apply_ax(ax[0], 0, 0);
+            fetch_ax(ax[0], 3);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            TCOW_STAGE(2, 0);
+            apply_ax(ax[1], 1, 1);
+            fetch_ax(ax[1], 4);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            TCOW_STAGE(3, 1);
+            apply_ax(ax[2], 2, 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            TCOW_STAGE(4, 0);
+            apply_ax(ax[0], 3, 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            apply_ax(ax[1], 4, 0);
+            return;
+        }
         fetch(oa, 0); TCOW_STAGE(0, 0);
         fetch(ob, 1); TCOW_STAGE(1, 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
