@@ -224,8 +224,9 @@ bool tcow_gemm_nt_c2_ok(const tcow_gemm_args* a) { return a->K % 128 == 0 && (lo
 int tcow_gemm_nt_bf16_c2(hipStream_t stream, const tcow_gemm_args* a) {
     NtParams p = nt_params_from_args(a);
     p.tiles_m = cdiv(a->M, D_BM); p.tiles_n = cdiv(a->N, D_BN);
-    // second workgroup of each CU: late by this many microseconds per 64-wide K tile (0.45 us: about half of a tile's main loop when it runs alone)
-    static const float skew_us = [] { const char* e = getenv("TCOW_GEMM_C2_SKEW"); return e ? (float)atof(e) : 0.45f; }();
+    // second workgroup of each CU: late by this many microseconds per 64-wide K tile (A/B only; default 0: over the nine shapes of the path 851 us
+    // without a skew, 870 / 883 / 924 us with 0.45 / 0.9 / 1.3 us per K tile -- a late start is lost time, the epilogues do not hide under it)
+    static const float skew_us = [] { const char* e = getenv("TCOW_GEMM_C2_SKEW"); return e ? (float)atof(e) : 0.0f; }();
     static const int skew_mode = [] { const char* e = getenv("TCOW_GEMM_C2_SKEWMODE"); return e ? atoi(e) : 1; }();
     p.skew = (int)(skew_us * 100.f * (float)(a->K / 64)); p.skew_mode = skew_mode;
     typedef void (*Kern)(NtParams);
