@@ -325,7 +325,7 @@ def main():
         ks = timer.summary()
         peak = {'bf16': PEAK_BF16_TFLOPS, 'fp16': PEAK_BF16_TFLOPS, 'fp32': PEAK_F32_TFLOPS, 'bf16x3': PEAK_BF16_TFLOPS / 3.0}[args.precision]   # (dense f16 = dense bf16 peak)   # bf16x3: three MFMAs per product
         traffic = pmc_traffic() if args.precision in ('bf16', 'fp16') else None        # (same kernels, same bytes in both 16-bit builds)
-        roof = dict(bound='mfma', kernel={'bf16': 'gemm_nt_bf16_320_kernel (+ gemm_nt_bf16_256_kernel, gemm_nt_bf16_kernel)', 'fp16': 'gemm_nt_bf16_320_kernel built for binary16 (libtcow_hip_fp16.so)',
+        roof = dict(bound='mfma', kernel={'bf16': 'gemm_nt_bf16_320_kernel (+ gemm_nt_bf16_c2_kernel, gemm_nt_bf16_256_kernel, gemm_nt_bf16_kernel)', 'fp16': 'gemm_nt_bf16_320_kernel built for binary16 (libtcow_hip_fp16.so)',
                             'fp32': 'gemm_f32_kernel', 'bf16x3': 'gemm_x3_kernel'}[args.precision],
                     achieved=ks['tflops'], peak=peak, unit='TFLOP/s', frac=ks['tflops'] / peak, traffic=traffic,
                     launches_per_step=ks['launches'] / args.steps, avg_launch_us=ks['avg_us'], flops_per_launch=ks['flops_per_launch'])

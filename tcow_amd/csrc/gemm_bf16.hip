@@ -614,10 +614,11 @@ int tcow_gemm_nt_bf16(hipStream_t stream, const tcow_gemm_args* a) {
         const long rounds = (t320 + 255) / 256;
         const bool fills = t320 * 100 >= rounds * 256 * 80;   // (measured: still ahead of the 256 / 128 tiles at 88 % -- configs[3], configs[4])
         // the 160 x 256 tile at two workgroups per CU (gemm_nt_c2.hip): same shapes (its tiles are the wave rows of the 320 tile)
-        // TCOW_GEMM_C2: 0 (default) = never, 1 = every shape the 320 tile takes, 2 = only where it measured ahead of the 320 tile at M = 27 090
+        // TCOW_GEMM_C2: 0 = never, 1 = every shape the 320 tile takes, 2 (default) = only where it measured ahead of the 320 tile at M = 27 090
         // (profiles/r04_gemm_c2.txt): short-K GEMMs with an f32 residual epilogue (the HBM-bound epilogue hides under the co-resident
-        // workgroup's main loop) and plain short-K GEMMs of three rounds
-        static const int c2 = [] { const char* e = getenv("TCOW_GEMM_C2"); return e ? atoi(e) : 0; }();
+        // workgroup's main loop) and plain short-K GEMMs of three rounds.  Same-box A/B of the training step: 28.05 / 28.10 ms with 2,
+        // 28.24 / 28.30 ms with 0.
+        static const int c2 = [] { const char* e = getenv("TCOW_GEMM_C2"); return e ? atoi(e) : 2; }();
         const bool c2_pick = c2 == 1 || (c2 == 2 && a->K <= 1024 && ((a->out_f32 && a->resid) || (a->act == TCOW_ACT_NONE && !a->row_scale && !a->resid && !a->bias2 && a->N >= 2304 && a->N < 3072)));
         if (a->tile == 160 || (a->tile == 0 && c2_pick && wide && (wide == 2 || (fills && t320 >= 200)) && tcow_gemm_nt_c2_ok(a))) {
             TCOW_CHECK_ARG(tcow_gemm_nt_c2_ok(a), "tcow_gemm_nt(bf16): tile 160 needs K %% 128 == 0 and operands below 2 GiB");
