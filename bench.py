@@ -38,6 +38,7 @@ def parse():
     ap.add_argument('--launch-selftest', action='store_true', help='only start the ranks, all-reduce one number and print the rank count (CPU-runnable check of the N > 1 launch path)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true', help='skip the fp32 parity-mode timing and the live max|d| check against the oracle')
+    ap.add_argument('--no-config-legs', action='store_true', help='skip the configs[3] long-clip forward and configs[4] batched-eval legs')
     ap.add_argument('--parity-steps', type=int, default=10, help='timed steps of the bf16x3 / fp32 legs (the fp16 leg runs --steps)')
     ap.add_argument('--cpu-budget-s', type=float, default=25.0)
     return ap.parse_args()
@@ -127,6 +128,100 @@ def pmc_traffic():
     return None
 
 
+def trained_scale_case(cfg, so, synth, args):
+    """Inputs + oracle logits of the trained-magnitude parity case (one more oracle forward, ~7 s on the GPU box's host), or None when the
+    run is not at the BASELINE configs[1] geometry the fixture's head gain was calibrated for."""
+    import numpy as np
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tests', 'golden', 'g16_cfg2_trained_scale.npz')
+    if not os.path.exists(path) or (args.frames, args.height, args.width, args.depth) != (30, 240, 320, 12):
+        return None
+    meta = json.loads(bytes(np.load(path)['meta']).decode())
+    sd = synth.trained_scale_state_dict(synth.make_state_dict(cfg, meta['seed']), meta['qk_gain'], meta['w_gain'], meta['head_gain'])
+    clip = synth.make_clip(1, args.frames, args.height, args.width, seed=meta['seed'])
+    rgb = torch.from_numpy(clip['rgb']); qm = torch.from_numpy(synth.make_query_mask(clip, 0, 0))
+    with torch.no_grad():
+        ref, _ = so.seeker_forward(so.to_torch_state_dict(sd), cfg, rgb, qm)
+    return dict(sd=sd, rgb=rgb, qm=qm, ref=ref)
+
+
+def rccl_knobs():
+    """The RCCL / overlap settings an N > 1 run was taken with (environment as seen by rank 0): what the `ddp` block's numbers depend on."""
+    keys = ('NCCL_MAX_NCHANNELS', 'NCCL_MIN_NCHANNELS', 'NCCL_ALGO', 'NCCL_PROTO', 'NCCL_BUFFSIZE', 'RCCL_MSCCL_ENABLE', 'TCOW_DDP_OVERLAP', 'TCOW_DDP_AVG',
+            'TCOW_DIST_BACKEND', 'HSA_ENABLE_IPC_MODE_LEGACY')
+    return {k: os.environ.get(k) for k in keys if os.environ.get(k) is not None}
+
+
+def config_legs(args, dev):
+    """BASELINE.json configs[3] and configs[4] in the bench line (a few seconds each; the same computations as tools/run_configs.py):
+      config3_long_forward : T=60 480x640 inference forward (S = 1201 spatial x 60 temporal tokens), ms, achieved TFLOP/s, and the share of
+                             the forward spent in the attention kernels (their launches timed alone with HIP events, x 12 blocks);
+      config4_batched_eval : 4 queries x 4 temporal strides = 16 eval forwards of the configs[1] shape as ONE batched call: forwards/s, and
+                             the binary-mask agreement + max|d| of the first forward against the CPU oracle."""
+    from oracle import seeker_oracle as so
+    from tcow_amd import flops, ops, synth
+    from tcow_amd.seeker import Seeker
+    out = {}
+
+    def build(cfg):
+        net = Seeker(None, num_total_frames=cfg['num_total_frames'], frame_height=cfg['frame_height'], frame_width=cfg['frame_width'], causal_attention=1,
+                     drop_path_rate=0.0, precision=args.precision)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg, 900).items()}, strict=True)
+        return net.to(dev).eval()
+
+    def timeit(f, n, w):
+        for _ in range(w):
+            f()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(n):
+            f()
+        torch.cuda.synchronize(); return (time.perf_counter() - t0) / n
+
+    # ---- configs[3]
+    cfg3 = synth.seeker_config(num_total_frames=60, frame_height=480, frame_width=640, causal_attention=1)
+    net = build(cfg3)
+    clip = synth.make_clip(1, 60, 480, 640, seed=900)
+    rgb = torch.from_numpy(clip['rgb']).to(dev); qm = torch.from_numpy(synth.make_query_mask(clip, 0, 0)).to(dev)
+    torch.cuda.reset_peak_memory_stats()
+    with torch.no_grad():
+        t = timeit(lambda: net(rgb, qm), 5, 2)
+        om, _ = net(rgb, qm)
+    fl = flops.seeker_forward_flops(1, 60, 30, 40, 768, 12, 12)
+    g = net.seeker.geometry(1)
+    mode = net.seeker.mode
+    qkv = torch.randn(g['M'], 3 * g['D'], device=dev).to(ops.tdtype(mode)); o = torch.empty(g['M'], g['D'], device=dev, dtype=ops.tdtype(mode))
+    shp = ops.attn_shape(mode, 1, g['T'], g['S'], g['D'], g['heads'], 1)
+    t_sp = timeit(lambda: ops.attn_fwd(shp, True, qkv, o, None), 10, 3); t_tm = timeit(lambda: ops.attn_fwd(shp, False, qkv, o, None), 10, 3)
+    out['config3_long_forward'] = dict(workload='configs[3]: T=60 480x640 inference forward, 1 query, causal_attention=1', ms=t * 1e3, tflops=fl['total'] / t / 1e12,
+                                       forward_tflop=fl['total'] / 1e12, attn_frac=12 * (t_sp + t_tm) / t, attn_spatial_us=t_sp * 1e6, attn_temporal_us=t_tm * 1e6,
+                                       attn_tflops=fl['attention'] / (12 * (t_sp + t_tm)) / 1e12, finite=bool(torch.isfinite(om).all()),
+                                       peak_mem_gb=torch.cuda.max_memory_allocated() / 1e9)
+    del net, rgb, qm, om, qkv, o
+    torch.cuda.empty_cache()
+
+    # ---- configs[4]
+    cfg1 = synth.seeker_config(causal_attention=1)
+    net = build(cfg1)
+    kb = synth.to_torch_tree(synth.make_kubric_batch(1, 120, 240, 320, seed=900, n_objects=5))   # one long synthetic video, sub-sampled with strides 1..4
+    rgb_full = kb['kubric_retval']['pv_rgb_tf']; segm = kb['kubric_retval']['pv_segm_tf']
+    rgbs, qms = [], []
+    for stride in (1, 2, 3, 4):                                             # data_utils.py:301-342 usage modes: frame_start 0, stride s
+        idx = torch.arange(30) * stride
+        for q in range(4):
+            rgbs.append(rgb_full[0, :, idx]); m = torch.zeros(1, 30, 240, 320); m[0, 0] = (segm[0, 0, 0] == q + 1).float(); qms.append(m)
+    rgb = torch.stack(rgbs).to(dev); qm = torch.stack(qms).to(dev)
+    with torch.no_grad():
+        t = timeit(lambda: net(rgb, qm), 3, 1)
+        om, _ = net(rgb, qm)
+        ref, _ = so.seeker_forward(so.to_torch_state_dict(synth.make_state_dict(cfg1, 900)), cfg1, rgb[:1].cpu(), qm[:1].cpu())
+    o1 = om[:1].cpu()
+    out['config4_batched_eval'] = dict(workload='configs[4]: 4 queries x 4 temporal strides = 16 eval forwards (T=30 240x320) as one batched call', ms=t * 1e3,
+                                       forwards_per_s=16 / t, mask_agreement=float(((o1 > 0) == (ref > 0)).float().mean()), max_abs_d=float((o1 - ref).abs().max()),
+                                       against='oracle (CPU), first of the 16 forwards', finite=bool(torch.isfinite(om).all()))
+    del net
+    torch.cuda.empty_cache()
+    return out
+
+
 def parity_leg(make_trainer, bf16_net, ref_mask, args, bf16_rate=None):
     """The precision story in the bench line (north_star: mask-logit max|d| < 1e-3 vs the reference):
       * fp16_mode: the same training step with precision='fp16' (the benchmarked kernels compiled for IEEE binary16 storage: three more
@@ -156,6 +251,12 @@ def parity_leg(make_trainer, bf16_net, ref_mask, args, bf16_rate=None):
                     with torch.no_grad():
                         ref, _ = so.seeker_forward(osd, cfg, rgb, qm)
                 cases.append((wseed, cseed, rgb.cuda(), qm.cuda(), ref))
+        # parity at TRAINED-checkpoint magnitudes (tests/golden/g16_cfg2_trained_scale.npz: q / k rows x3, block weights x1.5, mask head scaled
+        # to logit std 5): 16-bit error is relative, so the figure that survives a real checkpoint is max|d| / std and the binary-mask agreement
+        ts = trained_scale_case(cfg, so, synth, args)
+        if ts is not None:
+            sds['ts'] = {k: torch.from_numpy(v).cuda() for k, v in ts['sd'].items()}
+            cases.append(('ts', 900, ts['rgb'].cuda(), ts['qm'].cuda(), ts['ref']))
 
     def max_abs_d(name, net):
         if ref_mask is None:
@@ -168,9 +269,17 @@ def parity_leg(make_trainer, bf16_net, ref_mask, args, bf16_rate=None):
                 net.load_state_dict(sds[wseed], strict=True); net.seeker.invalidate_weight_cache(); loaded = wseed
             with torch.no_grad():
                 om, _ = net(rgb, qm)
-            vals.append(float((om.cpu() - ref).abs().max()))
+            om = om.cpu()
+            if wseed == 'ts':
+                t = out.setdefault('trained_scale', dict(logit_std=float(ref.std()), weights='synth.trained_scale_state_dict(seed 900, qk_gain 3, w_gain 1.5, head scaled to logit std 5)',
+                                                         max_abs_d={}, max_abs_d_rel={}, mask_agreement={}))
+                d = float((om - ref).abs().max())
+                t['max_abs_d'][name] = d; t['max_abs_d_rel'][name] = d / t['logit_std']; t['mask_agreement'][name] = float(((om > 0) == (ref > 0)).float().mean())
+                continue
+            vals.append(float((om - ref).abs().max()))
         out.setdefault('max_abs_d', {})[name] = max(vals)
         out.setdefault('max_abs_d_cases', {})[name] = vals
+        out.setdefault('max_abs_d_rel', {})[name] = max(vals) / float(ref_mask.std())      # relative to the logits' std (0.154 at these weights)
         net.load_state_dict(trained, strict=True); net.seeker.invalidate_weight_cache(); net.train()
 
     max_abs_d('bf16', bf16_net)
@@ -226,7 +335,7 @@ def main():
     args = parse()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(self_launch(args))
-    from tcow_amd import ddp, flops, ops, synth
+    from tcow_amd import ddp, engine, flops, ops, synth
     from tcow_amd.seeker import Seeker
     rank, local_rank, world = ddp.init_distributed()
     if args.launch_selftest:
@@ -343,7 +452,8 @@ def main():
             # what the scaling curve needs to explain itself: how long the compute stream stood still for the gradient all-reduce (rank 0),
             # how much went over xGMI per step in how many collectives, and the spread of the per-rank step times
             res['ddp'] = dict(ddp_stats, ms_per_step_min=min(rank_ms), ms_per_step_max=max(rank_ms), ranks=world,
-                              group_blocks=int(os.environ.get('TCOW_DDP_GROUP', '4')),
+                              group_blocks=engine.group_sizes(args.depth),          # blocks per gradient group, top group first (TCOW_DDP_GROUP)
+                              rccl=rccl_knobs(),
                               cpu_baseline='reported at N = 1 only (rank 0 of a single-GPU run)')
         ref_mask = None
         if not args.no_cpu_baseline and world == 1:
@@ -353,6 +463,11 @@ def main():
                 res['cpu_baseline'] = dict(value=None, unit='clips/s', cores=os.cpu_count(), kind='port', sample=f'failed: {e}')
         if world == 1 and args.precision == 'bf16' and not args.no_parity:
             res.update(parity_leg(make_trainer, net, ref_mask, args, bf16_rate=clips_per_s))
+        if world == 1 and not args.no_config_legs:
+            try:
+                res.update(config_legs(args, dev))
+            except Exception as e:  # reported asides; never lose the headline over them
+                res['config_legs_error'] = repr(e)
         print(json.dumps(res), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

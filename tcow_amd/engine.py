@@ -87,6 +87,23 @@ def _get_weight(module, p, train):
     return Wc, Wt
 
 
+def group_sizes(depth, spec=None):
+    """Blocks per gradient group, TOP group first (the order the backward finishes them): TCOW_DDP_GROUP = one number (every group that
+    size, the bottom one takes the remainder) or a comma list 'a,b,c' (top group a blocks, the next b, ...; the last entry repeats until the
+    blocks are used up, the bottom group is cut to what is left).  Default '5,5,2' at depth 12: the bottom group's gradients only exist
+    when the backward is over, so its all-reduce cannot overlap anything -- it is kept small (2 blocks + embeddings = 76 MB instead of the
+    190 MB of an even 4/4/4 split), and the weight-gradient launches of the 5-block groups fill three whole rounds of the chip with ONE
+    token slice (765 tiles of 256 x 256 on 256 CUs).  Other depths default to groups of four."""
+    if spec is None:
+        spec = os.environ.get('TCOW_DDP_GROUP') or ('5,5,2' if depth == 12 else '4')
+    want = [max(1, int(x)) for x in str(spec).split(',') if x.strip()] or [4]
+    sizes, left, k = [], depth, 0
+    while left > 0:
+        gs = min(want[min(k, len(want) - 1)], left)
+        sizes.append(gs); left -= gs; k += 1
+    return sizes
+
+
 def _fold_on(module):
     return ops.is16(module.mode) and module.attention_type == 'divided_space_time' and os.environ.get('TCOW_FOLD', '1') != '0'
 
@@ -559,18 +576,19 @@ def run_backward(module, sv, params, d_mask, d_flags):
     Co = module.output_channels
     have_flags = module.flag_channels > 0 and d_flags is not None and d_flags.numel() > 0
     head_idx = ([nb, nb + 1] if module.norm_embeddings else []) + [nb + 2, nb + 3] + ([nb + 4, nb + 5] if have_flags else [])
-    # Gradient buckets = GROUPS of transformer blocks (TCOW_DDP_GROUP blocks each, default 4; the top group also carries the output heads, the
-    # bottom one the embeddings): 3 all-reduces of ~150-190 MB at depth 12 instead of 14 of ~38 MB -- each collective is a window in which
+    # Gradient buckets = GROUPS of transformer blocks (group_sizes(): TCOW_DDP_GROUP, default 5 / 5 / 2 from the top at depth 12; the top group
+    # also carries the output heads, the bottom one the embeddings): 3 all-reduces of ~75-190 MB at depth 12 instead of 14 of ~38 MB -- each collective is a window in which
     # resident RCCL workgroups push the one-workgroup-per-CU GEMMs into an extra round (profiles/r02_cu_contention.txt), so fewer, larger
     # ones.  The WEIGHT-GRADIENT GEMMs of a group are issued together at its end as well (one grouped launch over 28 problems = 612 tiles of
     # 256 x 256 at ViT-B): so many tiles fill whole rounds of the chip with TWO token slices instead of five, i.e. 60 % less f32 partial-sum
     # traffic in the GEMM and in the fold (tcow_tn_group_slices); nothing in the backward chain waits for a weight gradient, and the bucket
     # is not published before the group's end anyway.  Their operands (a block's activations and output gradients) stay alive that long.
-    gs = max(1, int(os.environ.get('TCOW_DDP_GROUP', '4')))
     group_lo = {}                                   # block index -> first block of its group
-    for hi_ in range(depth, 0, -gs):
-        for j in range(max(0, hi_ - gs), hi_):
-            group_lo[j] = max(0, hi_ - gs)
+    hi_ = depth
+    for gs in group_sizes(depth):
+        for j in range(hi_ - gs, hi_):
+            group_lo[j] = hi_ - gs
+        hi_ -= gs
     top_lo = group_lo[depth - 1]
     # The folded projection's three gradients per block (tproj.weight, tproj.bias, tfc.weight) come out of small products that are worth
     # batching over ALL blocks (a launch of three 768^3 problems is pure latency: 35 us whether it carries 3 problems or 12), so they form one

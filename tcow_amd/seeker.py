@@ -218,11 +218,19 @@ class QueryMaskTracker(nn.Module):
             from . import engine
             engine.refresh_weights(self)       # all operand copies of the next step in one launch
 
-    def _apply(self, fn, *a, **k):
+    def _drop_operand_caches(self):
+        """Everything derived from the parameters' storage: 16-bit W / W^T copies, their registries and pointer tables, the folded
+        products and the persistent gradient buffers.  They are keyed by id(parameter), which survives a `.data` swap."""
         self._wcache = {}
         self.__dict__.pop('_wreg', None); self.__dict__.pop('_wtab', None); self.__dict__.pop('_foldreg', None)
         self._gbufs = {}
-        return super()._apply(fn, *a, **k)
+
+    def _apply(self, fn, *a, **kw):
+        # .to() / .cuda() / .half() swap the parameters' .data (neither id() nor ._version changes): every cache that holds device
+        # pointers or copies of the old storage must go, and so must the cached parameter list
+        self._drop_operand_caches()
+        self.invalidate_param_cache()
+        return super()._apply(fn, *a, **kw)
 
     @property
     def vit(self):
@@ -248,10 +256,6 @@ class QueryMaskTracker(nn.Module):
 
     def invalidate_param_cache(self):
         self.__dict__.pop('_param_list_cache', None)
-
-    def _apply(self, fn, *a, **kw):
-        self.invalidate_param_cache()
-        return super()._apply(fn, *a, **kw)
 
     def _param_list_uncached(self):
         v = self.vit

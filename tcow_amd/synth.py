@@ -97,6 +97,30 @@ def make_state_dict(cfg, seed=900):
     return out
 
 
+def trained_scale_state_dict(sd, qk_gain=3.0, w_gain=1.5, head_gain=1.0):
+    """A state dict with the MAGNITUDES of a trained checkpoint instead of the init's (the synthetic weights are trunc-normal(0.02): attention
+    scores of std ~0.3, i.e. near-uniform softmax rows, and mask logits of std ~0.15 -- a trained TCOW checkpoint has peaked attention and
+    logits of |x| ~ 10).  The q and k rows of every qkv weight / bias are multiplied by `qk_gain` (scores x qk_gain^2), every other Linear
+    weight of the blocks (v rows, proj, temporal_fc, fc1, fc2) by `w_gain`, and the mask head (tracker_post_linear weight AND bias, so the
+    logits scale exactly linearly) by `head_gain`.  Used by the parity-at-scale fixture g16 and the bench's `trained_scale` case: 16-bit
+    error is relative, so what must be shown is that max|d| / std(logits) and the binary masks hold when the logits are 30x larger."""
+    out = OrderedDict()
+    for k, v in sd.items():
+        v = np.array(v, dtype=np.float32, copy=True)
+        leaf = k.split('.')[-1]
+        if '.qkv.' in k:
+            D = v.shape[0] // 3
+            v[:2 * D] *= np.float32(qk_gain)
+            if leaf == 'weight':
+                v[2 * D:] *= np.float32(w_gain)
+        elif leaf == 'weight' and ('.blocks.' in k) and v.ndim == 2:
+            v *= np.float32(w_gain)
+        elif k.startswith('seeker.tracker_post_linear.'):
+            v *= np.float32(head_gain)
+        out[k] = np.ascontiguousarray(v)
+    return out
+
+
 def make_clip(B, T, H, W, seed=900, n_objects=4):
     """Synthetic Kubric-shaped clip: rgb ~ U[0,1) (B,3,T,H,W) f32 plus K moving rectangles drawn in
     painter's order. Returns dict with rgb, visible segmentation `segm` (B,1,T,H,W) uint8 (0 = bg,

@@ -84,3 +84,65 @@ def test_bench_self_launches_n_ranks():
     env2 = dict(env, WORLD_SIZE='1', RANK='0')
     bad = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1'], env=env2, capture_output=True, text=True, timeout=300)
     assert bad.returncode != 0 and 'WORLD_SIZE' in (bad.stderr + bad.stdout)
+
+
+def test_group_sizes_spec():
+    """TCOW_DDP_GROUP: one number or a comma list, top group first; the bottom group is small by default (its all-reduce cannot overlap)."""
+    from tcow_amd.engine import group_sizes
+    assert group_sizes(12, '4') == [4, 4, 4] and group_sizes(12, '5') == [5, 5, 2] and group_sizes(12, '5,5,2') == [5, 5, 2]
+    assert group_sizes(12, '6,3') == [6, 3, 3] and group_sizes(4, '2') == [2, 2] and group_sizes(3, '8') == [3] and group_sizes(12, '12') == [12]
+    assert sum(group_sizes(24, None if 'TCOW_DDP_GROUP' not in os.environ else '4')) == 24
+    assert group_sizes(12, '5,5,2') == group_sizes(12, None) or 'TCOW_DDP_GROUP' in os.environ
+
+
+def test_backward_publishes_only_finished_buckets():
+    """CPU guard on engine.run_backward's ordering (the GPU tests check the values): every publish() of a block group must come after the
+    flush_pending() that issues the group's deferred weight-gradient GEMMs and LayerNorm folds, the late fold bucket after
+    finish_fold_group(), and `return grads` after grad_hook.finish().  Checked on the function's AST: for each publish call the nearest
+    preceding statement that touches `pending` / `ln_jobs` work must be the flush."""
+    import ast
+    import inspect
+    from tcow_amd import engine
+    src = inspect.getsource(engine.run_backward)
+    tree = ast.parse(src)
+    fn = tree.body[0]
+    calls = []                                       # (lineno, name) of the calls that matter, in source order, nested defs excluded
+    class V(ast.NodeVisitor):
+        def visit_FunctionDef(self, node):
+            if node is fn:
+                self.generic_visit(node)
+        def visit_Call(self, node):
+            f = node.func
+            name = f.id if isinstance(f, ast.Name) else (f.attr if isinstance(f, ast.Attribute) else None)
+            if name in ('publish', 'flush_pending', 'finish_fold_group', 'finish', 'linear_bwd', 'layernorm_bwd'):
+                calls.append((node.lineno, name))
+            self.generic_visit(node)
+    V().visit(tree)
+    calls.sort()
+    names = [n for _, n in calls]
+    pubs = [i for i, n in enumerate(names) if n == 'publish']
+    assert len(pubs) == 3                                                   # block groups above the bottom one, the late fold bucket, the bottom group
+    # (1) group publish inside the block loop: the last deferred producer before it is followed by a flush
+    i = pubs[0]
+    last_producer = max(j for j in range(i) if names[j] in ('linear_bwd', 'layernorm_bwd'))
+    assert 'flush_pending' in names[last_producer:i], names
+    # (2) the late bucket: behind finish_fold_group()
+    assert names[pubs[1] - 1] == 'finish_fold_group', names
+    # (3) the bottom bucket, then the drain, then nothing else
+    assert names[pubs[2] + 1:] == ['finish'], names
+    ret = [n.lineno for n in ast.walk(fn) if isinstance(n, ast.Return) and isinstance(n.value, ast.Name) and n.value.id == 'grads']
+    assert ret and ret[-1] > calls[-1][0]
+    # the bottom group's own weight gradients: the block loop's flush happens for i == 0 too (group_lo[0] == 0), before the loop ends
+    assert 'if group_lo[i] == i or len(pending) + 8 > tn_group_max:' in src
+
+
+def test_hook_sees_complete_buckets_with_a_fake_engine_run():
+    """The same ordering, dynamically: run engine.run_backward's bucket bookkeeping with stub ops and a recording hook is not possible without
+    the GPU library, so this drives GradSync the way the backward does and checks that finish() leaves nothing pending before gradients are
+    handed out (single process: the hook is a no-op but its state machine still runs)."""
+    from tcow_amd import ddp
+    sync = ddp.GradSync(1, force=False)
+    for tag in ('g7', 'g2', 'fold', 'g0'):
+        sync(tag, torch.ones(3))
+    sync.finish()
+    assert sync.pending == [] and sync.deferred == [] and sync.steps == 1

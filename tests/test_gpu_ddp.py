@@ -133,3 +133,37 @@ def test_rccl_world_of_one_runs_the_real_buckets(cuda, monkeypatch):
         assert float(flat[12345]) == 12345.0
     finally:
         dist.destroy_process_group()
+
+
+def test_full_size_two_rank_bench_line_on_one_gpu(cuda):
+    """The N > 1 bench line of BASELINE configs[2] (DDP, one clip per rank, T=30 240x320, 12 blocks) executed at HEAD: `python bench.py --gpus 2`
+    starts its two ranks itself; both share this box's one GPU (bench.py maps local_rank % device_count) and reduce over gloo.  Exercises
+    bench.py's world > 1 branches (barriers, max over ranks, the `ddp` block) and engine.run_backward's bucket publishing with the real
+    buckets -- everything the driver's SCALE run executes except RCCL's wire.  The line is kept under gpurun_out/ (copied to profiles/)."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    from tcow_amd import engine
+    env = dict(os.environ)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'TCOW_DDP_GROUP'):
+        env.pop(k, None)
+    env['TCOW_DIST_BACKEND'] = 'gloo'
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--no-parity'],
+                         env=env, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+    try:
+        os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+        with open(os.path.join(ROOT, 'gpurun_out', 'bench_2rank_gloo_one_gpu.json'), 'w') as f:
+            f.write(json.dumps(res) + '\n')
+    except OSError:
+        pass
+    assert res['n_gpus'] == 2 and res['ranks_seen'] == 2 and res['steps'] == 3 and res['scaling'] == 'weak'
+    assert res['value'] > 0 and np.isfinite(res['final_loss']) and res['config']['parallelism'] == 'dp2'
+    d = res['ddp']
+    sizes = engine.group_sizes(12)
+    assert d['ranks'] == 2 and d['group_blocks'] == sizes and d['buckets'] == len(sizes) + 1          # block groups + the folded projection's late bucket
+    assert abs(d['allreduce_bytes'] - 488.6e6) < 2e6                                                # every trained parameter once, f32
+    assert d['allreduce_exposed_ms'] >= 0.0 and 0 < d['ms_per_step_min'] <= d['ms_per_step_max'] and abs(d['ms_per_step_max'] - res['ms_per_step']) < 1e-6
+    assert 'cpu_baseline' not in res and 'roofline' in res

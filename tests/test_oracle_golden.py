@@ -80,6 +80,40 @@ def test_config2_full_size_matches_reference():
     _check_summary('g4_cfg2_T30_240x320')
 
 
+def trained_scale_inputs(meta):
+    """Weights / clip of the g16 fixture: the seed's synthetic state dict pushed to trained magnitudes (synth.trained_scale_state_dict) with
+    the head gain the generator calibrated against the reference."""
+    cfg = meta['cfg']
+    sd = synth.trained_scale_state_dict(synth.make_state_dict(cfg, meta['seed']), meta['qk_gain'], meta['w_gain'], meta['head_gain'])
+    clip = synth.make_clip(1, cfg['num_total_frames'], cfg['frame_height'], cfg['frame_width'], seed=meta['seed'])
+    return cfg, sd, torch.from_numpy(clip['rgb']), torch.from_numpy(synth.make_query_mask(clip, 0, 0))
+
+
+def mask_bits(om, frames):
+    """Binary masks (logit > 0) of the given frames, bit-packed as in the g16 fixture."""
+    return np.packbits((np.asarray(om)[:, :, list(frames)] > 0).reshape(-1))
+
+
+def test_trained_scale_full_size_matches_reference():
+    """g16: BASELINE configs[1] geometry with weights of trained magnitude (peaked attention, logit std 5): the restatement tracks the
+    reference at the same RELATIVE bound as at std 0.154 (TOL / 0.154 per unit of std), and their binary masks agree except where the
+    reference's own logit is within rounding of zero."""
+    torch.set_num_threads(8)
+    meta, g = load_golden('g16_cfg2_trained_scale')
+    cfg, sd, rgb, qm = trained_scale_inputs(meta)
+    with torch.no_grad():
+        om, fl = so.seeker_forward(so.to_torch_state_dict(sd), cfg, rgb, qm)
+    std = float(g['logit_std'])
+    assert abs(float(om.std()) - std) < 1e-3 and 4.5 < std < 5.5
+    pooled, fsum, fmax = summarise(om)
+    rel = TOL * std / 0.154
+    assert np.abs(pooled - g['pooled']).max() < rel and np.abs(fmax - g['frame_absmax']).max() < rel
+    assert np.abs(fl.numpy() - g['output_flags']).max() < 1e-4
+    bits = mask_bits(om.numpy(), meta['mask_frames'])
+    differ = np.unpackbits(bits ^ g['mask_bits']).mean()
+    assert differ < 1e-5                                                   # a handful of pixels whose reference logit is ~1e-6
+
+
 @pytest.mark.parametrize('name', ['g11_depth18', 'g11_depth24', 'g10_pretrained'])
 def test_depth_variants_and_pretrained_forward_match_reference(name):
     """V0: the reference's native depth-18 / depth-24 geometries (vit.py:433-447); g10: weights that went through the reference's
