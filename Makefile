@@ -16,7 +16,7 @@ all: $(LIB) $(LIB16)
 
 # (attention: no NaN arithmetic on the path -- lets fmaxf chains become v_max3_f32 without canonicalising v_max instructions)
 $(OBJ)/attention_bf16.hip.o: EXTRA := -fno-honor-nans -fno-slp-vectorize
-$(OBJ)/%.hip.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/gemm_f32.h $(CSRC)/gemm_nt_common.h include/tcow_hip.h
+$(OBJ)/%.hip.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/gemm_f32.h $(CSRC)/gemm_nt_common.h $(CSRC)/attention_tiles.h $(CSRC)/attention_common.h include/tcow_hip.h
 	@mkdir -p $(OBJ)
 	$(HIPCC) $(HIPFLAGS) $(EXTRA) -x hip -c $< -o $@
 
@@ -28,7 +28,7 @@ $(LIB): $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
 
 $(OBJ16)/attention_bf16.hip.o: EXTRA := -fno-honor-nans -fno-slp-vectorize
-$(OBJ16)/%.hip.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/gemm_f32.h $(CSRC)/gemm_nt_common.h include/tcow_hip.h
+$(OBJ16)/%.hip.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/gemm_f32.h $(CSRC)/gemm_nt_common.h $(CSRC)/attention_tiles.h $(CSRC)/attention_common.h include/tcow_hip.h
 	@mkdir -p $(OBJ16)
 	$(HIPCC) $(HIPFLAGS) $(EXTRA) -DTCOW_FP16 -x hip -c $< -o $@
 
@@ -76,3 +76,11 @@ build/ubench_tn_ab: tools/ubench_tn_ab.hip $(CSRC)/gemm_bf16.hip $(CSRC)/gemm_nt
 build/ubench_mfma: tools/ubench_mfma.hip
 	@mkdir -p build
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -x hip $< -o $@
+
+build/ubench_p4_ab%: tools/ubench_p4.hip tools/attn_fwd_p4.hip $(CSRC)/attention_tiles.h $(CSRC)/common.h
+	@mkdir -p build
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fno-honor-nans -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form -Wno-unused-result -DP4_AB=$* -x hip $< -o $@
+
+build/ubench_p4: tools/ubench_p4.hip tools/attn_fwd_p4.hip $(CSRC)/attention_tiles.h $(CSRC)/common.h
+	@mkdir -p build
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fno-honor-nans -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form -Wno-unused-result -x hip $< -o $@

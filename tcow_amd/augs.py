@@ -315,8 +315,13 @@ def apply_augs(modalities, augs_params, out_h, out_w, center_crop=False, draws_i
             draws = draws_in if draws_in is not None else photometric_draws(augs_params)
             fi, ys, xs = crop_maps(augs_params, H, W, out_h, out_w, center_crop)
             y0, x0, h, w = center_rect(H, W, out_h, out_w, center_crop)
-            img = photometric_hip(fr.float(), fi, (y0, x0, h, w), draws)            # frame selection + centre crop + the three operators: one kernel
             ident = np.arange(len(fi), dtype=np.int32)
+            if fr.dtype == torch.float32 and fr.is_contiguous():
+                img = photometric_hip(fr, fi, (y0, x0, h, w), draws)               # frame selection + centre crop + the three operators: one kernel
+            else:
+                # a half / double / strided source: convert only the selected frames and the cropped window, never the whole clip
+                sel = fr[:, torch.as_tensor(np.asarray(fi, dtype=np.int64), device=fr.device), y0:y0 + h, x0:x0 + w].to(torch.float32).contiguous()
+                img = photometric_hip(sel, ident, (0, 0, h, w), draws)
             if len(ys) == out_h and len(xs) == out_w:
                 out[name] = gather_clip(img, ident, (ys - y0).astype(np.int32), (xs - x0).astype(np.int32))
             else:

@@ -57,7 +57,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_c2_kernel(NtParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc16[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // ---- direct-to-LDS loads through BUFFER descriptors (bounds-checked: rows past M / N read as zeros).  One load instruction moves one
+    // ---- direct-to-LDS loads through BUFFER descriptors (bounds-checked: rows past M / N read as zeros -- the tile's row offset travels in the
+    // SCALAR offset, and on gfx950 the range check of a raw buffer covers voffset + soffset: tools/probe_soffset.hip,
+    // profiles/r05_probe_soffset.txt; a load whose sum passes num_records returns zeros and makes no memory request).  One load instruction moves one
     // SUBTILE = 8 rows x 128 B (k = 64): whole 128-byte cache lines.  (profiles/r04_c2_whole_line_probe.txt: with 16 rows x 64 B pieces --
     // the k = 32 planes of the 320 kernel's loop -- every line crosses the L2 -> L1 path twice, half of it unused each time, and the load
     // stream of a GEMM saturates the L2s at 14 TB/s of useful bytes; whole-line pieces move the same bytes in 0.57 of the time.)
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_c2_kernel(NtParams p) {
     do {                                                                                                                                  \
         const uint32_t bo_ = (PAR) * D_A;                                                                                                 \
         const uint32_t kb_ = (uint32_t)((kt) + 1) * 128u, kb2_ = (uint32_t)((kt) + 2) * 128u;                                             \
-        /* no next tile: the PER-LANE offset (the one the range check covers) is sent past the descriptor = zeros, no traffic */          \
+        /* no next tile: the per-lane offset is sent past the descriptor = zeros, no traffic */                                           \
         const uint32_t wv_ = (LOAD) ? w_vo : 0x80000000u, av_ = (LOAD2) ? a_vo : 0x80000000u;                                             \
         const bool ld_ = !(AB & 2);                                                                                                       \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); C2_PIN;                                                                        \

@@ -507,7 +507,9 @@ __global__ void __launch_bounds__(256) query_tables_kernel(QueryTablesArgs a) {
     if (f < a.n_counts) a.counts[f] = 0;                                  // (n_counts <= n: 1 + 2 Q <= B Q T checked by the caller)
     if (f >= n) return;
     const int t = f % a.T, bq = f / a.T, b = bq / a.Q;
-    const int s = (int)a.sel[bq];
+    int s = (int)a.sel[bq];
+    const int smax = (a.K < a.M ? a.K : a.M) - 1;                         // (callers validate 0 <= sel < min(K, M) on the host -- pipeline.forward_kubric; a bad index
+    s = s < 0 ? 0 : (s > smax ? smax : s);                                //  handed to the C ABI directly is clamped rather than read through)
     if (t == 0) a.query_idx[bq] = s;
     const float* of = a.occl_fracs + (((size_t)b * a.K + s) * a.T + t) * 3;
     const float* frame = a.dag + ((size_t)b * a.T + t) * a.M * a.M * 3;

@@ -130,7 +130,14 @@ class SeekerPipeline:
         if sel_query_inds is None:
             sel_query_inds = sample_query_inds(B, Qs, kr['pv_inst_count'], des, self.phase, self.rng)
         pos_count = None; tab = None
-        if segm.is_cuda and segm.dtype == torch.uint8 and div.dtype == torch.uint8 and (H * W) % 16 == 0:
+        sel_host = sel_query_inds if not sel_query_inds.is_cuda else None
+        if sel_host is not None and sel_host.numel() and (int(sel_host.min()) < 0 or int(sel_host.max()) >= min(occl_fracs.shape[1], dag.shape[2])):
+            # the tensor path below would raise on such an index (occl_fracs[b, sel], dag[b, :, sel]); the table kernel reads through it
+            raise IndexError(f'query instance index out of range: {sel_host.tolist()} with {occl_fracs.shape[1]} trajectories / {dag.shape[2]} instances')
+        Mi = div.shape[1]
+        # (the table kernel wants B*Qs*T >= 1 + 2 Qs threads for its counters and instance ids that fit a byte: otherwise the tensor path)
+        if (segm.is_cuda and segm.dtype == torch.uint8 and div.dtype == torch.uint8 and (H * W) % 16 == 0 and B * Qs * T >= 1 + 2 * Qs and B * Qs * T < 65536
+                and Mi <= 255):
             # one HIP pass over the segmentation maps for all queries (tcow_build_masks); the per-frame occluder / container choice
             # stays a handful of tensor ops on (B,Qs,T,M)-sized data
             from . import ops
