@@ -862,11 +862,8 @@ static void set_lds_attr(K kernel, int bytes) {
 // nt = number of 32-position tiles.  Workgroup-shared (spatial) sequences and temporal sequences of more than 64 positions take the streaming
 // kernels; shorter temporal sequences the wave-private ones.  (The resident / persistent forward variants of round 3 are in
 // tools/attn_fwd_variants.inc, the whole-sequence-resident SHARED = true instantiations of the *_mfma kernels are no longer built.)
-// streaming kernels: tiles per LDS chunk -- 5 when that saves a chunk round (nt = 10: two rounds instead of three), else 4; TCOW_ATTN_CH=4|5 forces
-static bool stream_ch5(int nt) {
-    static const int v = [] { const char* e = getenv("TCOW_ATTN_CH"); return e ? atoi(e) : 0; }();
-    return v == 5 || (v != 4 && (nt + 4) / 5 < (nt + 3) / 4);
-}
+// streaming backward kernels: tiles per LDS chunk -- 5 when that saves a chunk round (nt = 10: two rounds instead of three), else 4
+static bool stream_ch5(int nt) { return (nt + 4) / 5 < (nt + 3) / 4; }
 
 bool tcow_attn_mfma_supported(const SeqDesc& d, bool shared) {
     (void)d; (void)shared;
@@ -914,9 +911,9 @@ int tcow_attn_mfma_bwd(hipStream_t st, const SeqDesc& d, bool shared, const void
     float2* ld = (float2*)ws;
     const long total = (long)pairs * nt * 32;
     int blocks = cdiv(total, 256); if (blocks > 8192) blocks = 8192;
-    // spatial sequences of up to ten tiles: the one-kernel backward (TCOW_ATTN_ONE=0: the two streaming kernels, A/B)
-    static const int one = [] { const char* e = getenv("TCOW_ATTN_ONE"); return e ? atoi(e) : 1; }();
-    if (shared && one && nt <= ONE_MAX_NT && nt >= 4) {
+    // spatial sequences of four to ten tiles: the one-kernel backward (221 -> 150 us at S = 301 against the two streaming kernels, which longer
+    // sequences keep)
+    if (shared && nt <= ONE_MAX_NT && nt >= 4) {
         set_lds_attr(attn_bwd_one_kernel, ONE_LDS);
         hipLaunchKernelGGL(attn_bwd_one_kernel, dim3(pairs), dim3(768), ONE_LDS, st, d, nt, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv);
         TCOW_CHECK_LAUNCH();

@@ -51,104 +51,6 @@ __device__ __forceinline__ float4 epi_bias(const NtParams& p, int tid, int n0) {
     return (p.bias && gn < p.N) ? ld4(p.bias + gn) : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
-// ---- v2: same 128x128 tile, but K walked 32 at a time through a 4-deep LDS ring with COUNTED waits:
-// the loads of slice kt+3 are issued in iteration kt and only slice kt+1 is waited for (s_waitcnt vmcnt(8) leaves
-// two slices = 8 wave-loads in flight across the raw s_barrier), so L2/HBM latency spans three compute phases
-// instead of one.  LDS rows are 64 B (4 chunks); chunk c of row r sits at c ^ ((r>>2)&3): conflict-free b128 reads.
-constexpr int R_BK = 32;
-constexpr int R_TILE = 128 * 64;            // 8 KiB per operand per slice
-constexpr int R_STAGE = 2 * R_TILE;
-constexpr int R_NS = 4;
-
-__global__ __launch_bounds__(256, 2) void gemm_nt_bf16_ring_kernel(NtParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int l31 = lane & 31, hi = lane >> 5;
-    const int nblk = p.tiles_m * p.tiles_n;
-    const int pid = xcd_remap(blockIdx.x, nblk);
-    const int pm = pid / p.tiles_n, pn = pid - pm * p.tiles_n;
-    const int m0 = pm * BM, n0 = pn * BN;
-    const float4 b4 = epi_bias(p, tid, n0);
-
-    // wave w issues wave-loads 2w, 2w+1 of each operand per slice; a wave-load covers 16 tile rows x 64 B
-    const bf16_t* a_src[2];
-    const bf16_t* w_src[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int r = (wave * 2 + j) * 16 + (lane >> 2);
-        const int c = (lane & 3) ^ ((r >> 2) & 3);
-        int gm = m0 + r; gm = gm < p.M ? gm : p.M - 1;
-        int gn = n0 + r; gn = gn < p.N ? gn : p.N - 1;
-        a_src[j] = p.A + (size_t)gm * p.lda + c * 8;
-        w_src[j] = p.W + (size_t)gn * p.ldw + c * 8;
-    }
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int nk = p.K / R_BK;
-    auto issue = [&](int kt) {
-        char* sa = smem + (kt & (R_NS - 1)) * R_STAGE;
-        char* sw = sa + R_TILE;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            glds16(a_src[j] + (size_t)kt * R_BK, sa + (wave * 2 + j) * 1024);
-            glds16(w_src[j] + (size_t)kt * R_BK, sw + (wave * 2 + j) * 1024);
-        }
-    };
-    auto wait_slices_in_flight = [&](int n) {   // wait until at most n slices (4 wave-loads each) are still outstanding
-        if (n >= 2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-        else if (n == 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    };
-    int a_off[2], w_off[2], a_sw[2], w_sw[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int ra = wm * 64 + i * 32 + l31, rw = wn * 64 + i * 32 + l31;
-        a_off[i] = ra * 64; a_sw[i] = (ra >> 2) & 3;
-        w_off[i] = rw * 64; w_sw[i] = (rw >> 2) & 3;
-    }
-
-    const int pre = nk < 3 ? nk : 3;
-    for (int s = 0; s < pre; ++s) issue(s);
-    wait_slices_in_flight(pre - 1);
-    __builtin_amdgcn_s_barrier();
-
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 3 < nk) issue(kt + 3);
-        const char* sa = smem + (kt & (R_NS - 1)) * R_STAGE;
-        const char* sw = sa + R_TILE;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int c = 2 * ks + hi;
-            bf16x8 fa[2], fw[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                fa[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sa + a_off[i] + ((c ^ a_sw[i]) << 4)));
-                fw[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sw + w_off[i] + ((c ^ w_sw[i]) << 4)));
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = TCOW_MFMA_32x32x16_H16(fa[i], fw[j], acc[i][j], 0, 0, 0);
-        }
-        // slice kt+1 must have landed; slices kt+2, kt+3 (if issued) may stay in flight across the barrier
-        int ahead = nk - 2 - kt; ahead = ahead > 2 ? 2 : (ahead < 0 ? 0 : ahead);
-        wait_slices_in_flight(ahead);
-        __builtin_amdgcn_s_barrier();
-    }
-    asm volatile("" ::: "memory");
-    nt_epilogue(p, smem, acc, b4, tid, wm, wn, l31, hi, m0, n0);
-}
-
 // ---- 256 x 256 tile, 8 waves (2 x 4, 128 x 64 each).  PMC on the 128-tile kernel (profiles/r01_pmc_gemm_units.txt): zero LDS bank
 // conflicts, LdsUtil ~22 %, MFMA pipe busy 41-48 %, half of all wave cycles parked in the vmcnt/barrier wait and the texture-address
 // path 58-68 % busy -- the 128 x 128 x 64 step pulls 32 KiB per workgroup per 2.1 MFLOP through the global->LDS path and is bound
@@ -298,9 +200,10 @@ constexpr int C_WTILE = C_BN * 128;             // 32 KiB
 constexpr int C_STAGE = C_ATILE + C_WTILE;      // 72 KiB
 constexpr int C_LDS = 2 * C_STAGE;              // 144 KiB
 
-// ML = 1: the main loop first built stand-alone in tools/gemm_p8.hip (16x16x32 MFMAs on 1 KiB subtiles, four phases per K tile, wave rows staggered by a barrier) in front of the
-// same epilogues: the accumulators then sit as [10 row blocks of 16][4 column blocks of 16] and only the staging step differs.
-template <typename E, int ML = 0>
+// The main loop was first built stand-alone in tools/gemm_p8.hip (16x16x32 MFMAs on 1 KiB subtiles, four phases per K tile, wave rows staggered by a
+// barrier): the accumulators sit as [10 row blocks of 16][4 column blocks of 16] (ML = 1 form of the shared epilogue; the round-2 two-stage loop on
+// 32x32x16 MFMAs -- ML = 0, 7-12 % slower on every shape, profiles/r03_gemm_shapes.txt -- is gone).
+template <typename E, int ML = 1>
 __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_320_kernel(NtParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -325,7 +228,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_320_kernel(NtParams p) {
     for (int i = 0; i < 10; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc16[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if constexpr (ML == 1) {
+    static_assert(ML == 1, "one main loop");
+    {
         // (see tools/gemm_p8.hip for the layout and the ordering argument; BM = 320: 20 row blocks, 5 per wave and phase)
         constexpr int ARB = 20, RBH = 5, A_PLANE = ARB * 1024, KH = A_PLANE + 16 * 1024, KTILE = 2 * KH, NA = 3;
         const int wr = wm, wc = wn;
@@ -417,92 +321,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_320_kernel(NtParams p) {
         if (wr == 0) __builtin_amdgcn_s_barrier();
 #undef P8_DSR
 #undef P8_PHASE_TAIL
-    } else {
-    // wave w issues wave-loads 5w..5w+4 of A (8 rows x 128 B each) and 4w..4w+3 of W per stage; 32-bit element offsets from the
-    // tile's first row keep the nine addresses in nine registers
-    const bf16_t* a_base = p.A + (size_t)m0 * p.lda;
-    const bf16_t* w_base = p.W + (size_t)n0 * p.ldw;
-    uint32_t a_src[5], w_src[4];
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        const int r = (wave * 5 + j) * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ ((r >> 1) & 7);
-        const int rr = m0 + r < p.M ? r : p.M - 1 - m0;
-        a_src[j] = (uint32_t)(rr * p.lda + c * 8);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int r = (wave * 4 + j) * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ ((r >> 1) & 7);
-        const int rr = n0 + r < p.N ? r : p.N - 1 - n0;
-        w_src[j] = (uint32_t)(rr * p.ldw + c * 8);
-    }
-    const int nk = p.K / BK;
-    auto issue = [&](int kt, int stage) {
-        char* sa = smem + stage * C_STAGE;
-        char* sw = sa + C_ATILE;
-#pragma unroll
-        for (int j = 0; j < 5; ++j) glds16(a_base + a_src[j] + (size_t)kt * BK, sa + (wave * 5 + j) * 1024);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) glds16(w_base + w_src[j] + (size_t)kt * BK, sw + (wave * 4 + j) * 1024);
-    };
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(LDS_PTR(char))smem;
-    uint32_t a_ad[4], w_ad[4];
-    {
-        const int ra = wm * 160 + l31, rw = wn * 64 + l31;       // rows 32 apart share the swizzle ((r>>1)&7)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            a_ad[ks] = lds0 + ra * 128 + (((2 * ks + hi) ^ ((ra >> 1) & 7)) << 4);
-            w_ad[ks] = lds0 + C_ATILE + rw * 128 + (((2 * ks + hi) ^ ((rw >> 1) & 7)) << 4);
-        }
-    }
-    u32x4 fa[2][5], fw[2][2];
-#define TCOW_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
-#define TCOW_READ_FRAGS(buf, ks, so)                                                                        \
-    do {                                                                                                    \
-        const uint32_t aa = a_ad[ks] + (so), ww = w_ad[ks] + (so);                                          \
-        TCOW_DSR(fw[buf][0], ww, 0); TCOW_DSR(fw[buf][1], ww, 4096);                                        \
-        TCOW_DSR(fa[buf][0], aa, 0); TCOW_DSR(fa[buf][1], aa, 4096); TCOW_DSR(fa[buf][2], aa, 8192);        \
-        TCOW_DSR(fa[buf][3], aa, 12288); TCOW_DSR(fa[buf][4], aa, 16384);                                   \
-    } while (0)
-#define TCOW_MFMA10(buf)                                                                                                  \
-    _Pragma("unroll") for (int i = 0; i < 5; ++i)                                                                        \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                    \
-            acc[i][j] = TCOW_MFMA_32x32x16_H16(__builtin_bit_cast(bf16x8, fw[buf][j]), __builtin_bit_cast(bf16x8, fa[buf][i]), acc[i][j], 0, 0, 0)
-
-    issue(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    TCOW_READ_FRAGS(0, 0, 0u);
-    for (int kt = 0; kt < nk; ++kt) {
-        const uint32_t so = (uint32_t)(kt & 1) * C_STAGE;
-        if (kt + 1 < nk) issue(kt + 1, (kt & 1) ^ 1);
-        TCOW_READ_FRAGS(1, 1, so);
-        asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        TCOW_MFMA10(0);
-        TCOW_READ_FRAGS(0, 2, so);
-        asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        TCOW_MFMA10(1);
-        TCOW_READ_FRAGS(1, 3, so);
-        asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        TCOW_MFMA10(0);
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        TCOW_MFMA10(1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (kt + 1 < nk) TCOW_READ_FRAGS(0, 0, (uint32_t)((kt + 1) & 1) * C_STAGE);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#undef TCOW_DSR
-#undef TCOW_READ_FRAGS
-#undef TCOW_MFMA10
-
     }
     wave_tile_epilogue_160x64<E, ML>(p, smem + wave * (64 * 68 * 4), acc, acc16, lane, m0 + wm * 160, n0 + wn * 64);
 }
@@ -606,30 +424,25 @@ int tcow_gemm_nt_bf16(hipStream_t stream, const tcow_gemm_args* a) {
     NtParams p = nt_params_from_args(a);
     p.tiles_m = cdiv(a->M, BM); p.tiles_n = cdiv(a->N, BN);
     TCOW_CHECK_ARG(a->tile == 0 || a->tile == 128 || a->tile == 160 || a->tile == 256 || a->tile == 320, "tcow_gemm_nt(bf16): tile must be 0, 128, 160, 256 or 320 (got %d)", a->tile);
-    static const int big = [] { const char* e = getenv("TCOW_GEMM_BIG"); return e ? atoi(e) : 1; }();
-    static const int wide = [] { const char* e = getenv("TCOW_GEMM_320"); return e ? atoi(e) : 1; }();
     {
         // the 320 x 256 tile runs one workgroup per CU: take it when its tiles fill whole rounds of the 256 CUs
         const long t320 = (long)cdiv(a->M, C_BM) * cdiv(a->N, C_BN);
         const long rounds = (t320 + 255) / 256;
         const bool fills = t320 * 100 >= rounds * 256 * 80;   // (measured: still ahead of the 256 / 128 tiles at 88 % -- configs[3], configs[4])
         // the 160 x 256 tile at two workgroups per CU (gemm_nt_c2.hip): same shapes (its tiles are the wave rows of the 320 tile)
-        // TCOW_GEMM_C2: 0 = never, 1 = every shape the 320 tile takes, 2 (default) = only where it measured ahead of the 320 tile at M = 27 090
-        // (profiles/r04_gemm_c2.txt): short-K GEMMs with an f32 residual epilogue (the HBM-bound epilogue hides under the co-resident
-        // workgroup's main loop) and plain short-K GEMMs of three rounds.  Same-box A/B of the training step: 28.05 / 28.10 ms with 2,
-        // 28.24 / 28.30 ms with 0.
-        static const int c2 = [] { const char* e = getenv("TCOW_GEMM_C2"); return e ? atoi(e) : 2; }();
-        const bool c2_pick = c2 == 1 || (c2 == 2 && a->K <= 1024 && ((a->out_f32 && a->resid) || (a->act == TCOW_ACT_NONE && !a->row_scale && !a->resid && !a->bias2 && a->N >= 2304 && a->N < 3072)));
-        if (a->tile == 160 || (a->tile == 0 && c2_pick && wide && (wide == 2 || (fills && t320 >= 200)) && tcow_gemm_nt_c2_ok(a))) {
+        // It takes the shapes where it measured ahead of the 320 tile at M = 27 090 (profiles/r04_gemm_c2.txt): short-K GEMMs with an f32 residual
+        // epilogue (the HBM-bound epilogue hides under the co-resident workgroup's main loop) and plain short-K GEMMs of three rounds.  Same-box A/B
+        // of the training step in round 4: 28.05 / 28.10 ms with this routing, 28.24 / 28.30 ms without the kernel.
+        const bool c2_pick = a->K <= 1024 && ((a->out_f32 && a->resid) || (a->act == TCOW_ACT_NONE && !a->row_scale && !a->resid && !a->bias2 && a->N >= 2304 && a->N < 3072));
+        if (a->tile == 160 || (a->tile == 0 && c2_pick && fills && t320 >= 200 && tcow_gemm_nt_c2_ok(a))) {
             TCOW_CHECK_ARG(tcow_gemm_nt_c2_ok(a), "tcow_gemm_nt(bf16): tile 160 needs K %% 128 == 0 and operands below 2 GiB");
             return tcow_gemm_nt_bf16_c2(stream, a);
         }
-        if (a->tile == 320 || (a->tile == 0 && wide && (wide == 2 || (fills && t320 >= 200)))) {
+        if (a->tile == 320 || (a->tile == 0 && fills && t320 >= 200)) {
             p.tiles_m = cdiv(a->M, C_BM); p.tiles_n = cdiv(a->N, C_BN);
             // epilogue specialisations for the combinations the path uses; anything else takes the run-time-configured kernel
             typedef void (*Kern)(NtParams);
             const int rows = (a->row_scale ? 1 : 0) | (a->resid ? 2 : 0) | (a->bias2 ? 4 : 0);
-            static const int ml = [] { const char* e = getenv("TCOW_GEMM_ML"); return e ? atoi(e) : 1; }();
             const bool vec8 = a->N % 8 == 0 && a->ldc % 8 == 0 && a->ldr % 8 == 0 && a->ldaux % 8 == 0;   // the row-operand epilogues move 8 columns per lane
 #define TCOW_PICK(R)                                                                                                                         \
             do {                                                                                                                             \
@@ -645,7 +458,7 @@ int tcow_gemm_nt_bf16(hipStream_t stream, const tcow_gemm_args* a) {
                 else if (a->act == TCOW_ACT_GELU && rows == 0) k = gemm_nt_bf16_320_kernel<EpiCfg<TCOW_ACT_GELU, 0>, R>;                     \
             } while (0)
             Kern k;
-            if (ml && a->K % 64 == 0) TCOW_PICK(1); else TCOW_PICK(0);
+            TCOW_PICK(1);                        // (K % 64 == 0: checked above)
 #undef TCOW_PICK
             tcow_ensure_lds(reinterpret_cast<const void*>(k), C_LDS);
             hipLaunchKernelGGL(k, dim3(p.tiles_m * p.tiles_n), dim3(512), C_LDS, stream, p);
@@ -654,24 +467,17 @@ int tcow_gemm_nt_bf16(hipStream_t stream, const tcow_gemm_args* a) {
         }
     }
     // the 256-square tile runs one workgroup per CU: it only pays when there are several full rounds of tiles (>= ~2.7 per CU)
-    if (a->tile == 256 || (a->tile == 0 && big && (long)cdiv(a->M, B_BM) * cdiv(a->N, B_BN) >= 700)) {
+    if (a->tile == 256 || (a->tile == 0 && (long)cdiv(a->M, B_BM) * cdiv(a->N, B_BN) >= 700)) {
         p.tiles_m = cdiv(a->M, B_BM); p.tiles_n = cdiv(a->N, B_BN);
         tcow_ensure_lds(reinterpret_cast<const void*>(gemm_nt_bf16_256_kernel), B_LDS);
         hipLaunchKernelGGL(gemm_nt_bf16_256_kernel, dim3(p.tiles_m * p.tiles_n), dim3(512), B_LDS, stream, p);
         TCOW_CHECK_LAUNCH();
         return TCOW_OK;
     }
-    static const int variant = [] { const char* e = getenv("TCOW_GEMM_NT"); return e ? atoi(e) : 3; }();   // 3 = two-stage BK=64 (default), 2 = 4-deep BK=32 ring (A/B; slower, profiles/r01_gemm_variants.txt). A register-direct
-    // epilogue with the swapped MFMA orientation (5-10 % slower: its 8-byte stores land 32 rows apart) and a BK=32 two-stage variant
-    // with 4 workgroups per CU (10-30 % slower: 64-byte rows, twice the barriers) and a single-stage BK=64 variant with 4 workgroups per CU
-    // (+-5 %: latency hiding is not the limit, L2->LDS bytes per FLOP are) were also tried and dropped.
-    if (variant == 2) {
-        tcow_ensure_lds(reinterpret_cast<const void*>(gemm_nt_bf16_ring_kernel), NT_LDS_BYTES);
-        hipLaunchKernelGGL(gemm_nt_bf16_ring_kernel, dim3(p.tiles_m * p.tiles_n), dim3(256), NT_LDS_BYTES, stream, p);
-    } else {
-        tcow_ensure_lds(reinterpret_cast<const void*>(gemm_nt_bf16_kernel), NT_LDS_BYTES);
-        hipLaunchKernelGGL(gemm_nt_bf16_kernel, dim3(p.tiles_m * p.tiles_n), dim3(256), NT_LDS_BYTES, stream, p);
-    }
+    // (tried and dropped on this tile: a 4-deep BK = 32 ring -- profiles/r01_gemm_variants.txt --, a register-direct epilogue with the swapped MFMA
+    // orientation, BK = 32 two-stage and BK = 64 single-stage variants with 4 workgroups per CU: -5 ... -30 %)
+    tcow_ensure_lds(reinterpret_cast<const void*>(gemm_nt_bf16_kernel), NT_LDS_BYTES);
+    hipLaunchKernelGGL(gemm_nt_bf16_kernel, dim3(p.tiles_m * p.tiles_n), dim3(256), NT_LDS_BYTES, stream, p);
     TCOW_CHECK_LAUNCH();
     return TCOW_OK;
 }
@@ -855,20 +661,13 @@ __device__ __forceinline__ bf16x8 tr_frag512(const char* tile, int off0) {
 }
 
 namespace {
-#ifdef TCOW_TN_DBG      // tools/ubench_tn.hip: shader-clock stamps of one stage of the weight-gradient loop, 16 per wave (each stamp drains the LDS
-                        // queue -- s_memtime returns through lgkmcnt -- so the pipelined read phases come out longer than they are)
-__device__ long long* g_tn_dbg; __device__ int g_tn_dbg_it;
-#define TN_STAMP(i) do { if (it == g_tn_dbg_it && lane == 0) g_tn_dbg[(blockIdx.x * 8 + wave) * 16 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
-#else
-#define TN_STAMP(i) do { } while (0)
-#endif
 // one workgroup of the 256-tile weight-gradient GEMM `p`: pid = slice * tiles + tile
 // AB: ablation switches of tools/ubench_tn_ab.hip (0 in the library): 2 = no loads after the first stage, 4 = no barriers in the loop, 8 = no slab
 // store (accumulators kept alive), 16 = no transpose reads in the loop, 32 = no MFMAs, 64 = no bias column sums.
 // SCHED = 1 (round 4): the stage's ONE wait + barrier sits between the third and the fourth k-step instead of at the stage end: the fourth
 // k-step's fragments are in registers by then, so its MFMAs run right behind the barrier while the NEXT stage's first fragments are read and the
 // stage after next is requested into the buffer this stage has just released -- no stage boundary at which all eight waves wait for the barrier,
-// then for their first transpose reads, with the matrix pipe idle.  (SCHED = 0: the round-3 order, kept for A/B through TCOW_GEMM_TN_SCHED=0.)
+// then for their first transpose reads, with the matrix pipe idle.  (The round-3 order -- wait + barrier at the stage end -- is gone: 553-566 vs 504 us per block.)
 template <int AB = 0, int SCHED = 1>
 __device__ __forceinline__ void tn256_body(const TnParams& p, const int pid, char* smem) {
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1148,57 +947,7 @@ __device__ __forceinline__ void tn256_body(const TnParams& p, const int pid, cha
             __builtin_amdgcn_sched_barrier(0);
             TCOW_TN_MFMA8(1);
         }
-    } else {
-    for (int it = 0; it < nmt; ++it) {
-            const int stage = it & 1;
-            const uint32_t so = (uint32_t)stage * T2_STAGE;
-            TN_STAMP(0);
-            if (it + 1 < nmt && !(AB & 2)) {
-                const int mt = mbeg + (it + 1) * T2_MC;
-                if (interior && small32 && (mt + T2_MC <= mend || mend == p.M)) issue_fast(mt, stage ^ 1); else issue(mt, stage ^ 1);
-            }
-            TN_STAMP(1);
-            const char* sy = smem + stage * T2_STAGE;
-            TCOW_TN_READ(1, 1, so);
-            asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            TN_STAMP(2);
-            TCOW_TN_MFMA8(0);
-            TCOW_TN_READ(0, 2, so);
-            asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            TN_STAMP(3);
-            TCOW_TN_MFMA8(1);
-            TCOW_TN_READ(1, 3, so);
-            asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            TN_STAMP(4);
-            TCOW_TN_MFMA8(0);
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            TN_STAMP(5);
-            TCOW_TN_MFMA8(1);
-            TN_STAMP(6);
-            if (p.bias_part && !(AB & 64)) {
-    #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int r = cs_lo + cs_rg + 16 * u;
-                    if (r < cs_hi) {
-                        const uint4 v = *reinterpret_cast<const uint4*>(sy + r * T2_ROWB + ((cs_chunk ^ ((r & 3) << 2)) << 4));
-                        csum[0] += bflo(v.x); csum[1] += bfhi(v.x); csum[2] += bflo(v.y); csum[3] += bfhi(v.y);
-                        csum[4] += bflo(v.z); csum[5] += bfhi(v.z); csum[6] += bflo(v.w); csum[7] += bfhi(v.w);
-                    }
-                }
-            }
-            TN_STAMP(7);
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            TN_STAMP(8);
-            if (!(AB & 4)) __syncthreads();
-            TN_STAMP(9);
-            if (it + 1 < nmt) TCOW_TN_READ(0, 0, so ^ (uint32_t)T2_STAGE);
-        }
-}
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #undef TCOW_TRR
 #undef TCOW_TN_READ
@@ -1280,16 +1029,15 @@ int tcow_tn_splits_256(int M, int N, int K) {
     return s;
 }
 bool tcow_tn_use_256(int M, int N, int K) {
-    static const int on = [] { const char* e = getenv("TCOW_GEMM_TN_BIG"); return e ? atoi(e) : 1; }();
     const int tiles = cdiv(N, T2) * cdiv(K, T2);
     // (a 768 x 768 weight = 9 tiles x 28 slices still wins 12 % over the 128-tile kernel despite the larger slab fold)
-    return on && M >= 4096 && N >= 256 && K >= 256 && tiles >= (on == 2 ? 1 : 9) && tiles <= 256;
+    return M >= 4096 && N >= 256 && K >= 256 && tiles >= 9 && tiles <= 256;
 }
 
-// TCOW_GEMM_TN_SCHED=0: the round-3 stage order of the 256-tile weight-gradient loop (A/B; default 1, see tn256_body)
-// 2 (default): as 1 with the transpose reads of the next k-step and the next stage's requests spread between the MFMAs of every k-step, the loads
-// as buffer loads with scalar row offsets -- whole 256-tiles and 32-bit byte offsets only (tn_whole), otherwise 1
-static int tn_sched() { static const int v = [] { const char* e = getenv("TCOW_GEMM_TN_SCHED"); return e ? atoi(e) : 2; }(); return v; }
+// stage loop of the 256-tile weight-gradient kernel (tn256_body): SCHED = 2 -- the transpose reads of the next k-step and the next stage's requests
+// spread between the MFMAs of every k-step, the loads as buffer loads with scalar row offsets -- for whole 256-tiles with 32-bit byte offsets
+// (tn_whole), SCHED = 1 (the same wait / barrier placement, general addressing) otherwise
+static int tn_sched() { return 2; }
 static bool tn_whole(int M, int N, int K, long ldy, long ldx) { return N % T2 == 0 && K % T2 == 0 && (long)M * ldy < (1L << 29) && (long)M * ldx < (1L << 29); }
 
 int tcow_gemm_tn_bf16(hipStream_t stream, int M, int N, int K, const bf16_t* dY, long ldy, const bf16_t* X, long ldx, float* slab, int splits,
@@ -1298,7 +1046,7 @@ int tcow_gemm_tn_bf16(hipStream_t stream, int M, int N, int K, const bf16_t* dY,
     TnParams p;
     p.M = M; p.N = N; p.K = K; p.dY = dY; p.ldy = ldy; p.X = X; p.ldx = ldx; p.slab = slab;
     p.tiles_n = cdiv(N, TN_T); p.tiles_k = cdiv(K, TN_T);
-    static const int mc = [] { const char* e = getenv("TCOW_GEMM_TN_MC"); return (e && atoi(e) == 64) ? 64 : 32; }();   // 32 (4 workgroups/CU) measured 5-25 % faster than 64 (profiles/r01_gemm_tn_ab.txt)
+    constexpr int mc = 32;                      // token rows per stage of the 128-tile kernel: 32 (4 workgroups/CU) measured 5-25 % ahead of 64 (profiles/r01_gemm_tn_ab.txt)
     int mps = cdiv(M, splits); mps = ((mps + 63) / 64) * 64;
     p.mps = mps;
     const int nz = cdiv(M, mps);
@@ -1307,7 +1055,6 @@ int tcow_gemm_tn_bf16(hipStream_t stream, int M, int N, int K, const bf16_t* dY,
     p.bias_part = bias_part;
     p.rows_per_pk = cdiv(mc, p.tiles_k);
     if (bias_parts_out) *bias_parts_out = nz * p.tiles_k * 2;
-    tcow_ensure_lds(reinterpret_cast<const void*>(gemm_tn_bf16_kernel<64>), 65536);
     if (tcow_tn_use_256(M, N, K)) {
         p.tiles_n = cdiv(N, T2); p.tiles_k = cdiv(K, T2);
         p.rows_per_pk = cdiv(T2_MC, p.tiles_k);
@@ -1318,14 +1065,13 @@ int tcow_gemm_tn_bf16(hipStream_t stream, int M, int N, int K, const bf16_t* dY,
         tcow_ensure_lds(reinterpret_cast<const void*>(gemm_tn_bf16_256_kernel<S>), T2_LDS);                                \
         hipLaunchKernelGGL(gemm_tn_bf16_256_kernel<S>, dim3(nz * p.tiles_n * p.tiles_k), dim3(512), T2_LDS, stream, p);    \
     } while (0)
-        if (sched == 2) TN_LAUNCH(2); else if (sched == 1) TN_LAUNCH(1); else TN_LAUNCH(0);
+        if (sched == 2) TN_LAUNCH(2); else TN_LAUNCH(1);
 #undef TN_LAUNCH
         TCOW_CHECK_LAUNCH();
         return TCOW_OK;
     }
     const dim3 grid(8 * cdiv(nz, 8) * p.tiles_n * p.tiles_k);
-    if (mc == 32) hipLaunchKernelGGL(gemm_tn_bf16_kernel<32>, grid, dim3(256), 32768, stream, p);
-    else hipLaunchKernelGGL(gemm_tn_bf16_kernel<64>, grid, dim3(256), 65536, stream, p);
+    hipLaunchKernelGGL(gemm_tn_bf16_kernel<32>, grid, dim3(256), 32768, stream, p);
     TCOW_CHECK_LAUNCH();
     return TCOW_OK;
 }
@@ -1348,8 +1094,6 @@ int tcow_tn_group_slices(int n, const tcow_tn_problem* pr) {
     int tiles = 0;
     for (int i = 0; i < n; ++i) tiles += cdiv(pr[i].N, T2) * cdiv(pr[i].K, T2);
     int max_s = pr[0].M / 256; if (max_s > 64) max_s = 64; if (max_s < 1) max_s = 1;
-    static const int forced = [] { const char* e = getenv("TCOW_GEMM_TN_SLICES"); return e ? atoi(e) : 0; }();       // (A/B)
-    if (forced > 0) return forced < max_s ? forced : max_s;
     int best = 1; double best_cost = 1e30;
     for (int s = 1; s <= max_s; ++s) {
         const int wg = s * tiles, rounds = cdiv(wg, 256);
@@ -1386,7 +1130,7 @@ int tcow_gemm_tn_bf16_group(hipStream_t stream, int n, const tcow_tn_problem* pr
         tcow_ensure_lds(reinterpret_cast<const void*>(gemm_tn_bf16_256_group_kernel<S>), T2_LDS);                          \
         hipLaunchKernelGGL(gemm_tn_bf16_256_group_kernel<S>, dim3(first), dim3(512), T2_LDS, stream, g);                   \
     } while (0)
-    if (sched == 2) TN_LAUNCH(2); else if (sched == 1) TN_LAUNCH(1); else TN_LAUNCH(0);
+    if (sched == 2) TN_LAUNCH(2); else TN_LAUNCH(1);
 #undef TN_LAUNCH
     TCOW_CHECK_LAUNCH();
     return TCOW_OK;

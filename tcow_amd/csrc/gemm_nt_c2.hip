@@ -15,8 +15,8 @@
 //   * One wave per SIMD and workgroup, so the loop is software-pipelined inside the wave instead of across a staggered wave pair: a K tile is four
 //     blocks of 20 MFMAs; the next block's fragment reads and the next tile's 13 loads are placed one per MFMA gap (no burst that leaves the MFMA
 //     pipe without work), and ONE workgroup barrier per K tile publishes the next A tile.
-//   * Co-resident workgroups would run in lock step (same work, same start) and reach their epilogues together; the second workgroup of every CU
-//     therefore starts late by about half a main loop (NtParams::skew, first dispatch round only) -- from then on one is always ahead.
+//   * (A start skew of the second workgroup of each CU -- so that the pair's epilogues do not coincide -- was measured in round 4 and removed: over the
+//     nine shapes of the path 851 us without, 870 / 883 / 924 us with 0.45 / 0.9 / 1.3 us per K tile; a late start is lost time.)
 #include <stdlib.h>
 
 #include "common.h"
@@ -42,14 +42,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_c2_kernel(NtParams p) {
     const int pid = xcd_remap(blockIdx.x, nblk);
     const int pm = pid / p.tiles_n, pn = pid - pm * p.tiles_n;
     const int m0 = pm * D_BM, n0 = pn * D_BN;
-    if (p.skew > 0) {
-        const int b = blockIdx.x;
-        const bool late = (p.skew_mode & 3) == 2 ? (b < 512 && ((b >> 3) & 1)) : (b >= 256 && b < 512);
-        if (late) {
-            const long long t0 = wall_clock64();
-            while (wall_clock64() - t0 < p.skew) __builtin_amdgcn_s_sleep(8);
-        }
-    }
     f32x16 acc[5][2];                                 // (unused: the epilogue's 32x32x16 form)
     f32x4 acc16[10][4];
 #pragma unroll
@@ -119,7 +111,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_c2_kernel(NtParams p) {
 
     // ---- prologue: tile 0 in, its W k-half-0 and A rows 0-79 k-half-0 fragments requested
     const int nk = p.K / 64;
-    if (p.skew_mode & 4) __builtin_amdgcn_s_setprio(2);       // main loop above the co-resident workgroup's epilogue in the issue arbitration
 #pragma unroll
     for (int q = 0; q < 8; ++q) C2_LDW(q, 0u);
 #pragma unroll
@@ -205,7 +196,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_c2_kernel(NtParams p) {
 #undef C2_LDW
 #undef C2_GLDS
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    if (p.skew_mode & 4) __builtin_amdgcn_s_setprio(0);
     // every wave has finished its fragment reads before any wave's staging writes land in the buffers
     __builtin_amdgcn_s_barrier();
     if (AB & 8) {
@@ -226,11 +216,6 @@ bool tcow_gemm_nt_c2_ok(const tcow_gemm_args* a) { return a->K % 128 == 0 && (lo
 int tcow_gemm_nt_bf16_c2(hipStream_t stream, const tcow_gemm_args* a) {
     NtParams p = nt_params_from_args(a);
     p.tiles_m = cdiv(a->M, D_BM); p.tiles_n = cdiv(a->N, D_BN);
-    // second workgroup of each CU: late by this many microseconds per 64-wide K tile (A/B only; default 0: over the nine shapes of the path 851 us
-    // without a skew, 870 / 883 / 924 us with 0.45 / 0.9 / 1.3 us per K tile -- a late start is lost time, the epilogues do not hide under it)
-    static const float skew_us = [] { const char* e = getenv("TCOW_GEMM_C2_SKEW"); return e ? (float)atof(e) : 0.0f; }();
-    static const int skew_mode = [] { const char* e = getenv("TCOW_GEMM_C2_SKEWMODE"); return e ? atoi(e) : 1; }();
-    p.skew = (int)(skew_us * 100.f * (float)(a->K / 64)); p.skew_mode = skew_mode;
     typedef void (*Kern)(NtParams);
     const int rows = (a->row_scale ? 1 : 0) | (a->resid ? 2 : 0) | (a->bias2 ? 4 : 0);
     const bool vec8 = a->N % 8 == 0 && a->ldc % 8 == 0 && a->ldr % 8 == 0 && a->ldaux % 8 == 0;   // the row-operand epilogues move 8 columns per lane

@@ -25,7 +25,6 @@ struct NtParams {
     bf16_t* aux; long ldaux;
     int tiles_m, tiles_n;
     const float* bias2; const float* row_scale2;      // second bias with its own row scale (the folded temporal projection), or NULL
-    int skew, skew_mode;                              // gemm_nt_c2.hip: start delay of a CU's second workgroup in 10-ns ticks (0 = none)
 };
 
 // the launch parameters of a validated tcow_gemm_nt call (tile counts are filled by the kernel's launcher)
@@ -36,7 +35,7 @@ static inline NtParams nt_params_from_args(const tcow_gemm_args* a) {
     p.C = a->C; p.ldc = a->ldc; p.out_f32 = a->out_f32; p.bias = a->bias; p.row_scale = a->row_scale;
     p.resid = a->resid; p.ldr = a->ldr; p.act = a->act; p.aux = (bf16_t*)a->aux; p.ldaux = a->ldaux;
     p.bias2 = a->bias2; p.row_scale2 = a->row_scale2;
-    p.tiles_m = p.tiles_n = 0; p.skew = p.skew_mode = 0;
+    p.tiles_m = p.tiles_n = 0;
     return p;
 }
 

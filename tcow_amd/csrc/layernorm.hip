@@ -194,11 +194,11 @@ int tcow_launch_row_reduce_group(hipStream_t stream, int n, const float* const* 
                                  float* const* out2, const int* N3, float* const* out3, const int* accumulate);
 int tcow_launch_row_reduce3(hipStream_t stream, const float* part, int nrows, long ld, int N1, float* out1, int N2, float* out2, int N3, float* out3, int accumulate);
 
-static const int kLnBwdBlocks = [] { const char* e = getenv("TCOW_LN_BWD_BLOCKS"); const int v = e ? atoi(e) : 768; return v >= 1 ? v : 768; }();
+static const int kLnBwdBlocks = 768;
 // (grid-stride blocks of the backward: 768 = three 4-wave workgroups per CU in ONE round -- the kernel needs 154 VGPRs at D = 768, i.e. three
 // waves per SIMD; 512 -> 768: 78 -> 73.5 us, 1024 (1.33 rounds) 84 us.  The colsum variant needs 180 VGPRs = two waves per SIMD: 512 blocks.)
-static const int kLnBwdBlocksCsum = [] { const char* e = getenv("TCOW_LN_BWD_BLOCKS_CSUM"); const int v = e ? atoi(e) : 512; return v >= 1 && v <= kLnBwdBlocks ? v : (kLnBwdBlocks < 512 ? kLnBwdBlocks : 512); }();
-static const int kLnFwdBlocks = [] { const char* e = getenv("TCOW_LN_FWD_BLOCKS"); const int v = e ? atoi(e) : 4096; return v >= 1 ? v : 4096; }();     // grid-stride blocks of the forward (512 ... 8192 measured within 6 %: tools/dev_ln_time.py)
+static const int kLnBwdBlocksCsum = 512;
+static const int kLnFwdBlocks = 4096;     // grid-stride blocks of the forward (512 ... 8192 measured within 6 %: tools/dev_ln_time.py)
 
 extern "C" {
 

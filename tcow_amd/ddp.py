@@ -7,12 +7,19 @@ are independent through the model and the per-example loss (pipeline.py:50-83), 
 over replicas (loss.py:356-369), so the MI355X counterpart is plain gradient averaging:
 
   * each rank owns B clips (1 in BASELINE configs[2]) and runs forward / loss / backward locally;
-  * the hand-written backward (engine.run_backward) finishes one gradient bucket at a time -- the output heads,
-    then transformer blocks depth-1 .. 0 (20 tensors, ~9.45 M f32 = 37.8 MB each at ViT-B), then the embeddings --
-    each as ONE flat f32 buffer; `GradSync` launches an asynchronous all-reduce on the bucket the moment it is
-    complete, so communication of block i overlaps the backward compute of blocks i-1 .. 0;
-  * xGMI is point-to-point (7 links x ~153 GB/s per GPU): 37.8 MB buckets keep every ring step well above the
-    latency floor while leaving 13 collectives in flight behind ~2/3 of the backward;
+  * the hand-written backward (engine.run_backward) finishes its parameter gradients in GROUPS of transformer blocks
+    (engine.group_sizes: TCOW_DDP_GROUP, default 5 / 5 / 2 blocks from the top at depth 12; the top group also carries the
+    output heads, the bottom one the embeddings), each as ONE flat f32 buffer, plus one late bucket for the three tensors
+    per block that come out of the folded temporal projection: 4 buckets per step at ViT-B -- 180 + 177 + 75 + 57 MB of the
+    488.6 MB.  `GradSync` launches an asynchronous all-reduce on a bucket the moment the backward publishes it, so the two
+    upper groups travel while the blocks below them are still being differentiated; the bottom group and the late bucket
+    exist only when the backward is over and cannot overlap anything, which is why the bottom group is the small one
+    (132 MB exposed by construction instead of the 203 MB of an even 4 / 4 / 4 split);
+  * few, large collectives on purpose: xGMI is point-to-point (7 links x ~153 GB/s per GPU), a ring sees ~300 GB/s of bus
+    bandwidth, and every collective is a window in which resident RCCL workgroups push the one-workgroup-per-CU GEMMs of
+    the backward into an extra round (profiles/r02_cu_contention.txt: 20-23 % on the 320-tile GEMMs while any CU is held).
+    RCCL's channel count (NCCL_MAX_NCHANNELS) trades that window's length against its depth; the run records the knobs it
+    saw in the `ddp.rccl` field of the bench line, none is set by this module;
   * parameters the step does not touch (model.norm.*, flag_post_linear.* in Kubric training) have no gradient on
     any rank and are simply not part of any bucket -- no unused-parameter handshake is needed.
 """

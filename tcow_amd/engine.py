@@ -105,7 +105,7 @@ def group_sizes(depth, spec=None):
 
 
 def _fold_on(module):
-    return ops.is16(module.mode) and module.attention_type == 'divided_space_time' and os.environ.get('TCOW_FOLD', '1') != '0'
+    return ops.is16(module.mode) and module.attention_type == 'divided_space_time'
 
 
 def _fold_products(ents):

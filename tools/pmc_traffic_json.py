@@ -31,12 +31,13 @@ per = {}
 for k, (v, c) in fetch.items():
     if 'gemm_nt_bf16' in k:
         m = re.search(r'EpiCfg<(-?\d+), (-?\d+)>', k)
-        tag = f'<{m.group(1)},{m.group(2)}>' if m else k[:40]
+        kn = re.match(r'(?:void )?(gemm_nt_bf16\w*)', k)                  # the kernel's own name stays in the key: the 320 and the c2 kernel share epilogue tags
+        tag = (kn.group(1) if kn else k[:40]) + (f'<{m.group(1)},{m.group(2)}>' if m else '')
         per[tag] = dict(fetch_kib=v / c, dispatches=c, write_kib=(write[k][0] / write[k][1] if k in write and write[k][1] else None))
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sha = hashlib.sha256(b''.join(open(os.path.join(root, 'tcow_amd', 'csrc', f), 'rb').read() for f in ('gemm_bf16.hip', 'gemm_nt_common.h'))).hexdigest()     # (as bench.py pmc_traffic)
 rec = dict(kernel='gemm_nt_bf16_*_kernel (every NT-GEMM launch of the timed steps at M = 27090, dispatch-weighted)',
-           command='rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE --kernel-trace -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-parity (tools/pmc_bench.sh)',
+           command='rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE --kernel-trace -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-parity --no-config-legs (tools/pmc_bench.sh)',
            dispatches_fetch=n_f, dispatches_write=n_w, fetch_size_kib_mean=f_nt, write_size_kib_mean=w_nt,
            fetch_correction=corr, calibration=dict(scale_cast_fetch_kib=sc_f, ln_fwd_fetch_kib=ln_f, known_f32_read_kib=known_read, scale_cast_write_kib=sc_w, known_bf16_write_kib=known_write),
            traffic_bytes_per_launch=(f_nt * corr + w_nt) * 1024.0 if f_nt and w_nt else None, gemm_bf16_sha256=sha, per_kernel=per)
