@@ -161,6 +161,97 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_stream(SeqDesc sd, int nt, co
     if (active) fwd_store(sd, base, head, q, hi, m, l, o0, o1, out, lse);
 }
 
+// The streaming forward for sequences WITHOUT a causal mask (spatial / joint attention: every call of the training step), on a VALU diet.  The
+// streaming kernel above is VALU-throughput-bound at its 2.6-4 waves per SIMD (profiles/r05_attn_fwd_p4.txt: at d = 64 a tile step's softmax
+// costs more issue cycles than its 8 MFMAs), so what counts is the number of vector instructions per step -- 87 in fwd_tile:
+//   * Q is multiplied by 0.125 log2(e) ONCE, when its fragments are loaded (16-bit result: the scores see one more rounding of q, the saved
+//     log-sum-exp stays consistent with the probabilities the forward used), so the exponent needs no scaling;
+//   * the running reference maximum sits in the C operand of the first S MFMA -- S' = K Q'^T - m comes out of the matrix pipe and
+//     p = exp2(S') is one instruction per element (fwd_tile: one fma + one exp);
+//   * no mask arithmetic except on the sequence's last key tile (padding keys).
+// (Walking a chunk's tiles by an unrolled loop -- fragment addresses as lane constant + immediate -- was tried: hipcc then carries the accumulators through
+// 50 register copies per step and needs 202 registers, one wave per SIMD less.)
+// The lazy maximum is fwd_tile's: the reference moves only when some row grew by more than 2^8, and the first key tile always sets it.
+__device__ __forceinline__ void fwd_tile_pre(const char* ktile, const char* vtile, const bf16x8 (&qf)[4], bool first, bool pad, int lr, int l31, int hi, int lane, float& m,
+                                             float& l, f32x16& negm, f32x16& o0, f32x16& o1) {
+    f32x16 s = TCOW_MFMA_32x32x16_H16(frag_row(ktile, l31, 0, hi), qf[0], negm, 0, 0, 0);      // (negm = 0 until the first key tile has set the reference)
+#pragma unroll
+    for (int ks = 1; ks < 4; ++ks) s = TCOW_MFMA_32x32x16_H16(frag_row(ktile, l31, ks, hi), qf[ks], s, 0, 0, 0);
+    if (pad) {                                              // the sequence's last key tile: padding keys underflow to probability 0
+        TCOW_NO_IFCVT();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = (crow32(r, hi) >= lr) ? -1e30f : s[r];
+    }
+    float mx = fmaxf(fmaxf(s[0], s[1]), s[2]);
+#pragma unroll
+    for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, s[r]), s[r + 1]);
+    mx = half_max(fmaxf(mx, s[15]));                        // row maximum of this tile, relative to the reference
+    if (first || __any(mx > 8.0f)) {
+        TCOW_NO_IFCVT();
+        const float delta = first ? mx : fmaxf(mx, 0.0f);   // (the first tile SETS the reference, later ones only raise it)
+        const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-delta);       // (first tile: l = O = 0)
+        m += delta;
+        l *= alpha;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; s[r] -= delta; negm[r] = -m; }
+    }
+    float p[16];
+    float pa = 0.f, pb = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) { p[r] = __builtin_amdgcn_exp2f(s[r]); p[r + 1] = __builtin_amdgcn_exp2f(s[r + 1]); pa += p[r]; pb += p[r + 1]; }
+    l += pa + pb;
+    const bf16x8 pb0 = pack8(p), pb1 = pack8(p + 8);
+    o0 = TCOW_MFMA_32x32x16_H16(frag_tr(vtile, 0, 0, lane), pb0, o0, 0, 0, 0);
+    o1 = TCOW_MFMA_32x32x16_H16(frag_tr(vtile, 0, 1, lane), pb0, o1, 0, 0, 0);
+    o0 = TCOW_MFMA_32x32x16_H16(frag_tr(vtile, 1, 0, lane), pb1, o0, 0, 0, 0);
+    o1 = TCOW_MFMA_32x32x16_H16(frag_tr(vtile, 1, 1, lane), pb1, o1, 0, 0, 0);
+}
+
+template <int CH>
+__global__ __launch_bounds__(256, 2) void attn_fwd_stream_nc(SeqDesc sd, int nt, const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * CH * TILE_B];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const StreamWork sw_ = stream_work(sd.n_outer * sd.n_inner * sd.heads, (nt + 3) / 4);
+    if (!sw_.valid) return;
+    const int item = sw_.pair / sd.heads, head = sw_.pair - item * sd.heads;
+    const long base = seq_base(sd, item);
+    const long ld3 = 3L * sd.D, pse = sd.pos_stride * ld3;
+    const bf16_t* qh = qkv + base * ld3 + head * ATT_HD;
+    char* kt = smem;
+    char* vt = smem + CH * TILE_B;
+    load_chunk2<CH>(qh + sd.D, pse, qh + 2 * sd.D, pse, 0, nt, sd.L, kt, vt, wave, lane);
+    const int qt = sw_.chunk * 4 + wave;
+    const bool active = qt < nt;
+    const int q = 32 * qt + l31;
+    const int qc = q < sd.L ? q : sd.L - 1;
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        typedef __attribute__((ext_vector_type(8))) float f32x8;
+        qf[ks] = __builtin_convertvector(__builtin_convertvector(frag_row_global(qh, pse, qc, ks, hi), f32x8) * (kScale * kLog2e), bf16x8);
+    }
+    f32x16 o0, o1, negm;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; negm[r] = 0.f; }
+    float m = 0.f, l = 0.f;
+    const int lr = sd.L - 32 * (nt - 1);                    // valid keys of the last tile
+    const bool pad = lr < 32;
+    for (int c0 = 0; c0 < nt; c0 += CH) {
+        if (c0) {
+            __syncthreads();                               // previous chunk fully consumed
+            load_chunk2<CH>(qh + sd.D, pse, qh + 2 * sd.D, pse, c0, nt, sd.L, kt, vt, wave, lane);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int jend = (c0 + CH < nt) ? c0 + CH : nt;
+        if (active)
+            for (int j = c0; j < jend; ++j) fwd_tile_pre(kt + (j - c0) * TILE_B, vt + (j - c0) * TILE_B, qf, j == 0, pad && j == nt - 1, lr, l31, hi, lane, m, l, negm, o0, o1);
+    }
+    if (active) fwd_store(sd, base, head, q, hi, m, l, o0, o1, out, lse);
+}
+
 // ------------------------------------------------------------------------------------------------ backward prep
 // ld[(item*heads + h)*Lp + q] = (lse, delta), delta = sum_d dO*O  -- packed per sequence so the kernels read it contiguously
 __global__ void attn_bwd_prep_kernel(SeqDesc sd, int Lp, const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout, const float* __restrict__ lse,
@@ -779,7 +870,12 @@ __global__ __launch_bounds__(768) void attn_bwd_one_kernel(SeqDesc sd, int nt, c
                     else { ONE_RD(1, kt + 2); ONE_WAIT(2, 8); ONE_MF(2, kt); }
                 }
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // (the last key tiles have requested strip fragments two tiles past the end into the three sets: the wait re-defines them, so that hipcc -- which
+            // knows nothing of reads issued by asm statements -- cannot reuse a register the late data will still land on; cf. gemm_nt_c2.hip)
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(fr[0][0]), "+v"(fr[0][1]), "+v"(fr[0][2]), "+v"(fr[0][3]), "+v"(fr[1][0]), "+v"(fr[1][1]), "+v"(fr[1][2]), "+v"(fr[1][3]),
+                           "+v"(fr[2][0]), "+v"(fr[2][1]), "+v"(fr[2][2]), "+v"(fr[2][3])
+                         :: "memory");
 #undef ONE_WAIT
 #undef ONE_RD
 #undef ONE_MF
@@ -882,7 +978,8 @@ int tcow_attn_mfma_fwd(hipStream_t st, const SeqDesc& d, bool shared, const void
     const int pairs = d.n_outer * d.n_inner * d.heads;
     if (shared || nt > 2) {
         // (forward: four tiles per chunk -- with five, 40 KiB per workgroup, the fourth workgroup of a CU no longer fits and 56 us become 60)
-        hipLaunchKernelGGL(attn_fwd_stream<4>, dim3(stream_grid(pairs, cdiv(nt, 4))), dim3(256), 0, st, d, nt, (const bf16_t*)qkv, (bf16_t*)out, lse);
+        if (d.diag >= (1 << 27) && nt >= 2) hipLaunchKernelGGL(attn_fwd_stream_nc<4>, dim3(stream_grid(pairs, cdiv(nt, 4))), dim3(256), 0, st, d, nt, (const bf16_t*)qkv, (bf16_t*)out, lse);
+        else hipLaunchKernelGGL(attn_fwd_stream<4>, dim3(stream_grid(pairs, cdiv(nt, 4))), dim3(256), 0, st, d, nt, (const bf16_t*)qkv, (bf16_t*)out, lse);
     } else {
         const int lds = 4 * 3 * nt * TILE_B;
         set_lds_attr(attn_fwd_mfma<false>, lds);

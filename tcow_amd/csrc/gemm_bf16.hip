@@ -948,7 +948,14 @@ __device__ __forceinline__ void tn256_body(const TnParams& p, const int pid, cha
             TCOW_TN_MFMA8(1);
         }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // (SCHED = 2: the last stage's fourth k-step has requested fragments of a stage that does not exist into set 0.  The wait re-defines those
+    // registers, so that hipcc -- which knows nothing of reads issued by asm statements -- cannot hand them to the code behind the loop before the
+    // data is in: see the same note in gemm_nt_c2.hip, where exactly that corrupted tiles)
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(fxl[0][0]), "+v"(fxl[0][1]), "+v"(fxh[0][0]), "+v"(fxh[0][1]), "+v"(fyl[0][0]), "+v"(fyl[0][1]), "+v"(fyl[0][2]), "+v"(fyl[0][3]),
+                   "+v"(fyh[0][0]), "+v"(fyh[0][1]), "+v"(fyh[0][2]), "+v"(fyh[0][3])
+                 :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
 #undef TCOW_TRR
 #undef TCOW_TN_READ
 #undef TCOW_TN_FRAG

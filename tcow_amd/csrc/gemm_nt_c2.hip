@@ -195,7 +195,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_c2_kernel(NtParams p) {
 #undef C2_LDWV
 #undef C2_LDW
 #undef C2_GLDS
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    // The last tile's block 3 has requested the fragments of a tile that does not exist (stale bytes nobody uses) into fa[0] / fw[0].  hipcc knows
+    // nothing of reads issued by asm statements: to it those registers are dead behind the loop, free for the epilogue's values -- and register-only
+    // instructions may be scheduled ABOVE a wait that clobbers nothing but memory, where the late data then lands on top of them (round 5: whole wave
+    // tiles of the row-scale epilogue came out corrupted in 7 of 10 launches after an unrelated edit had shifted the register allocation).  The
+    // wait therefore re-defines the nine registers: nothing can take them before the data is in.
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
+                 : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]), "+v"(fa[0][4]), "+v"(fw[0][0]), "+v"(fw[0][1]), "+v"(fw[0][2]), "+v"(fw[0][3])
+                 :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
     // every wave has finished its fragment reads before any wave's staging writes land in the buffers
     __builtin_amdgcn_s_barrier();
     if (AB & 8) {
