@@ -9,7 +9,8 @@
 // is found exactly by an 11/11/9-bit radix select over the float bit pattern (loss values are >= 0, so the unsigned
 // pattern orders like the value); elements equal to the k-th value share the remaining weight equally (a valid
 // sub-gradient where torch.topk picks an arbitrary subset of the ties).
-// All passes stream x, t, w once (12 B/pixel; the gradient pass also writes 4 B/pixel): HBM-bound.
+// Pass A and the gradient pass stream x, t, w once (12 B/pixel; + 4 B/pixel written: the loss values' bit patterns / the gradient); the two
+// radix passes in between read only those bit patterns (4 B/pixel, no arithmetic -- round 5: they recomputed the loss from x, t, w before).
 #include "common.h"
 
 namespace {
@@ -38,6 +39,7 @@ struct MlCtl {
 
 struct MlWs {
     int* fsel; double* fwsum; double* part; unsigned* hist; MlCtl* ctl; int nblk;
+    unsigned* vb;                           // [n_frames * frame_len] bit patterns of the (weighted) loss values: written by pass A, read by the radix passes
 };
 
 // bce-with-logits and sigmoid of one pixel; identical instruction sequence in every pass (the radix passes rely on it)
@@ -142,16 +144,21 @@ __global__ void __launch_bounds__(kThreads) ml_stats_kernel(MlView v, MlWs ws) {
     __syncthreads();
     float s[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     if (live) {
-        for_each_vec(v, f, [&](float4 x, float4 t, float4 w, int) {
+        uint4* vbo = need_hist ? reinterpret_cast<uint4*>(ws.vb + (long)f * v.L4 * 4) : nullptr;
+        for_each_vec(v, f, [&](float4 x, float4 t, float4 w, int i) {
             const float xs[4] = {x.x, x.y, x.z, x.w}, ts[4] = {t.x, t.y, t.z, t.w}, wv[4] = {w.x, w.y, w.z, w.w};
+            unsigned vbs[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float bce, p; bce_sig(xs[e], ts[e], bce, p);
                 const unsigned vb = vbits(bce, wv[e], v.weighted);
+                vbs[e] = vb;
                 s[0] += bce * wv[e]; s[1] += __builtin_bit_cast(float, vb);
                 s[2] += p * ts[e]; s[3] += p; s[4] += ts[e];
                 if (need_hist) atomicAdd(&hist[vb >> 20], 1u);
             }
+            // the radix passes that follow only need the bit patterns: 4 B/pixel instead of x, t, w again (12 B/pixel) and no arithmetic
+            if (vbo) vbo[i] = make_uint4(vbs[0], vbs[1], vbs[2], vbs[3]);
         });
     }
     const int blk = blockIdx.y * gridDim.x + blockIdx.x;
@@ -176,16 +183,21 @@ template <int LEVEL> __global__ void __launch_bounds__(kThreads) ml_hist_kernel(
     for (int i = threadIdx.x; i < NB; i += kThreads) hist[i] = 0u;
     __syncthreads();
     const unsigned prefix = LEVEL == 2 ? c->b1 : ((c->b1 << 11) | c->b2);
-    for_each_vec(v, f, [&](float4 x, float4 t, float4 w, int) {
-        const float xs[4] = {x.x, x.y, x.z, x.w}, ts[4] = {t.x, t.y, t.z, t.w}, wv[4] = {w.x, w.y, w.z, w.w};
+    const uint4* vbi = reinterpret_cast<const uint4*>(ws.vb + (long)f * v.L4 * 4);          // pass A's bit patterns of this frame
+    const int base = blockIdx.x * kVecPerBlock;
+#pragma unroll
+    for (int j = 0; j < kVecPerBlock / kThreads; ++j) {
+        const int i = base + j * kThreads + threadIdx.x;
+        if (i >= v.L4) continue;
+        const uint4 q = vbi[i];
+        const unsigned vbs[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            float bce, p; bce_sig(xs[e], ts[e], bce, p);
-            const unsigned vb = vbits(bce, wv[e], v.weighted);
+            const unsigned vb = vbs[e];
             if (LEVEL == 2) { if ((vb >> 20) == prefix) atomicAdd(&hist[(vb >> 9) & 2047u], 1u); }
             else            { if ((vb >> 9) == prefix) atomicAdd(&hist[vb & 511u], 1u); }
         }
-    });
+    }
     __syncthreads();
     unsigned* gh = ws.hist + (LEVEL == 2 ? kBins12 : 2 * kBins12);
     for (int i = threadIdx.x; i < NB; i += kThreads)
@@ -337,6 +349,7 @@ size_t tcow_mask_loss_workspace_bytes(long n_frames, long frame_len) {
     b += ((size_t)ml_nblk(n_frames, frame_len) * kNPart * sizeof(double) + 255) & ~(size_t)255;
     b += (2 * kBins12 + kBins3) * sizeof(unsigned);
     b += 512;
+    b += (size_t)n_frames * (size_t)frame_len * sizeof(unsigned);           // the loss values' bit patterns between pass A and the radix passes
     return b;
 }
 
@@ -361,7 +374,8 @@ int tcow_mask_loss(void* stream, const tcow_mask_loss_args* a) {
     ws.nblk = ml_nblk(a->n_frames, a->frame_len);
     ws.part = (double*)p; p += ((size_t)ws.nblk * kNPart * sizeof(double) + 255) & ~(size_t)255;
     ws.hist = (unsigned*)p; p += (2 * kBins12 + kBins3) * sizeof(unsigned);
-    ws.ctl = (MlCtl*)p;
+    ws.ctl = (MlCtl*)p; p += 512;
+    ws.vb = (unsigned*)p;
     static_assert(sizeof(MlCtl) <= 512, "control block");
     const dim3 grid((v.L4 + kVecPerBlock - 1) / kVecPerBlock, v.n_frames);
     ml_frames_kernel<<<v.n_frames, kThreads, 0, st>>>(v, ws);
