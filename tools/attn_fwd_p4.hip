@@ -105,6 +105,9 @@ __device__ __forceinline__ float p4_max3(float a, float b, float c) { return fma
 #ifndef P4_AB
 #define P4_AB 0
 #endif
+#ifndef P4_ASM_ROUNDS
+#define P4_ASM_ROUNDS 1      // NW = 8: the rounds of attn_round_asm.inc (0: the C++ rounds, compiler-scheduled)
+#endif
 
 // ---- the softmax of one tile step in eight pieces (one per MFMA gap).  G = 0 .. 3 run beside the PV MFMAs of the previous tile in the round,
 // G = 4 .. 7 beside the S MFMAs of the next one.
@@ -357,6 +360,94 @@ __device__ __forceinline__ void p4_round(P4Ctx<NW>& c, P4Tile (&t)[NQ], bf16x8 (
     }
 }
 
+// ---- the same rounds with every hot instruction as its own asm volatile statement: tools/gen_attn_round.py -> attn_round_asm.inc (source order =
+// issue order; NW = 8 form: S from C = 0, m subtracted by the softmax; the compiler keeps register allocation and the LDS-read waits)
+#ifndef P4A_DBG_MFMA
+#define P4A_DBG_MFMA 0
+#endif
+#ifdef TCOW_FP16
+#define PA_CVT_ASM "v_cvt_pk_f16_f32"
+#else
+#define PA_CVT_ASM "v_cvt_pk_bf16_f32"
+#endif
+#if P4A_DBG_MFMA
+#define PA_MFMA_Z(d, a, b) d = TCOW_MFMA_32x32x16_H16(a, b, (f32x16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, 0, 0, 0)
+#define PA_MFMA(d, a, b) d = TCOW_MFMA_32x32x16_H16(a, b, d, 0, 0, 0)
+#define PA_PV_FIRST(d, a, b) d = TCOW_MFMA_32x32x16_H16(a, b, d, 0, 0, 0)
+#else
+#define PA_MFMA_Z(d, a, b) asm volatile(TCOW_MFMA_32x32x16_H16_ASM " %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b))
+#define PA_MFMA(d, a, b) asm volatile(TCOW_MFMA_32x32x16_H16_ASM " %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b))
+#define PA_PV_FIRST(d, a, b) asm volatile("s_nop 1\n\t" TCOW_MFMA_32x32x16_H16_ASM " %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b))
+#endif
+#ifndef P4A_DBG
+#define P4A_DBG 0          // bisecting aid: 1 = half-wave maximum in C++, 2 = every VALU statement in C++ (compiler-ordered), 4 = MFMAs as builtins
+#endif
+#if P4A_DBG & 2
+#define PA_MAX3(d, a, b, c_) d = fmaxf(fmaxf(a, b), c_)
+#define PA_MAX(d, a, b) d = fmaxf(a, b)
+#define PA_SUB(d, a, b) d = (a) - (b)
+#define PA_ADD(d, a, b) d = (a) + (b)
+#define PA_EXP(d, a) d = __builtin_amdgcn_exp2f(a)
+#define PA_CVT(d, a, b) d = pack_bf2(a, b)
+#else
+#define PA_MAX3(d, a, b, c_) asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c_))
+#define PA_MAX(d, a, b) asm volatile("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b))
+#define PA_SUB(d, a, b) asm volatile("v_sub_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b))
+#define PA_ADD(d, a, b) asm volatile("v_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b))
+#define PA_EXP(d, a) asm volatile("v_exp_f32 %0, %1" : "=v"(d) : "v"(a))
+#define PA_CVT(d, a, b) asm volatile(PA_CVT_ASM " %0, %1, %2" : "=v"(d) : "v"(a), "v"(b))
+#endif
+#if P4A_DBG & 3
+#define PA_HALFMAX(x) x = half_max(x)
+#else
+#define PA_HALFMAX(x) do { float hm_; asm volatile("v_mov_b32 %1, %0\n\tv_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 0\n\tv_max_f32 %0, %0, %1" : "+v"(x), "=&v"(hm_)); } while (0)
+#endif
+#define PA_NOP1() asm volatile("s_nop 1")
+#define PA_NOP11() asm volatile("s_nop 10")
+#define PA_PFRAG(T, X) do { X.f0 = p4_pfrag(t[T], 0); X.f1 = p4_pfrag(t[T], 1); } while (0)
+#define PA_VREAD(s_, dt_) vf[s_][dt_] = p4_read_v(c, g_, s_, dt_)
+#define PA_KREAD() do { if (c.g < c.total_g) p4_read_k(c, c.g, kf); } while (0)
+#define PA_ADVANCE() p4_advance(c, next_item)
+#define DEC(T, X) do { if (P4A_FIRST || __any(X.mxr > 8.0f)) { TCOW_NO_IFCVT(); p4a_rescale<P4A_FIRST>(t[T], X.mxr); } } while (0)
+
+struct P4AScr {                      // softmax temporaries of one query tile (registers; the second half of tile B's step lives across rounds)
+    float t0, t1, t2, t3, t4, u0, u1, mx, mxr, pa, pb;
+    float d[16], p[16], sm[16];
+    bf16x8 f0, f1;
+};
+
+template <bool FIRST>
+__device__ __forceinline__ void p4a_rescale(P4Tile& t, float mxr) {
+    const float delta = FIRST ? mxr : fmaxf(mxr, 0.0f);
+    t.m += delta;
+    if (!FIRST) {
+        const float alpha = __builtin_amdgcn_exp2f(-delta);
+        t.l *= alpha;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { t.o0[r] *= alpha; t.o1[r] *= alpha; }
+    }
+}
+
+#include "attn_round_asm.inc"
+
+template <int NW, int NQ, int MODE, bool PAD, typename F>
+__device__ __forceinline__ void p4a_round(P4Ctx<NW>& c, P4Tile (&t)[NQ], bf16x8 (&kf)[4], bf16x8 (&vf)[2][2], P4AScr& A, P4AScr& B, const float (&padadd)[16], F&& next_item) {
+    constexpr bool P4A_FIRST = MODE == P4_FIRST;
+    const int g_ = c.g;
+    (void)g_; (void)padadd;
+    if constexpr (NQ == 2) {
+        if constexpr (MODE == P4_FIRST) P4A_ROUND_NQ2_FIRST();
+        else if constexpr (MODE == P4_DRAIN) P4A_ROUND_NQ2_DRAIN();
+        else if constexpr (PAD) P4A_ROUND_NQ2_STEADY_PAD();
+        else P4A_ROUND_NQ2_STEADY();
+    } else {
+        static_assert(NQ == 1, "asm rounds: one or two query tiles per wave");
+        if constexpr (MODE == P4_FIRST) P4A_ROUND_NQ1_FIRST();
+        else if constexpr (PAD) P4A_ROUND_NQ1_STEADY_PAD();
+        else P4A_ROUND_NQ1_STEADY();
+    }
+}
+
 // query tiles of an item that wave w owns: NW = 4: tiles w, w + 4, w + 8 of the chunk; NW = 8: waves 0-3 take tiles w, w + 4, waves 4-7 tile 8 + (w - 4)
 // (the SIMD of waves w and w + 4 then carries 3 / 3 / 2 / 2 of ten tiles either way)
 template <int NW> __device__ __forceinline__ int p4_nqw(int n, int wave) {
@@ -427,12 +518,25 @@ __device__ __forceinline__ void p4_run_item(P4Ctx<NW>& c, const SeqDesc& sd, con
         bf16x8 vf[2][2];
         P4_STAMP(const long long ti1_ = P4_NOW(); c.t_pro += ti1_ - ti0_;)
         // (sequences of at least two key tiles: tcow_attn_fwd_p4_ok; the last key tile's round masks the padding keys when L % 32 != 0)
-        p4_round<NW, NQ, P4_FIRST, false, AG>(c, t, kf, vf, next_item);
+        if constexpr (NW == 8 && P4_ASM_ROUNDS) {
+            P4AScr A, B;
+            float padadd[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) padadd[r] = (crow32(r, c.hi) >= c.lr) ? -1e30f : 0.0f;
+            p4a_round<NW, NQ, P4_FIRST, false>(c, t, kf, vf, A, B, padadd, next_item);
 #pragma unroll 1
-        for (int j = 1; j < c.nt - 1; ++j) p4_round<NW, NQ, P4_STEADY, false, AG>(c, t, kf, vf, next_item);
-        if (lastpad_seq) p4_round<NW, NQ, P4_STEADY, true, AG>(c, t, kf, vf, next_item);
-        else p4_round<NW, NQ, P4_STEADY, false, AG>(c, t, kf, vf, next_item);
-        if constexpr (NQ > 1) p4_round<NW, NQ, P4_DRAIN, false, AG>(c, t, kf, vf, next_item);
+            for (int j = 1; j < c.nt - 1; ++j) p4a_round<NW, NQ, P4_STEADY, false>(c, t, kf, vf, A, B, padadd, next_item);
+            if (lastpad_seq) p4a_round<NW, NQ, P4_STEADY, true>(c, t, kf, vf, A, B, padadd, next_item);
+            else p4a_round<NW, NQ, P4_STEADY, false>(c, t, kf, vf, A, B, padadd, next_item);
+            if constexpr (NQ > 1) p4a_round<NW, NQ, P4_DRAIN, false>(c, t, kf, vf, A, B, padadd, next_item);
+        } else {
+            p4_round<NW, NQ, P4_FIRST, false, AG>(c, t, kf, vf, next_item);
+#pragma unroll 1
+            for (int j = 1; j < c.nt - 1; ++j) p4_round<NW, NQ, P4_STEADY, false, AG>(c, t, kf, vf, next_item);
+            if (lastpad_seq) p4_round<NW, NQ, P4_STEADY, true, AG>(c, t, kf, vf, next_item);
+            else p4_round<NW, NQ, P4_STEADY, false, AG>(c, t, kf, vf, next_item);
+            if constexpr (NQ > 1) p4_round<NW, NQ, P4_DRAIN, false, AG>(c, t, kf, vf, next_item);
+        }
         // ---- normalise, store whole rows through the staging tile, log-sum-exp
         P4_STAMP(const long long ti2_ = P4_NOW(); c.t_rounds += ti2_ - ti1_;)
         p4_acc_fence<AG>();
