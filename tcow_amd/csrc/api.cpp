@@ -211,6 +211,11 @@ int tcow_gemm_tn_grouped(void* stream, int dtype, int n, const tcow_tn_problem* 
     for (int i = 0; i < n; ++i) {
         slabs[i] = (float*)w; w += (long)(nz_req + 1) * pr[i].N * pr[i].K * 4;
         parts[i] = pr[i].bias_grad ? (float*)w : nullptr; w += (long)(nz_req + 1) * ((pr[i].K + 255) / 256) * 2 * pr[i].N * 4 + 64;
+        // ONE token slice (a group whose tiles fill whole rounds of the chip by themselves: five ViT-B blocks = 765 tiles): nothing to fold, so the
+        // kernel writes a dense, non-accumulating weight gradient straight into its destination -- no slab image written, re-read and copied
+        // (2 x 177 MB per five-block group); only the bias-gradient partials still go through the fold launch
+        if (nz_req == 1 && !pr[i].accumulate && pr[i].lddw == pr[i].K && tcow_fold_vec_ok(pr[i].dW, (long)pr[i].N * pr[i].K, pr[i].K, pr[i].dW, pr[i].lddw))
+            slabs[i] = pr[i].dW;
     }
     int nz = 0;
     int rc = tcow_gemm_tn_bf16_group((hipStream_t)stream, n, pr, nz_req, slabs, parts, &nz, nparts);

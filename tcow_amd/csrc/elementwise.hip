@@ -208,6 +208,30 @@ __global__ void unpatchify_pool_fwd_kernel(int BT, int Hp, int Wp, int P, int C,
         pooled[i] = a * inv;
     }
 }
+// The same for stride 4 and P % 8 == 0 (the path's head: P = 16) with 16-byte loads: one thread takes 8 consecutive patch pixels of FOUR consecutive
+// patch rows (a 4 x 8 block of one channel of one token = two pooled outputs), i.e. four loads 2 P elements apart and one 8-byte store -- the
+// one-output version reads its 4 x 4 window as sixteen 2-byte loads (48 us for 41 MB at configs[1]).
+template <typename T>
+__global__ __launch_bounds__(256) void unpatchify_pool4_fwd_kernel(int BT, int Hp, int Wp, int P, int C, const T* __restrict__ pm, float* __restrict__ pooled) {
+    const int S = Hp * Wp + 1, Ps = P / 4, Ho = Hp * Ps, Wo = Wp * Ps, K = C * P * P, P8 = P / 8;
+    const int per_tok = C * Ps * P8;                         // threads per token: channel x pooled row x 8-pixel piece
+    const long total = (long)BT * (S - 1) * per_tok;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int tok = (int)(i / per_tok), r = (int)(i - (long)tok * per_tok);
+        const int piece = r % P8, yb = (r / P8) % Ps, c = r / (P8 * Ps);
+        const int bt = tok / (S - 1), n = tok - bt * (S - 1), hp = n / Wp, wp = n - hp * Wp;
+        const T* src = pm + ((size_t)bt * S + 1 + n) * K + (size_t)c * P * P + (4 * yb) * P + piece * 8;
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int dy = 0; dy < 4; ++dy) {
+            const float4 u = ld4(src + dy * P), v = ld4(src + dy * P + 4);
+            a0 += (u.x + u.y) + (u.z + u.w); a1 += (v.x + v.y) + (v.z + v.w);
+        }
+        float* o = pooled + (((size_t)bt * C + c) * Ho + hp * Ps + yb) * Wo + wp * Ps + piece * 2;
+        *reinterpret_cast<float2*>(o) = make_float2(a0 * 0.0625f, a1 * 0.0625f);
+    }
+}
+
 template <typename T>
 __global__ void unpatchify_pool_bwd_kernel(int BT, int Hp, int Wp, int P, int C, int st, const float* __restrict__ dpooled, T* __restrict__ dpm) {
     const int S = Hp * Wp + 1, Ps = P / st, Ho = Hp * Ps, Wo = Wp * Ps, K = C * P * P;
@@ -593,6 +617,13 @@ int tcow_cls_merge_bwd_cast(void* stream, int dtype, int B, int T_, int S, int D
 int tcow_unpatchify_pool_fwd(void* stream, int dtype, int BT, int Hp, int Wp, int P, int C, int st, const void* pm, float* pooled) {
     TCOW_CHECK_ARG(BT > 0 && Hp > 0 && Wp > 0 && P > 0 && C > 0 && st > 0 && P % st == 0 && pm && pooled, "tcow_unpatchify_pool_fwd: bad arguments");
     const long total = (long)BT * C * Hp * Wp * (P / st) * (P / st);
+    if (st == 4 && P % 8 == 0 && ((P / 4) * Wp) % 2 == 0 && (dtype == TCOW_BF16 || dtype == TCOW_F32)) {      // the path's head: 16-byte loads (see the kernel)
+        const long nthr = (long)BT * Hp * Wp * C * (P / 4) * (P / 8);
+        if (dtype == TCOW_BF16) hipLaunchKernelGGL(unpatchify_pool4_fwd_kernel<bf16_t>, dim3(gs_blocks(nthr)), dim3(256), 0, (hipStream_t)stream, BT, Hp, Wp, P, C, (const bf16_t*)pm, pooled);
+        else hipLaunchKernelGGL(unpatchify_pool4_fwd_kernel<float>, dim3(gs_blocks(nthr)), dim3(256), 0, (hipStream_t)stream, BT, Hp, Wp, P, C, (const float*)pm, pooled);
+        TCOW_CHECK_LAUNCH();
+        return TCOW_OK;
+    }
     if (dtype == TCOW_BF16) hipLaunchKernelGGL(unpatchify_pool_fwd_kernel<bf16_t>, dim3(gs_blocks(total)), dim3(256), 0, (hipStream_t)stream, BT, Hp, Wp, P, C, st, (const bf16_t*)pm, pooled);
     else if (dtype == TCOW_F32) hipLaunchKernelGGL(unpatchify_pool_fwd_kernel<float>, dim3(gs_blocks(total)), dim3(256), 0, (hipStream_t)stream, BT, Hp, Wp, P, C, st, (const float*)pm, pooled);
     else { tcow_set_error("tcow_unpatchify_pool_fwd: unknown dtype %d", dtype); return TCOW_ERR_INVALID_ARG; }

@@ -337,13 +337,15 @@ int tcow_launch_slab_reduce_group(hipStream_t stream, int n, const float* const*
         const long nel = rows[i] * cols[i];
         j.slab = slab[i]; j.slab_stride = nel; j.n4 = nel / 4; j.cols4 = cols[i] / 4; j.ldo = ldo[i]; j.out = out[i];
         j.part = bias_part[i]; j.bias_out = bias_out[i]; j.nz = nz; j.accumulate = accumulate[i];
-        j.slab_blocks = (int)cdiv(nel / 4, FOLD_BLK); j.nparts = bias_nparts[i]; j.N = (int)rows[i];
+        j.slab_blocks = slab[i] == out[i] ? 0 : (int)cdiv(nel / 4, FOLD_BLK);       // (slab == destination: the GEMM wrote its single slice in place)
+        j.nparts = bias_nparts[i]; j.N = (int)rows[i];
         j.blocks = j.slab_blocks + (bias_part[i] ? cdiv(rows[i], 16) : 0);
         g.first[i] = first;
         first += j.blocks;
     }
     for (int i = n; i < 40; ++i) { g.j[i] = g.j[0]; }
     for (int i = n; i <= 40; ++i) g.first[i] = first;
+    if (first == 0) return TCOW_OK;
     hipLaunchKernelGGL(slab_reduce4_group_kernel, dim3(first), dim3(256), 0, stream, g);
     TCOW_CHECK_LAUNCH();
     return TCOW_OK;
