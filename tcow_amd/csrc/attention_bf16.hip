@@ -804,9 +804,12 @@ __global__ __launch_bounds__(768) void attn_bwd_one_kernel(SeqDesc sd, int nt, c
     const int cw = wave - 10;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(LDS_PTR(char))smem;
     // strip write of this wave's dS block: lane (key l31, hi) holds queries 4 hi + {0..3}, 8 + .., 16 + .., 24 + ..: four 8-byte quads (slots
-    // hi, 2 + hi, 4 + hi, 6 + hi of the key's 64-byte row; slot s of key row k sits at s ^ (k & 7))
+    // hi, 2 + hi, 4 + hi, 6 + hi of the key's 64-byte row; slot s of key row k sits at s ^ ((k >> 1) & 7): a ds_write_b64 is served in groups of 16
+    // consecutive lanes over 32 banks -- rows of equal parity share their banks, so the eight of a group must differ in the slot --, and the chain
+    // waves' transpose reads in groups of 32 lanes over 64 banks: rows 8 g4 + tr, g4 = 0 / 1, must differ in bit 2 of the slot.  With k & 7, as in
+    // round 4, rows k and k + 8 met on one bank in both: SQ_LDS_BANK_CONFLICT = 17 % of the LDS cycles, profiles/r04_pmc_attn.txt.)
     const uint32_t sw = lds0 + ONE_STRIP + (32 * wave + l31) * 64;
-    const int k7 = l31 & 7;
+    const int k7 = (l31 >> 1) & 7;
 
     if (chain_wave) {
         // ---- the chain waves' own loop (a separate one: their 80 registers of K^T fragments must not be live across the tile-step code)
@@ -816,8 +819,8 @@ __global__ __launch_bounds__(768) void attn_bwd_one_kernel(SeqDesc sd, int nt, c
         const int krow = 8 * g4 + tr;                                                        // key row inside a 32-key tile (second read: + 4)
         const int kchunk = 4 * cw + (tc >> 1);                                               // channel block 2 cw; block 2 cw + 1 = chunk + 2 = offset ^ 32
         const uint32_t ko0 = ONE_K + krow * 128 + ((kchunk ^ swz_g(krow)) << 4) + (tc & 1) * 8, ko1 = ONE_K + (krow + 4) * 128 + ((kchunk ^ swz_g(krow + 4)) << 4) + (tc & 1) * 8;
-        const uint32_t so0 = ONE_STRIP + krow * 64 + ((tc ^ (krow & 7)) << 3);               // query half 0; half 1 = slot ^ 4 = offset ^ 32
-        const uint32_t so1 = ONE_STRIP + (krow + 4) * 64 + ((tc ^ ((krow + 4) & 7)) << 3);
+        const uint32_t so0 = ONE_STRIP + krow * 64 + ((tc ^ ((krow >> 1) & 7)) << 3);        // query half 0; half 1 = slot ^ 4 = offset ^ 32
+        const uint32_t so1 = ONE_STRIP + (krow + 4) * 64 + ((tc ^ (((krow + 4) >> 1) & 7)) << 3);
         // K^T fragments of ALL key tiles, once: they are the same in every step (80 registers the tile-step waves do not have to spare)
         u32x2_ kfr[ONE_MAX_NT][4];
 #pragma unroll

@@ -96,6 +96,17 @@ __device__ __forceinline__ void st4(bf16_t* p, float4 v) {
     *reinterpret_cast<uint2*>(p) = u;
 }
 
+// 16-byte store / load with a cache policy chosen per call site: NT = non-temporal (`nt` on the instruction) -- for a stream far larger than the
+// L2s (4 MB per XCD) that nobody re-reads soon.  A normal store allocates its line in L2 and pushes out lines other workgroups still share (GEMM
+// operand tiles); a non-temporal one does not stay.  Measured per stream: profiles/r05_nontemporal.txt (one stream of the path qualifies).
+typedef uint32_t tcow_u32x4 __attribute__((ext_vector_type(4)));
+template <bool NT> __device__ __forceinline__ void st16c(void* p, uint4 w) {
+    if constexpr (NT) __builtin_nontemporal_store((tcow_u32x4){w.x, w.y, w.z, w.w}, reinterpret_cast<tcow_u32x4*>(p)); else *reinterpret_cast<uint4*>(p) = w;
+}
+template <bool NT> __device__ __forceinline__ uint4 ld16c(const void* p) {
+    if constexpr (NT) { const tcow_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const tcow_u32x4*>(p)); return make_uint4(v[0], v[1], v[2], v[3]); } else return *reinterpret_cast<const uint4*>(p);
+}
+
 // ---- math
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float gelu_erf_grad(float x) {

@@ -433,7 +433,10 @@ int tcow_gemm_nt_bf16(hipStream_t stream, const tcow_gemm_args* a) {
         // It takes the shapes where it measured ahead of the 320 tile at M = 27 090 (profiles/r04_gemm_c2.txt): short-K GEMMs with an f32 residual
         // epilogue (the HBM-bound epilogue hides under the co-resident workgroup's main loop) and plain short-K GEMMs of three rounds.  Same-box A/B
         // of the training step in round 4: 28.05 / 28.10 ms with this routing, 28.24 / 28.30 ms without the kernel.
-        const bool c2_pick = a->K <= 1024 && ((a->out_f32 && a->resid) || (a->act == TCOW_ACT_NONE && !a->row_scale && !a->resid && !a->bias2 && a->N >= 2304 && a->N < 3072));
+        // ... and, since round 5, the x GELU' epilogue (fc2's input gradient): with its aux tile read non-temporally the pair fc2-gradient -> fc1-gradient takes
+        // 250 us on the 160 tile, 260 on the 320 tile (269 before; profiles/r05_nontemporal.txt)
+        const bool c2_pick = a->K <= 1024 && ((a->out_f32 && a->resid) || (a->act == TCOW_ACT_NONE && !a->row_scale && !a->resid && !a->bias2 && a->N >= 2304 && a->N < 3072) ||
+                                               (a->act == TCOW_ACT_MUL_AUX && !a->out_f32 && !a->row_scale && !a->resid && !a->bias2));
         if (a->tile == 160 || (a->tile == 0 && c2_pick && fills && t320 >= 200 && tcow_gemm_nt_c2_ok(a))) {
             TCOW_CHECK_ARG(tcow_gemm_nt_c2_ok(a), "tcow_gemm_nt(bf16): tile 160 needs K %% 128 == 0 and operands below 2 GiB");
             return tcow_gemm_nt_bf16_c2(stream, a);

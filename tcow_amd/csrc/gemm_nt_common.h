@@ -58,29 +58,50 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
 // t = 1 / (1 + p z), |error| <= 1.5e-7 -- four orders of magnitude below the bf16 rounding of the result, and the exponential
 // is exp(-x^2 / 2), i.e. the normal density GELU' needs anyway.  ~20 VALU operations per element where erff + expf take ~75
 // (measured: the erff epilogues added 120 us (GELU) and 200 us (GELU') to a 170 us fc1-shaped GEMM).
-__device__ __forceinline__ void gelu_parts(float x, float& cdf, float& pdf) {
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    const float e = __expf(-z * z);
-    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
-    const float erfabs = fmaf(-poly, e, 1.0f);
-    cdf = fmaf(0.5f, copysignf(erfabs, x), 0.5f);
-    pdf = 0.39894228040143267794f * e;
+// The arithmetic runs on PAIRS of elements with gfx950's packed-f32 instructions (v_pk_mul_f32 / v_pk_fma_f32: two lanes' worth of f32 work per issue
+// slot): per pair 14 packed operations + 2 x (|x| scale, rcp, exp2, sign insert) -- 16 issue slots per element instead of 22.  Same operation sequence
+// per element as the scalar form (each fma / mul / add is the same IEEE operation): identical results.  (Round 5 measured this as time-neutral: the
+// GELU GEMMs are bound by their store streams, not by VALU issue -- see the cache policy note below; kept for the lower instruction count.)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 pk_set(float v) { return (f32x2){v, v}; }
+__device__ __forceinline__ void gelu_parts2(f32x2 x, f32x2& cdf, f32x2& pdf) {
+    const f32x2 z = {fabsf(x.x) * 0.70710678118654752440f, fabsf(x.y) * 0.70710678118654752440f};
+    const f32x2 den = pk_fma(pk_set(0.3275911f), z, pk_set(1.0f));
+    const f32x2 t = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+    const f32x2 nzz = (-z) * z;
+    const f32x2 e = {__expf(nzz.x), __expf(nzz.y)};
+    const f32x2 poly = t * pk_fma(t, pk_fma(t, pk_fma(t, pk_fma(t, pk_set(1.061405429f), pk_set(-1.453152027f)), pk_set(1.421413741f)), pk_set(-0.284496736f)), pk_set(0.254829592f));
+    const f32x2 erfabs = pk_fma(-poly, e, pk_set(1.0f));
+    const f32x2 erfs = {copysignf(erfabs.x, x.x), copysignf(erfabs.y, x.y)};
+    cdf = pk_fma(pk_set(0.5f), erfs, pk_set(0.5f));
+    pdf = pk_set(0.39894228040143267794f) * e;
 }
-__device__ __forceinline__ float gelu_fast(float x) { float c, d; gelu_parts(x, c, d); return x * c; }
-__device__ __forceinline__ float dgelu_fast(float x) { float c, d; gelu_parts(x, c, d); return fmaf(x, d, c); }
-__device__ __forceinline__ float4 gelu4(float4 v) { return make_float4(gelu_fast(v.x), gelu_fast(v.y), gelu_fast(v.z), gelu_fast(v.w)); }
-__device__ __forceinline__ float4 dgelu4(float4 v, float4 a) {
-    return make_float4(v.x * dgelu_fast(a.x), v.y * dgelu_fast(a.y), v.z * dgelu_fast(a.z), v.w * dgelu_fast(a.w));
+__device__ __forceinline__ float4 gelu4(float4 v) {
+    f32x2 c0, q0, c1, q1; const f32x2 a = {v.x, v.y}, b = {v.z, v.w};
+    gelu_parts2(a, c0, q0); gelu_parts2(b, c1, q1);
+    const f32x2 g0 = a * c0, g1 = b * c1;
+    return make_float4(g0.x, g0.y, g1.x, g1.y);
+}
+__device__ __forceinline__ float4 dgelu4(float4 v, float4 x) {
+    f32x2 c0, q0, c1, q1; const f32x2 a = {x.x, x.y}, b = {x.z, x.w};
+    gelu_parts2(a, c0, q0); gelu_parts2(b, c1, q1);
+    const f32x2 d0 = (f32x2){v.x, v.y} * pk_fma(a, q0, c0), d1 = (f32x2){v.z, v.w} * pk_fma(b, q1, c1);
+    return make_float4(d0.x, d0.y, d1.x, d1.y);
 }
 // GELU and GELU' of the same argument (one erf / exp for both)
 __device__ __forceinline__ void gelu_both4(float4 v, float4& g, float4& d) {
-    float c, q;
-    gelu_parts(v.x, c, q); g.x = v.x * c; d.x = fmaf(v.x, q, c);
-    gelu_parts(v.y, c, q); g.y = v.y * c; d.y = fmaf(v.y, q, c);
-    gelu_parts(v.z, c, q); g.z = v.z * c; d.z = fmaf(v.z, q, c);
-    gelu_parts(v.w, c, q); g.w = v.w * c; d.w = fmaf(v.w, q, c);
+    f32x2 c0, q0, c1, q1; const f32x2 a = {v.x, v.y}, b = {v.z, v.w};
+    gelu_parts2(a, c0, q0); gelu_parts2(b, c1, q1);
+    const f32x2 g0 = a * c0, g1 = b * c1, d0 = pk_fma(a, q0, c0), d1 = pk_fma(b, q1, c1);
+    g = make_float4(g0.x, g0.y, g1.x, g1.y); d = make_float4(d0.x, d0.y, d1.x, d1.y);
 }
+
+// Cache policy.  The GELU' tile fc1's forward epilogue saves (166 MB at configs[1]) is read exactly once, a whole backward pass later: it is written with
+// NON-TEMPORAL stores and read (x GELU' epilogue) with non-temporal loads, so that it does not push the operand tiles the workgroups of a GEMM share out
+// of the 4 MB L2s: fc1 -> fc2 pair 354 -> 343 us, fc2-gradient -> fc1-gradient pair 269 -> 260 us.  Every other stream of the epilogues (16-bit output
+// tiles by epilogue kind, f32 outputs, residual loads) measured neutral or slower that way -- the next kernel re-reads them through the Infinity
+// Cache (profiles/r05_nontemporal.txt).
 
 struct EpiRow { float4 ext; float rs, rs2; };
 
@@ -268,7 +289,7 @@ __device__ __forceinline__ void wave_tile_epilogue_160x64(const NtParams& p, cha
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
                     const int gm = mrow8 + u * 32 + it * 8;
-                    a[it] = (ok8 && gm < p.M) ? *reinterpret_cast<const uint4*>(p.aux + (size_t)gm * p.ldaux + gn8) : make_uint4(0u, 0u, 0u, 0u);
+                    a[it] = (ok8 && gm < p.M) ? ld16c<true>(p.aux + (size_t)gm * p.ldaux + gn8) : make_uint4(0u, 0u, 0u, 0u);
                 }
             };
             fetch_ax(ax[0], 0); fetch_ax(ax[1], 1); fetch_ax(ax[2], 2);
@@ -343,7 +364,7 @@ __device__ __forceinline__ void wave_tile_epilogue_160x64(const NtParams& p, cha
                 if (E::act(p) == TCOW_ACT_GELU_DSAVE) {
                     float4 g0, d0, g1, d1; gelu_both4(v0, g0, d0); gelu_both4(v1, g1, d1);
                     uint4 w; w.x = pack_bf2(d0.x, d0.y); w.y = pack_bf2(d0.z, d0.w); w.z = pack_bf2(d1.x, d1.y); w.w = pack_bf2(d1.z, d1.w);
-                    *reinterpret_cast<uint4*>(p.aux + (size_t)gm * p.ldaux + gn8) = w;
+                    st16c<true>(p.aux + (size_t)gm * p.ldaux + gn8, w);
                     v0 = g0; v1 = g1;
                 } else if (E::act(p) == TCOW_ACT_GELU) {
                     if (p.aux) {

@@ -354,6 +354,13 @@ def test_im2col_normalisation_and_embeddings(ops, cuda, mname):
     ops.embed_bwd(gsrc, B, T, S, dpos, dtime)
     g4 = gsrc.reshape(B, T, S, D)
     assert rel(dpos, g4.sum((0, 1))) < 1e-5 and rel(dtime, g4[:, :, 1:].sum((0, 2))) < 1e-5
+    # more frames than one unrolled round of the position-gradient kernel (24), a last channel block that is not full, accumulate mode
+    B2, T2, S2, D2 = 3, 10, 5, 320
+    g2 = torch.randn(B2 * T2 * S2, D2, device=cuda, generator=g)
+    dpos2 = torch.ones(S2, D2, device=cuda); dtime2 = torch.ones(T2, D2, device=cuda)
+    ops.embed_bwd(g2, B2, T2, S2, dpos2, dtime2, accumulate=True)
+    g24 = g2.double().reshape(B2, T2, S2, D2)
+    assert rel(dpos2, 1 + g24.sum((0, 1))) < 1e-6 and rel(dtime2, 1 + g24[:, :, 1:].sum((0, 2))) < 1e-6
 
 
 def test_cls_merge_and_adjoint(ops, cuda):
@@ -390,6 +397,10 @@ def test_mask_head_pool_upsample(ops, cuda, st, bilinear):
     pooled = torch.empty(B * T, C, Hp * P // st, Wp * P // st, device=cuda)
     ops.unpatchify_pool_fwd(ops.F32, pm, B * T, Hp, Wp, P, C, st, pooled)
     assert rel(pooled, ref) < 1e-6
+    pb = torch.empty_like(pooled)                                                       # the binary-16 operand image of the same values (the path's head at bf16)
+    ops.unpatchify_pool_fwd(ops.BF16, pm.bfloat16(), B * T, Hp, Wp, P, C, st, pb)
+    xb = pm.bfloat16().double().reshape(B, T, S, C, P, P)[:, :, 1:].reshape(B, T, Hp, Wp, C, P, P).permute(0, 1, 4, 2, 5, 3, 6).reshape(B * T, C, Hp * P, Wp * P)
+    assert rel(pb, F.avg_pool2d(xb, st, st) if st > 1 else xb) < 1e-6
     if st > 1:
         up = F.interpolate(ref, scale_factor=st, mode='bilinear', align_corners=True) if bilinear else F.interpolate(ref, scale_factor=st, mode='nearest')
     else:
