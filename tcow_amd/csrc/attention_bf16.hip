@@ -510,10 +510,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_one_tile(SeqDesc sd, const bf
     char* qt_ = smem + wave * (4 * TILE_B + 256);
     char* kt = qt_ + TILE_B; char* vt = kt + TILE_B; char* dot_ = vt + TILE_B;
     float2* ldw = reinterpret_cast<float2*>(dot_ + TILE_B);
-    load_tile(qh, pse, 0, sd.L, qt_, lane);
-    load_tile(qh + sd.D, pse, 0, sd.L, kt, lane);
-    load_tile(qh + 2 * sd.D, pse, 0, sd.L, vt, lane);
-    load_tile(doh, pso, 0, sd.L, dot_, lane);
+    load_tile<LD_NT>(qh, pse, 0, sd.L, qt_, lane);
+    load_tile<LD_NT>(qh + sd.D, pse, 0, sd.L, kt, lane);
+    load_tile<LD_NT>(qh + 2 * sd.D, pse, 0, sd.L, vt, lane);
+    load_tile<LD_NT>(doh, pso, 0, sd.L, dot_, lane);
     const int qc = l31 < sd.L ? l31 : sd.L - 1;
     const float ls = lse[(base + (long)qc * sd.pos_stride) * sd.heads + w.head] * kLog2e;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -753,13 +753,13 @@ __global__ __launch_bounds__(768) void attn_bwd_one_kernel(SeqDesc sd, int nt, c
     ONE_STAMP(0);
     // ---- prologue: K_w / V_w tiles, the first two Q / dO tiles (a 1 KiB quarter per wave 0-7), the (lse, delta) table of query tile w
     if (owner) {
-        load_tile(qh + sd.D, pse, 32 * wave, sd.L, ktiles + wave * TILE_B, lane);
-        load_tile(qh + 2 * sd.D, pse, 32 * wave, sd.L, vtiles + wave * TILE_B, lane);
+        load_tile<LD_NT>(qh + sd.D, pse, 32 * wave, sd.L, ktiles + wave * TILE_B, lane);
+        load_tile<LD_NT>(qh + 2 * sd.D, pse, 32 * wave, sd.L, vtiles + wave * TILE_B, lane);
     }
     auto load_qdo = [&](int i, int buf) {                     // waves 0-3: quarter `wave` of Q_i, waves 4-7: quarter `wave - 4` of dO_i
         char* dst = smem + ONE_QDO + buf * (2 * TILE_B);
-        if (wave < 4) load_tile_chunk(qh, pse, 32 * i, sd.L, dst, wave, lane);
-        else if (wave < 8) load_tile_chunk(doh, pso, 32 * i, sd.L, dst + TILE_B, wave - 4, lane);
+        if (wave < 4) load_tile_chunk<LD_NT>(qh, pse, 32 * i, sd.L, dst, wave, lane);
+        else if (wave < 8) load_tile_chunk<LD_NT>(doh, pso, 32 * i, sd.L, dst + TILE_B, wave - 4, lane);
     };
     load_qdo(0, 0);
     if (nt > 1) load_qdo(1, 1);

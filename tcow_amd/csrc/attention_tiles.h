@@ -35,27 +35,35 @@ __device__ __forceinline__ float half_sum(float v) { float a = v, b = v; half_sw
 
 __device__ __forceinline__ int swz_g(int r) { return (((r >> 1) & 1) << 2) | ((r >> 2) & 3); }
 
+// AUX = cache policy bits of the load: 0 plain, LD_NT = non-temporal.  The backward kernels whose workgroup (or wave) is the only reader of its
+// (frame, head)'s q / k / v / dO -- attn_bwd_one_kernel, attn_bwd_one_tile -- load them non-temporally: tiles written a whole forward pass ago and never
+// read again should not displace what the neighbouring kernels share through the L2s (-0.14 ms per step together with LayerNorm backward's saved
+// input, profiles/r05_nontemporal.txt).  The forward kernels keep plain loads: their K / V tiles are shared by the workgroups of a (frame, head).
+constexpr int LD_NT = 2;
+template <int AUX = 0>
 __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((GLB_PTR(const uint32_t))gsrc, (LDS_PTR(uint32_t))lds_wave_base, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((GLB_PTR(const uint32_t))gsrc, (LDS_PTR(uint32_t))lds_wave_base, 16, 0, AUX);
 }
 
 // one wave loads a [32][64] bf16 tile: positions p0..p0+31 (clamped to L-1 so that padding rows hold finite data)
+template <int AUX = 0>
 __device__ __forceinline__ void load_tile(const bf16_t* src, long pse, int p0, int L, char* tile, int lane) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int r = 8 * j + (lane >> 3);
         const int c = (lane & 7) ^ swz_g(r);
         int pos = p0 + r; pos = pos < L ? pos : L - 1;
-        glds16(src + (size_t)pos * pse + c * 8, tile + j * 1024);
+        glds16<AUX>(src + (size_t)pos * pse + c * 8, tile + j * 1024);
     }
 }
 
 // rows 8c .. 8c+7 of such a tile (a quarter: one direct-to-LDS instruction)
+template <int AUX = 0>
 __device__ __forceinline__ void load_tile_chunk(const bf16_t* src, long pse, int p0, int L, char* tile, int c, int lane) {
     const int r = 8 * c + (lane >> 3);
     const int ch = (lane & 7) ^ swz_g(r);
     int pos = p0 + r; pos = pos < L ? pos : L - 1;
-    glds16(src + (size_t)pos * pse + ch * 8, tile + c * 1024);
+    glds16<AUX>(src + (size_t)pos * pse + ch * 8, tile + c * 1024);
 }
 
 // Streaming kernels: tiles c0 .. c0+CH-1 of two row sources into the LDS tile arrays ta / tb.  Wave w of the 4-wave workgroup brings tile c0+w;

@@ -109,7 +109,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int D, const T* _
         for (int i = 0; i < NV; ++i) {
             const int c = lane + i * 64;
             if (FULL || c < nv) {
-                xn[i] = ld4(x + (size_t)r * ldx + c * 4);
+                {   // (the layer's saved input: written a forward pass ago, read once -- non-temporal, see attention_tiles.h)
+                    typedef float f4v __attribute__((ext_vector_type(4)));
+                    const f4v t = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(x + (size_t)r * ldx + c * 4));
+                    xn[i] = make_float4(t[0], t[1], t[2], t[3]);
+                }
                 dn[i] = ld4(dy + (size_t)r * lddy + c * 4);
             }
         }
