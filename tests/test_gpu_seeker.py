@@ -42,7 +42,7 @@ def h16(precision):
 def h16f(precision):
     """The same for the occlusion flags: a clip has only T x 3 of them, and the maximum over so few samples moves by 2x between equivalent
     roundings of the same network (g11_depth24 in fp16: 0.99e-3 with the temporal projection as two GEMMs, 2.2e-3 folded into one; in bf16
-    the other way round, 9.9e-3 vs 4.1e-3 -- TCOW_FOLD=0 / 1 with tools/dev_bf16_ratios.py), so the binary16 bound keeps a factor 1.6 of slack."""
+    the other way round, 9.9e-3 vs 4.1e-3 -- measured with and without the fold in round 3, tools/dev_bf16_ratios.py), so the binary16 bound keeps a factor 1.6 of slack."""
     return 0.2 if precision == 'fp16' else 1.0
 
 

@@ -1,5 +1,5 @@
 """Dev: time the spatial attention kernels one by one (HIP events around single launches) at the benchmark shape + check EVERY (frame, head) vs torch.
-Environment: B (3), S (301), T (30), TCOW_ATTN_P4 = 0 | 4 | 8 (read by the library), FWD_ONLY=1."""
+Environment: B (3), S (301), T (30), FWD_ONLY=1.  (TCOW_LIB=<another build> compares builds on one box.)"""
 import os, sys, torch
 sys.path.insert(0, '.')
 from tcow_amd import ops
@@ -25,7 +25,7 @@ ref_lse = torch.logsumexp(sc, -1).permute(0, 2, 1).reshape(M, heads)
 ef = (out.float() - ref).abs().max().item(); el = (lse - ref_lse).abs().max().item()
 bad = (~torch.isfinite(out.float())).sum().item()
 tf = bench(lambda: ops.attn_fwd(shape, True, qkv, out, lse))
-msg = f'P4={os.environ.get("TCOW_ATTN_P4", "default")} S={S} B={B} T={T}: spatial fwd {tf:.1f} us | max|d| out {ef:.2e} lse {el:.2e} non-finite {bad} (ref max {ref.abs().max().item():.2f})'
+msg = f'S={S} B={B} T={T}: spatial fwd {tf:.1f} us | max|d| out {ef:.2e} lse {el:.2e} non-finite {bad} (ref max {ref.abs().max().item():.2f})'
 if not os.environ.get('FWD_ONLY'):
     tb = bench(lambda: ops.attn_bwd(shape, True, qkv, out, dout, lse, dqkv))
     xg = qkv.float().reshape(B, T, S, 3, heads, 64)[0, 0].requires_grad_(True)       # S,3,h,64
