@@ -261,8 +261,10 @@ int tcow_upsample_fwd(void* stream, int B, int T, int C, int h, int w, int st, i
                       float* out);
 int tcow_upsample_bwd(void* stream, int B, int T, int C, int h, int w, int st, int bilinear, const float* dout,
                       float* dpooled);
-/* tcow_upsample_bwd for the bilinear stride-4 head (h, w > 4) that also leaves max |dout| in *amax_bits as a float bit pattern (atomic maximum: the
- * caller zeroes it) -- the statistic the binary16 mode's power-of-two loss scale is chosen from, taken in the pass that reads dout anyway. */
+/* tcow_upsample_bwd for the bilinear stride-4 head (h, w > 4) that also leaves max |dout| in amax_bits[0 .. TCOW_AMAX_SLOTS) as float bit patterns:
+ * max |dout| = the maximum of the slots (atomic maxima, one per workgroup, spread over the slots; the caller zeroes all of them) -- the statistic the
+ * binary16 mode's power-of-two loss scale is chosen from, taken in the pass that reads dout anyway.  (ABI 9: one slot before.) */
+#define TCOW_AMAX_SLOTS 64
 int tcow_upsample_bwd_amax(void* stream, int B, int T, int C, int h, int w, int st, const float* dout, float* dpooled,
                            unsigned* amax_bits);
 int tcow_flags_fwd(void* stream, int BT, int S, int D, int F, const float* x, const float* Wf, const float* bf,
@@ -295,6 +297,11 @@ int tcow_cast_transpose_batched(void* stream, int dtype, const void* table, int 
 long tcow_adamw_chunk_bytes(void);
 int tcow_adamw_clip_step(void* stream, const void* chunks, int n_chunks, float lr, float beta1, float beta2, float eps,
                          float weight_decay, int step, float max_norm, float* scratch);
+/* The same on gradients that are still multiplied by a loss scale (binary16 training): *grad_inv_scale (device scalar, a power of two; NULL = 1) is
+ * the inverse scale.  The norm and the clip coefficient are those of the true gradients, the update multiplies the stored gradients by
+ * coefficient x inverse scale -- exact, and the separate unscaling pass over all gradients is gone.  (ABI 9) */
+int tcow_adamw_clip_step_scaled(void* stream, const void* chunks, int n_chunks, float lr, float beta1, float beta2, float eps,
+                                float weight_decay, int step, float max_norm, float* scratch, const float* grad_inv_scale);
 
 /* ------------------------------------------------------------------------------------------- mask objective (caller row L)
  * One channel of the TCOW mask loss, forward value and d(loss)/d(logits) together (loss.py:164-225, with

@@ -113,6 +113,7 @@ SIGNATURES = {
     'tcow_cast_transpose_batched': (_i, [_vp, _i, _vp, _i, _i]),
     'tcow_adamw_chunk_bytes': (_l, []),
     'tcow_adamw_clip_step': (_i, [_vp, _vp, _i, _f, _f, _f, _f, _f, _i, _f, _vp]),
+    'tcow_adamw_clip_step_scaled': (_i, [_vp, _vp, _i, _f, _f, _f, _f, _f, _i, _f, _vp, _vp]),
     'tcow_mask_loss_workspace_bytes': (ctypes.c_size_t, [_l, _l]),
     'tcow_mask_loss': (_i, [_vp, ctypes.POINTER(MaskLossArgs)]),
     'tcow_iou_counts': (_i, [_vp, _vp, _vp, _l, _l, _vp]),

@@ -402,8 +402,16 @@ __global__ void upsample_bwd_kernel(int B, int T_, int C, int h, int w, int st, 
         dpooled[i] = a;
     }
     if (amax_bits) {
+        // one atomic per WORKGROUP, spread over TCOW_AMAX_SLOTS words (the caller takes the maximum of the slots): device-scope atomics on ONE word are
+        // served one after the other (~10 ns each) -- with one per wave on one word the 16 000 of them were 160 us of a 200 us kernel
+        __shared__ float wmax[4];
         for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
-        if ((threadIdx.x & 63) == 0 && amax > 0.f) atomicMax(amax_bits, __builtin_bit_cast(unsigned, amax));      // (non-negative floats order as their bit patterns)
+        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = amax;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+            if (m > 0.f) atomicMax(amax_bits + (blockIdx.x & (TCOW_AMAX_SLOTS - 1)), __builtin_bit_cast(unsigned, m));      // (non-negative floats order as their bit patterns)
+        }
     }
 }
 

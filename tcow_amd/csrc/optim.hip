@@ -25,7 +25,12 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const Chunk* __restrict__ ch
     if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-__global__ __launch_bounds__(256) void clipcoef_kernel(const float* __restrict__ partial, int n, float max_norm, float* __restrict__ out /* [0]=coef, [1]=norm, [2]+=skipped */) {
+// gscale (may be NULL): the gradients in memory are g_true / *gscale' -- i.e. still multiplied by a loss scale whose INVERSE is *gscale (a power of two).
+// The norm is taken of the true gradients and the coefficient handed to the update kernel carries the inverse scale, so the update kernel's
+// g * coef is clip(g_true) exactly (powers of two commute with every rounding here): the binary16 mode's unscaling pass over all gradients
+// (488 MB read + written per step) disappears into this one-workgroup kernel.
+__global__ __launch_bounds__(256) void clipcoef_kernel(const float* __restrict__ partial, int n, float max_norm, float* __restrict__ out /* [0]=coef, [1]=norm, [2]+=skipped */,
+                                                       const float* __restrict__ gscale) {
     __shared__ float red[4];
     float s = 0.f;
     for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
@@ -33,11 +38,12 @@ __global__ __launch_bounds__(256) void clipcoef_kernel(const float* __restrict__
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const float norm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+        const float gs = gscale ? gscale[0] : 1.0f;
+        const float norm = sqrtf((red[0] + red[1]) + (red[2] + red[3])) * gs;
         float coef = max_norm > 0.f ? max_norm / (norm + 1e-6f) : 1.0f;
         // a non-finite gradient norm (an overflow in a 16-bit backward) marks the step as skipped: coefficient -1
         const bool skip = !(norm <= 3.0e38f);
-        out[0] = skip ? -1.0f : (coef < 1.0f ? coef : 1.0f);
+        out[0] = skip ? -1.0f : (coef < 1.0f ? coef : 1.0f) * gs;
         out[1] = norm;
         if (skip) out[2] += 1.0f;                  // steps skipped so far (every precision): the update kernel counts them out of its bias correction
     }
@@ -80,17 +86,23 @@ long tcow_adamw_chunk_bytes(void) { return (long)sizeof(Chunk); }
 // on return scratch[n_chunks] = clip coefficient (-1 = step skipped), scratch[n_chunks + 1] = total gradient norm,
 // scratch[n_chunks + 2] += 1 if the step was skipped (the caller zeroes it once; device side, no sync).  `step` = number of calls so far
 // (>= 1); the bias correction uses step - scratch[n_chunks + 2].
-int tcow_adamw_clip_step(void* stream, const void* chunks, int n_chunks, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
-                         float max_norm, float* scratch) {
+// tcow_adamw_clip_step_scaled: the gradients are still multiplied by a loss scale; grad_inv_scale (device scalar, a power of two; NULL = 1) is its inverse.
+int tcow_adamw_clip_step_scaled(void* stream, const void* chunks, int n_chunks, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                                float max_norm, float* scratch, const float* grad_inv_scale) {
     TCOW_CHECK_ARG(chunks && scratch && n_chunks > 0 && step >= 1, "tcow_adamw_clip_step: bad arguments");
     const Chunk* c = (const Chunk*)chunks;
     hipLaunchKernelGGL(sumsq_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, c, scratch);
     TCOW_CHECK_LAUNCH();
-    hipLaunchKernelGGL(clipcoef_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, scratch, n_chunks, max_norm, scratch + n_chunks);
+    hipLaunchKernelGGL(clipcoef_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, scratch, n_chunks, max_norm, scratch + n_chunks, grad_inv_scale);
     TCOW_CHECK_LAUNCH();
     hipLaunchKernelGGL(adamw_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, c, scratch + n_chunks, lr, beta1, beta2, eps, weight_decay, step);
     TCOW_CHECK_LAUNCH();
     return TCOW_OK;
+}
+
+int tcow_adamw_clip_step(void* stream, const void* chunks, int n_chunks, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                         float max_norm, float* scratch) {
+    return tcow_adamw_clip_step_scaled(stream, chunks, n_chunks, lr, beta1, beta2, eps, weight_decay, step, max_norm, scratch, nullptr);
 }
 
 }  // extern "C"

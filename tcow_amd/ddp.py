@@ -80,6 +80,11 @@ class GradSync:
         self._fresh = True
         self._exposed = collections.deque(maxlen=STATS_WINDOW)   # per finish(): (start event, end event) on the compute stream, or seconds on the CPU path
 
+    @property
+    def active(self):
+        """False when the hook moves nothing (one rank, not forced): engine.run_backward may then leave the binary16 loss scale for the optimizer to undo."""
+        return self.world > 1 or self.force
+
     def _launch(self, flat):
         op = dist.ReduceOp.AVG if self.native_avg else dist.ReduceOp.SUM
         wire = flat.to(torch.bfloat16) if self.bucket_dtype == 'bf16' else flat

@@ -299,11 +299,14 @@ def upsample_bwd(dout, B, T, C, h, w, st, bilinear, dpooled):
     return dpooled
 
 
+AMAX_SLOTS = 64          # TCOW_AMAX_SLOTS of include/tcow_hip.h
+
+
 def upsample_bwd_amax(dout, B, T, C, h, w, st, dpooled):
     """upsample_bwd (bilinear, stride 4, h, w > 4) that also returns max |dout| as a 0-dim f32 device tensor (see tcow_upsample_bwd_amax)."""
-    bits = torch.zeros(1, dtype=torch.int32, device=dout.device)
+    bits = torch.zeros(AMAX_SLOTS, dtype=torch.int32, device=dout.device)           # TCOW_AMAX_SLOTS partial maxima (one atomic per workgroup, spread over the slots)
     L.check(L.lib().tcow_upsample_bwd_amax(_stream(), B, T, C, h, w, st, dout.data_ptr(), dpooled.data_ptr(), bits.data_ptr()), 'tcow_upsample_bwd_amax')
-    return dpooled, bits.view(torch.float32)[0]
+    return dpooled, bits.view(torch.float32).amax()
 
 
 def flags_fwd(x, BT, S, Wf, bf, flags):

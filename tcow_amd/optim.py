@@ -53,6 +53,7 @@ class FusedAdamWClip(torch.optim.Optimizer):
             if hasattr(tracker, 'invalidate_weight_cache'):
                 self.on_step.append(tracker.invalidate_weight_cache)
             tracker.__dict__['_optim_attached'] = True      # (engine.run_backward warns when precision='fp16' trains without one: its loss scale could never recover)
+            tracker.__dict__['_optim_unscales'] = True      # binary16: gradient buckets may stay loss-scaled, step() folds the inverse scale into the clip coefficient (engine.run_backward)
         assert L.lib().tcow_adamw_chunk_bytes() == 40
 
     @property
@@ -139,12 +140,14 @@ class FusedAdamWClip(torch.optim.Optimizer):
         if not live:
             return loss
         step = self._step_base + self._steps_pending + 1
-        L.check(L.lib().tcow_adamw_clip_step(_ops_stream(), self._table.data_ptr(), self._table.shape[0], float(grp['lr']),
-                                             float(grp['betas'][0]), float(grp['betas'][1]), float(grp['eps']), float(grp['weight_decay']), step,
-                                             float(self.max_norm or 0.0), self.scratch.data_ptr()), 'tcow_adamw_clip_step')
+        trk = self._tracker
+        inv_scale = trk.__dict__.pop('pending_inv_scale', None) if trk is not None else None      # binary16: the last backward left its gradients loss-scaled
+        L.check(L.lib().tcow_adamw_clip_step_scaled(_ops_stream(), self._table.data_ptr(), self._table.shape[0], float(grp['lr']),
+                                                    float(grp['betas'][0]), float(grp['betas'][1]), float(grp['eps']), float(grp['weight_decay']), step,
+                                                    float(self.max_norm or 0.0), self.scratch.data_ptr(), inv_scale.data_ptr() if inv_scale is not None else None),
+                'tcow_adamw_clip_step_scaled')
         # precision='fp16': a non-finite gradient norm means the scaled backward overflowed binary16 -- the kernels above skipped the update
         # (clip coefficient -1); lower the module's loss-scale exponent by 4, otherwise let it creep back towards -2.  All on the device.
-        trk = self._tracker
         ls = getattr(trk, 'ls_log2', None) if trk is not None and getattr(trk, 'precision', None) == 'fp16' and getattr(trk, 'loss_scale', None) == 'dynamic' else None
         if ls is not None and ls.device == self.scratch.device:
             ok = self.scratch[-3] >= 0                       # clip coefficient -1 = skipped

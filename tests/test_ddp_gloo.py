@@ -67,6 +67,15 @@ def test_single_process_is_a_noop():
     assert torch.equal(t, torch.ones(5)) and sync.pending == []
 
 
+def test_a_hook_of_one_rank_says_it_is_inactive():
+    """engine.run_backward leaves the binary16 loss scale to the optimizer only when no ACTIVE data-parallel hook is attached (ranks choose their own
+    scales, so buckets must be unscaled before they are averaged): a GradSync of one rank is inactive unless forced."""
+    from tcow_amd import ddp
+    assert ddp.GradSync(world_size=1).active is False
+    assert ddp.GradSync(world_size=1, force=True).active is True
+    assert ddp.GradSync(world_size=2).active is True
+
+
 def test_bench_self_launches_n_ranks():
     """`python bench.py --gpus 2` with no launcher around it must start two ranks itself (it silently ran one) --
     exercised on CPU through the launch self-test (gloo), which stops before any GPU work."""

@@ -8,6 +8,8 @@ the domain offers at full size.  Stated tolerances (north_star: mask-logit max|d
               tools/dev_bf16_ratios.py; 3.4e-3 absolute at BASELINE configs[1], logit std 0.154); flags < 0.012 x their std (measured
               <= 0.0077).  bf16 operands cannot reach 1e-3 at these logit scales: profiles/r02_bf16_error_budget.txt (weight copies alone
               2.7e-3; every activation class 0.2 ... 2.0e-3); the reference itself under bf16 autocast deviates by 8e-3."""
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -557,6 +559,42 @@ def test_fp16_overflow_skips_the_step_and_lowers_the_loss_scale(cuda):
     opt.zero_grad(set_to_none=True); om, fl = net(rgb, qm); (om.square().mean() + fl.square().mean()).backward(); opt.step()          # scale 2^-4 of before: still a good step
     assert not all(torch.equal(a, p.detach()) for a, p in zip(before, net.parameters()))
     assert all(bool(torch.isfinite(p).all()) for p in net.parameters()) and -6.0 < float(net.seeker.ls_log2) < -5.9
+
+
+def test_fp16_unscaling_inside_the_optimizer_is_bit_identical(cuda):
+    """precision='fp16' with FusedAdamWClip(module=net) and no data-parallel hook: the backward leaves the gradient buckets loss-scaled and the
+    optimizer folds the inverse scale (a power of two) into its clip coefficient (tcow_adamw_clip_step_scaled) instead of a multiplication pass
+    over every bucket.  Same parameters, moments and gradient norm, bit for bit, as the path that unscales in the backward; param.grad of the
+    deferred path = scaled gradient, pending_inv_scale = the factor."""
+    from tcow_amd.optim import FusedAdamWClip
+    cfg = synth.seeker_config(num_total_frames=4, frame_height=32, frame_width=32, embed_dim=128, depth=2, num_heads=2, causal_attention=1)
+    sd = synth.make_state_dict(cfg, 5)
+    clip = synth.make_clip(1, 4, 32, 32, seed=2)
+    rgb = torch.from_numpy(clip['rgb']).cuda(); qm = torch.from_numpy(synth.make_query_mask(clip, 0, 0)).cuda()
+    out = {}
+    for deferred in (True, False):
+        net = build_hip_seeker(cfg, sd, 'fp16').cuda().train()
+        net.seeker.persistent_grads = True
+        opt = FusedAdamWClip(list(net.parameters()), lr=1e-3, max_norm=0.3, module=net)
+        if not deferred:
+            net.seeker.__dict__['_optim_unscales'] = False
+        norms = []
+        for it in range(3):
+            om, fl = net(rgb, qm)
+            (om.square().mean() * 1e-4 + fl.square().mean() * 1e-4).backward()
+            inv = net.seeker.__dict__.get('pending_inv_scale')
+            assert (inv is not None) == deferred
+            if it == 0:
+                g0 = [p.grad.clone() * (inv if deferred else 1.0) for p in net.parameters() if p.grad is not None]
+            opt.step()
+            assert net.seeker.__dict__.get('pending_inv_scale') is None
+            norms.append(float(opt.grad_norm()))
+        assert not torch.equal(net.seeker.tracker_post_linear.weight.detach().cpu().float(), torch.as_tensor(np.asarray(sd['seeker.tracker_post_linear.weight'])).float())      # the steps did move the parameters
+        out[deferred] = ([p.detach().clone() for p in net.parameters()], [opt.state[p]['exp_avg_sq'].clone() for p in net.parameters() if p in opt.state and 'exp_avg_sq' in opt.state[p]], norms, g0)
+    (pa, va, na, ga), (pb, vb, nb, gb) = out[True], out[False]
+    assert na == nb and all(math.isfinite(x) and x > 0 for x in na)
+    assert all(torch.equal(a, b) for a, b in zip(ga, gb))                 # scaled gradient x inverse scale == the unscaled gradient (power of two)
+    assert all(torch.equal(a, b) for a, b in zip(pa, pb)) and all(torch.equal(a, b) for a, b in zip(va, vb))
 
 
 def test_persistent_gradient_buckets(cuda):
