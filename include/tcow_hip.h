@@ -332,6 +332,9 @@ typedef struct {
 } tcow_mask_loss_args;
 size_t tcow_mask_loss_workspace_bytes(long n_frames, long frame_len);
 int tcow_mask_loss(void* stream, const tcow_mask_loss_args* args);
+/* n <= 4 channels of the objective (args[0 .. n)) as ONE set of launches: same n_frames / frame_len, the same `total` (accumulated in argument
+ * order), a separate workspace each.  (ABI 9) */
+int tcow_mask_loss_batch(void* stream, const tcow_mask_loss_args* args, int n);
 
 /* ------------------------------------------------------------------------------------------- IoU areas (caller row M)
  * eval/metrics.py:19-20,55-66: for each of n_frames contiguous frames of frame_len pixels, counts[f] = {|target|,

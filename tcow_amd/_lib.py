@@ -116,6 +116,7 @@ SIGNATURES = {
     'tcow_adamw_clip_step_scaled': (_i, [_vp, _vp, _i, _f, _f, _f, _f, _f, _i, _f, _vp, _vp]),
     'tcow_mask_loss_workspace_bytes': (ctypes.c_size_t, [_l, _l]),
     'tcow_mask_loss': (_i, [_vp, ctypes.POINTER(MaskLossArgs)]),
+    'tcow_mask_loss_batch': (_i, [_vp, ctypes.POINTER(MaskLossArgs), _i]),
     'tcow_iou_counts': (_i, [_vp, _vp, _vp, _l, _l, _vp]),
     'tcow_build_masks': (_i, [_vp, _i, _i, _i, _i, _l, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'tcow_build_query_masks': (_i, [_vp, _i, _i, _i, _i, _i, _l, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

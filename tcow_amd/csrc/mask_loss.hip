@@ -42,6 +42,12 @@ struct MlWs {
     unsigned* vb;                           // [n_frames * frame_len] bit patterns of the (weighted) loss values: written by pass A, read by the radix passes
 };
 
+// Up to kMaxJobs channels of the objective as ONE set of launches (round 5: the three channels of a step were 30 launches of 2-40 us each; the
+// workgroups of a pass now carry their job in blockIdx.z, the one-workgroup kernels run one workgroup per job): job = one tcow_mask_loss call.
+constexpr int kMaxJobs = 4;
+struct MlJob { MlView v; MlWs ws; float aot, lw; double topk_frac; float* loss; int radix; };
+struct MlBatch { int n; float* total; MlJob j[kMaxJobs]; };
+
 // bce-with-logits and sigmoid of one pixel; identical instruction sequence in every pass (the radix passes rely on it)
 __device__ __forceinline__ void bce_sig(float x, float t, float& bce, float& p) {
     const float e = expf(-fabsf(x));
@@ -67,7 +73,7 @@ __device__ __forceinline__ long elem_off(const MlView& v, int f, long stride) {
 }
 
 // ---- pass 0: which frames carry weight (loss.py:176-181) and the sum of the weights (loss.py:184)
-__global__ void __launch_bounds__(kThreads) ml_frames_kernel(MlView v, MlWs ws) {
+__device__ __forceinline__ void ml_frames_body(const MlView& v, const MlWs& ws) {
     __shared__ double red[kThreads / 64];
     const int f = blockIdx.x;
     const float fwv = v.fw ? v.fw[f] : 1.0f;
@@ -91,7 +97,7 @@ __global__ void __launch_bounds__(kThreads) ml_frames_kernel(MlView v, MlWs ws) 
 }
 
 // ---- control: n_sel, validity, k; clears the histograms
-__global__ void __launch_bounds__(kThreads) ml_ctl_kernel(MlView v, MlWs ws, double topk_frac) {
+__device__ __forceinline__ void ml_ctl_body(const MlView& v, const MlWs& ws, double topk_frac) {
     __shared__ double red[kThreads / 64];
     double nf = 0.0, wsum = 0.0;
     for (int f = threadIdx.x; f < v.n_frames; f += kThreads) { nf += ws.fsel[f] ? 1.0 : 0.0; wsum += ws.fwsum[f]; }
@@ -133,7 +139,7 @@ __device__ __forceinline__ unsigned vbits(float bce, float w, int weighted) {
 }
 
 // ---- pass A: sums for the three terms + level-1 histogram of the loss values
-__global__ void __launch_bounds__(kThreads) ml_stats_kernel(MlView v, MlWs ws) {
+__device__ __forceinline__ void ml_stats_body(const MlView& v, const MlWs& ws) {
     __shared__ unsigned hist[kBins12];
     __shared__ double red[kThreads / 64];
     const int f = blockIdx.y;
@@ -174,7 +180,7 @@ __global__ void __launch_bounds__(kThreads) ml_stats_kernel(MlView v, MlWs ws) {
 }
 
 // ---- levels 2 and 3 of the radix select: histogram the next digit of the values that share the known prefix
-template <int LEVEL> __global__ void __launch_bounds__(kThreads) ml_hist_kernel(MlView v, MlWs ws) {
+template <int LEVEL> __device__ __forceinline__ void ml_hist_body(const MlView& v, const MlWs& ws) {
     __shared__ unsigned hist[kBins12];
     const int f = blockIdx.y;
     const MlCtl* c = ws.ctl;
@@ -206,7 +212,7 @@ template <int LEVEL> __global__ void __launch_bounds__(kThreads) ml_hist_kernel(
 
 // ---- one wave walks a histogram from the top for the bin holding the (k - above)-th largest value;
 //      level 1 also folds the pass-A partial sums (fixed order: deterministic)
-template <int LEVEL> __global__ void __launch_bounds__(kThreads) ml_scan_kernel(MlView v, MlWs ws) {
+template <int LEVEL> __device__ __forceinline__ void ml_scan_body(const MlView& v, const MlWs& ws) {
     __shared__ double red[kThreads / 64];
     MlCtl* c = ws.ctl;
     if (LEVEL == 1) {
@@ -253,7 +259,7 @@ template <int LEVEL> __global__ void __launch_bounds__(kThreads) ml_scan_kernel(
 }
 
 // ---- pass E: gradient of the channel loss w.r.t. the logits + the top-k sum
-__global__ void __launch_bounds__(kThreads) ml_grad_kernel(MlView v, MlWs ws, float aot, float lw) {
+__device__ __forceinline__ void ml_grad_body(const MlView& v, const MlWs& ws, float aot, float lw) {
     __shared__ double red[kThreads / 64];
     const int f = blockIdx.y;
     const MlCtl* c = ws.ctl;
@@ -305,7 +311,7 @@ __global__ void __launch_bounds__(kThreads) ml_grad_kernel(MlView v, MlWs ws, fl
 }
 
 // ---- final: the scalar
-__global__ void __launch_bounds__(kThreads) ml_final_kernel(MlView v, MlWs ws, float aot, float loss_weight, float* loss, float* total) {
+__device__ __forceinline__ void ml_final_body(const MlView& v, const MlWs& ws, float aot, float loss_weight, float* loss, float* total) {
     __shared__ double red[kThreads / 64];
     MlCtl* c = ws.ctl;
     double s = 0.0;
@@ -335,6 +341,18 @@ __global__ void __launch_bounds__(kThreads) ml_final_kernel(MlView v, MlWs ws, f
     if (total) *total += loss_weight * L;
 }
 
+// ---- the launches: one per pass for all jobs of a batch
+__global__ void __launch_bounds__(kThreads) ml_frames_kernel(MlBatch b) { const MlJob& J = b.j[blockIdx.y]; ml_frames_body(J.v, J.ws); }
+__global__ void __launch_bounds__(kThreads) ml_ctl_kernel(MlBatch b) { const MlJob& J = b.j[blockIdx.x]; ml_ctl_body(J.v, J.ws, J.topk_frac); }
+__global__ void __launch_bounds__(kThreads) ml_stats_kernel(MlBatch b) { const MlJob& J = b.j[blockIdx.z]; ml_stats_body(J.v, J.ws); }
+template <int LEVEL> __global__ void __launch_bounds__(kThreads) ml_hist_kernel(MlBatch b) { const MlJob& J = b.j[blockIdx.z]; if (J.radix) ml_hist_body<LEVEL>(J.v, J.ws); }
+template <int LEVEL> __global__ void __launch_bounds__(kThreads) ml_scan_kernel(MlBatch b) { const MlJob& J = b.j[blockIdx.x]; if (LEVEL == 1 || J.radix) ml_scan_body<LEVEL>(J.v, J.ws); }
+__global__ void __launch_bounds__(kThreads) ml_grad_kernel(MlBatch b) { const MlJob& J = b.j[blockIdx.z]; ml_grad_body(J.v, J.ws, J.aot, J.lw); }
+// (one workgroup walks the jobs in order: `total` is accumulated in job order, as the one-launch-per-channel form did)
+__global__ void __launch_bounds__(kThreads) ml_final_kernel(MlBatch b) {
+    for (int i = 0; i < b.n; ++i) { const MlJob& J = b.j[i]; ml_final_body(J.v, J.ws, J.aot, J.lw, J.loss, b.total); __syncthreads(); }
+}
+
 static int ml_nblk(long n_frames, long frame_len) { return (int)(n_frames * ((frame_len / 4 + kVecPerBlock - 1) / kVecPerBlock)); }
 
 }  // namespace
@@ -353,7 +371,7 @@ size_t tcow_mask_loss_workspace_bytes(long n_frames, long frame_len) {
     return b;
 }
 
-int tcow_mask_loss(void* stream, const tcow_mask_loss_args* a) {
+static int ml_make_job(const tcow_mask_loss_args* a, MlJob& J) {
     TCOW_CHECK_ARG(a && a->logits && a->target && a->loss && a->ws, "tcow_mask_loss: null argument");
     TCOW_CHECK_ARG(a->n_frames > 0 && a->frame_len > 0 && a->frames_per_seq > 0 && a->n_frames % a->frames_per_seq == 0,
                    "tcow_mask_loss: bad frame counts");
@@ -363,12 +381,11 @@ int tcow_mask_loss(void* stream, const tcow_mask_loss_args* a) {
     TCOW_CHECK_ARG(a->n_frames * (a->frame_len / 4) < (1L << 31) && a->n_frames < 65536, "tcow_mask_loss: too many pixels for one call");
     TCOW_CHECK_ARG(a->ws_bytes >= tcow_mask_loss_workspace_bytes(a->n_frames, a->frame_len), "tcow_mask_loss: workspace too small");
     TCOW_CHECK_ARG(a->topk_frac > 0.0 && a->topk_frac <= 1.0, "tcow_mask_loss: topk_frac %g outside (0, 1]", a->topk_frac);
-    hipStream_t st = (hipStream_t)stream;
-    MlView v;
+    MlView& v = J.v;
     v.x = a->logits; v.xs = a->logits_seq_stride; v.t = a->target; v.ts = a->target_seq_stride;
     v.pw = a->pixel_w; v.fw = a->frame_w; v.dx = a->dlogits; v.dxs = a->dlogits_seq_stride;
     v.T = (int)a->frames_per_seq; v.L4 = (int)(a->frame_len / 4); v.n_frames = (int)a->n_frames; v.weighted = a->weighted_aot ? 1 : 0;
-    MlWs ws; char* p = (char*)a->ws;
+    MlWs& ws = J.ws; char* p = (char*)a->ws;
     ws.fsel = (int*)p; p += ((size_t)v.n_frames * sizeof(int) + 255) & ~(size_t)255;
     ws.fwsum = (double*)p; p += ((size_t)v.n_frames * sizeof(double) + 255) & ~(size_t)255;
     ws.nblk = ml_nblk(a->n_frames, a->frame_len);
@@ -377,22 +394,46 @@ int tcow_mask_loss(void* stream, const tcow_mask_loss_args* a) {
     ws.ctl = (MlCtl*)p; p += 512;
     ws.vb = (unsigned*)p;
     static_assert(sizeof(MlCtl) <= 512, "control block");
-    const dim3 grid((v.L4 + kVecPerBlock - 1) / kVecPerBlock, v.n_frames);
-    ml_frames_kernel<<<v.n_frames, kThreads, 0, st>>>(v, ws);
-    ml_ctl_kernel<<<1, kThreads, 0, st>>>(v, ws, a->topk_frac);
-    ml_stats_kernel<<<grid, kThreads, 0, st>>>(v, ws);
-    ml_scan_kernel<1><<<1, kThreads, 0, st>>>(v, ws);
-    if (a->topk_frac < 1.0 && a->aot_loss > 0.f) {
-        ml_hist_kernel<2><<<grid, kThreads, 0, st>>>(v, ws);
-        ml_scan_kernel<2><<<1, kThreads, 0, st>>>(v, ws);
-        ml_hist_kernel<3><<<grid, kThreads, 0, st>>>(v, ws);
-        ml_scan_kernel<3><<<1, kThreads, 0, st>>>(v, ws);
+    J.aot = a->aot_loss; J.lw = a->loss_weight; J.topk_frac = a->topk_frac; J.loss = a->loss;
+    J.radix = (a->topk_frac < 1.0 && a->aot_loss > 0.f) ? 1 : 0;
+    return TCOW_OK;
+}
+
+// n <= 4 channels of one objective in one set of launches: the same frame geometry, the same `total` (may be NULL) -- accumulated in argument
+// order --, separate workspaces.
+int tcow_mask_loss_batch(void* stream, const tcow_mask_loss_args* a, int n) {
+    TCOW_CHECK_ARG(a && n >= 1 && n <= kMaxJobs, "tcow_mask_loss_batch: 1 .. %d jobs (got %d)", kMaxJobs, n);
+    MlBatch b; b.n = n; b.total = a[0].total;
+    int any_radix = 0;
+    for (int i = 0; i < n; ++i) {
+        const int rc = ml_make_job(a + i, b.j[i]);
+        if (rc != TCOW_OK) return rc;
+        TCOW_CHECK_ARG(a[i].n_frames == a[0].n_frames && a[i].frame_len == a[0].frame_len && a[i].total == a[0].total,
+                       "tcow_mask_loss_batch: the jobs of a batch share n_frames, frame_len and total");
+        for (int k = 0; k < i; ++k) TCOW_CHECK_ARG(a[k].ws != a[i].ws, "tcow_mask_loss_batch: every job needs its own workspace");
+        any_radix |= b.j[i].radix;
     }
-    ml_grad_kernel<<<grid, kThreads, 0, st>>>(v, ws, a->aot_loss, a->loss_weight);
-    ml_final_kernel<<<1, kThreads, 0, st>>>(v, ws, a->aot_loss, a->loss_weight, a->loss, a->total);
+    for (int i = n; i < kMaxJobs; ++i) b.j[i] = b.j[0];
+    hipStream_t st = (hipStream_t)stream;
+    const MlView& v = b.j[0].v;
+    const dim3 grid((v.L4 + kVecPerBlock - 1) / kVecPerBlock, v.n_frames, n);
+    ml_frames_kernel<<<dim3(v.n_frames, n), kThreads, 0, st>>>(b);
+    ml_ctl_kernel<<<n, kThreads, 0, st>>>(b);
+    ml_stats_kernel<<<grid, kThreads, 0, st>>>(b);
+    ml_scan_kernel<1><<<n, kThreads, 0, st>>>(b);
+    if (any_radix) {
+        ml_hist_kernel<2><<<grid, kThreads, 0, st>>>(b);
+        ml_scan_kernel<2><<<n, kThreads, 0, st>>>(b);
+        ml_hist_kernel<3><<<grid, kThreads, 0, st>>>(b);
+        ml_scan_kernel<3><<<n, kThreads, 0, st>>>(b);
+    }
+    ml_grad_kernel<<<grid, kThreads, 0, st>>>(b);
+    ml_final_kernel<<<1, kThreads, 0, st>>>(b);
     TCOW_CHECK_LAUNCH();
     return TCOW_OK;
 }
+
+int tcow_mask_loss(void* stream, const tcow_mask_loss_args* a) { return tcow_mask_loss_batch(stream, a, 1); }
 
 }  // extern "C"
 

@@ -368,6 +368,33 @@ def mask_loss(logits, target, channel, pixel_w=None, frame_w=None, weighted_aot=
     return loss_out
 
 
+def mask_loss_channels(logits, target, jobs, aot_loss=0.8, topk_frac=1.0, total=None, dlogits=None):
+    """Several channels of the TCOW mask objective in ONE set of launches (tcow_mask_loss_batch).  jobs: up to 4 tuples
+    (channel, pixel_w | None, frame_w | None, weighted_aot, loss_weight, loss_out[1]); `total` receives sum_j loss_weight_j * loss_j in job order."""
+    _need_cuda(logits, target, total, dlogits)
+    BQ, C, T, H, W = logits.shape
+    for t in (logits, target, dlogits):
+        if t is not None and (t.dtype != torch.float32 or not t.is_contiguous() or t.shape != logits.shape):
+            raise L.TcowError('mask_loss: logits / target / dlogits must be contiguous f32 tensors of one shape')
+    n_frames, frame_len = BQ * T, H * W
+    lib = L.lib()
+    nb = lib.tcow_mask_loss_workspace_bytes(n_frames, frame_len)
+    arr = (L.MaskLossArgs * len(jobs))()
+    for i, (channel, pixel_w, frame_w, weighted_aot, loss_weight, loss_out) in enumerate(jobs):
+        _need_cuda(pixel_w, frame_w, loss_out)
+        if pixel_w is not None and (pixel_w.dtype != torch.float32 or not pixel_w.is_contiguous() or pixel_w.numel() != n_frames * frame_len):
+            raise L.TcowError('mask_loss: pixel_w must be a contiguous f32 tensor with one weight per pixel')
+        if frame_w is not None and (frame_w.dtype != torch.float32 or not frame_w.is_contiguous() or frame_w.numel() != n_frames):
+            raise L.TcowError('mask_loss: frame_w must be a contiguous f32 tensor with one weight per frame')
+        ws = workspace(nb, logits.device, 'mask_loss%d' % i)             # every job of a batch needs its own workspace
+        off = channel * T * frame_len * 4
+        arr[i] = L.MaskLossArgs(n_frames, frame_len, T, logits.data_ptr() + off, C * T * frame_len, target.data_ptr() + off, C * T * frame_len,
+                                _p(pixel_w), _p(frame_w), 1 if weighted_aot else 0, float(aot_loss), float(topk_frac), float(loss_weight),
+                                loss_out.data_ptr(), _p(total), (dlogits.data_ptr() + off) if dlogits is not None else None,
+                                C * T * frame_len, ws.data_ptr(), ws.numel())
+    L.check(lib.tcow_mask_loss_batch(_stream(), arr, len(jobs)), 'tcow_mask_loss_batch')
+
+
 def iou_counts(logits, target):
     """(..., H, W) f32 logits / targets -> int32 (..., 3): target area, intersection, union per frame (see tcow_iou_counts)."""
     _need_cuda(logits, target)

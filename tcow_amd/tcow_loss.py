@@ -65,12 +65,14 @@ class FusedMaskObjective(torch.autograd.Function):
         terms = acc[:3]; total = acc[3]
         need_grad = logits.requires_grad
         dl = torch.empty_like(lo) if need_grad else None
+        jobs = []
         for c, (pw, fw, weighted) in enumerate(((snitch_w, None, False), (None, occl_fw, True), (None, cont_fw, True))):
             if lws[c] > 0.0:
-                ops.mask_loss(lo, tg, c, pixel_w=pw, frame_w=fw, weighted_aot=weighted, aot_loss=aot_loss, topk_frac=topk_frac,
-                              loss_weight=lws[c], loss_out=terms[c:c + 1], total=total, dlogits=dl)
+                jobs.append((c, pw, fw, weighted, lws[c], terms[c:c + 1]))
             elif dl is not None:
                 dl[:, c].zero_()
+        if jobs:                                   # the active channels as ONE set of launches (tcow_mask_loss_batch)
+            ops.mask_loss_channels(lo, tg, jobs, aot_loss=aot_loss, topk_frac=topk_frac, total=total, dlogits=dl)
         ctx.dl = dl; ctx.shape = logits.shape
         ctx.mark_non_differentiable(terms)
         return total, terms

@@ -209,6 +209,35 @@ def test_fused_mask_loss_edge_cases(cuda):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('topk_frac', [1.0, 0.3])
+def test_mask_objective_channels_as_one_batch_are_bit_identical(cuda, topk_frac):
+    """tcow_mask_loss_batch: the three channels of the objective as one set of launches (job = blockIdx.z) against three tcow_mask_loss calls --
+    terms, total (accumulated in channel order) and every logit gradient bit for bit; also with one channel left out (loss weight 0)."""
+    from tcow_amd import ops
+    torch.manual_seed(11)
+    dev = 'cuda'
+    BQ, Tn, Hn, Wn = 3, 5, 24, 40
+    lo = torch.randn(BQ, 3, Tn, Hn, Wn, device=dev) * 2; tg = (torch.rand(BQ, 3, Tn, Hn, Wn, device=dev) > 0.7).float()
+    pw = torch.rand(BQ, Tn, Hn, Wn, device=dev) + 0.5
+    fw1 = torch.rand(BQ * Tn, device=dev) + 0.5; fw1[3] = 0.0
+    fw2 = torch.rand(BQ * Tn, device=dev) + 0.5
+    chans = ((0, pw, None, False, 1.0), (1, None, fw1, True, 0.3), (2, None, fw2, True, 0.2))
+    for active in ((0, 1, 2), (0, 2)):
+        single = dict(terms=torch.zeros(3, device=dev), total=torch.zeros((), device=dev), dl=torch.full_like(lo, 7.0))
+        for c, p_, f_, wt, lw in chans:
+            if c in active:
+                ops.mask_loss(lo, tg, c, pixel_w=p_, frame_w=f_, weighted_aot=wt, aot_loss=0.8, topk_frac=topk_frac, loss_weight=lw,
+                              loss_out=single['terms'][c:c + 1], total=single['total'], dlogits=single['dl'])
+        batch = dict(terms=torch.zeros(3, device=dev), total=torch.zeros((), device=dev), dl=torch.full_like(lo, 7.0))
+        ops.mask_loss_channels(lo, tg, [(c, p_, f_, wt, lw, batch['terms'][c:c + 1]) for c, p_, f_, wt, lw in chans if c in active],
+                               aot_loss=0.8, topk_frac=topk_frac, total=batch['total'], dlogits=batch['dl'])
+        assert torch.equal(single['terms'], batch['terms']) and torch.equal(single['total'], batch['total']) and torch.equal(single['dl'], batch['dl'])
+        assert float(batch['total']) > 0 and all(float(batch['terms'][c]) > 0 for c in active)
+        if 1 not in active:
+            assert float((batch['dl'][:, 1] - 7.0).abs().max()) == 0.0            # the channel that was left out is untouched
+
+
+@pytest.mark.gpu
 def test_iou_counts_kernel_matches_tensor_path(cuda):
     """tcow_iou_counts (integer areas, exact) behind calculate_metrics_mask_track vs the tensor reductions on the CPU."""
     torch.manual_seed(3)
