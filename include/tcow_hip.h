@@ -275,6 +275,8 @@ int tcow_flags_fwd(void* stream, int BT, int S, int D, int F, const float* x, co
  *   values / gradients -> GEMM operands (fuses the DropPath scale, vit_utils.py:139-154, in the backward).
  * tcow_cast_transpose: W f32 [N,K] -> Wc `dtype` [N,K] and/or Wt `dtype` [K,N] (either may be NULL): the
  *   per-step operand copies of the f32 master weights (Wt feeds the input-gradient GEMMs). */
+/* x[0 .. n) *= *scale, decided on the device: nothing is read or written when *scale == 1 (the upstream gradient of a scalar loss).  (ABI 9) */
+int tcow_scale_unless_one(void* stream, float* x, long n, const float* scale);
 int tcow_scale_cast(void* stream, int dtype, long rows, int D, const float* src, long ld_src, const float* row_scale,
                     void* dst, long ld_dst);
 /* DropPath row scales of all `depth` blocks of a divided space-time step (vit_utils.py:139-154 at vit.py:172-186) from uniform draws

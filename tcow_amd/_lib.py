@@ -108,6 +108,7 @@ SIGNATURES = {
     'tcow_flags_fwd': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'tcow_droppath_rows': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'tcow_scale_cast': (_i, [_vp, _i, _l, _i, _vp, _l, _vp, _vp, _l]),
+    'tcow_scale_unless_one': (_i, [_vp, _vp, _l, _vp]),
     'tcow_cast_transpose': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     'tcow_cast_desc_bytes': (_l, []),
     'tcow_cast_transpose_batched': (_i, [_vp, _i, _vp, _i, _i]),

@@ -706,6 +706,24 @@ int tcow_flags_fwd(void* stream, int BT, int S, int D, int F, const float* x, co
     return TCOW_OK;
 }
 
+// x *= *scale unless *scale == 1 (then no memory is touched): the upstream gradient of a scalar loss is 1 in the plain training step, and a
+// device-side branch is cheaper than a pass over an 83 MB gradient for it (the host cannot look at a device scalar without a synchronisation).
+__global__ __launch_bounds__(256) void scale_unless_one_kernel(float* __restrict__ x, long n4, long n, const float* __restrict__ scale) {
+    const float s = scale[0];
+    if (s == 1.0f) return;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        float4 v = ld4(x + i * 4); v.x *= s; v.y *= s; v.z *= s; v.w *= s; st4(x + i * 4, v);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < n - n4 * 4) x[n4 * 4 + threadIdx.x] *= s;
+}
+
+int tcow_scale_unless_one(void* stream, float* x, long n, const float* scale) {
+    TCOW_CHECK_ARG(x && scale && n > 0 && ((uintptr_t)x & 15) == 0, "tcow_scale_unless_one: bad arguments");
+    hipLaunchKernelGGL(scale_unless_one_kernel, dim3(gs_blocks(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, x, n / 4, n, scale);
+    TCOW_CHECK_LAUNCH();
+    return TCOW_OK;
+}
+
 int tcow_scale_cast(void* stream, int dtype, long rows, int D, const float* src, long ld_src, const float* row_scale, void* dst, long ld_dst) {
     TCOW_CHECK_ARG(rows > 0 && D > 0 && D % 4 == 0 && src && dst && ld_src % 4 == 0 && ld_dst % 4 == 0, "tcow_scale_cast: bad arguments");
     if (dtype == TCOW_BF16) hipLaunchKernelGGL(scale_cast_kernel<bf16_t>, dim3(gs_blocks(rows * D / 4)), dim3(256), 0, (hipStream_t)stream, rows, D, src, ld_src, row_scale, (bf16_t*)dst, ld_dst);

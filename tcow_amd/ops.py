@@ -314,6 +314,15 @@ def flags_fwd(x, BT, S, Wf, bf, flags):
     return flags
 
 
+def scale_unless_one(x, scale):
+    """x *= scale (a 0-dim / 1-element f32 device tensor) in place, decided on the device: no memory traffic when scale == 1 (tcow_scale_unless_one)."""
+    _need_cuda(x, scale)
+    if x.dtype != torch.float32 or not x.is_contiguous() or scale.dtype != torch.float32 or scale.numel() != 1:
+        raise L.TcowError('scale_unless_one: a contiguous f32 tensor and a one-element f32 scale')
+    L.check(L.lib().tcow_scale_unless_one(_stream(), x.data_ptr(), x.numel(), scale.data_ptr()), 'tcow_scale_unless_one')
+    return x
+
+
 def scale_cast(mode, src, row_scale, dst):
     rows, D = src.shape
     L.check(_sel(mode)[0].tcow_scale_cast(_stream(), _sel(mode)[1], rows, D, src.data_ptr(), src.stride(0), _p(row_scale), dst.data_ptr(), dst.stride(0)), 'tcow_scale_cast', _sel(mode)[0])

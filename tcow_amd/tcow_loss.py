@@ -80,6 +80,12 @@ class FusedMaskObjective(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_total, _g_terms):
         dl = ctx.dl; ctx.dl = None
+        if dl is None:
+            return None, None, None, None, None, None, None, None
+        if g_total.dtype == torch.float32 and g_total.numel() == 1 and g_total.device == dl.device:
+            from . import ops
+            ops.scale_unless_one(dl, g_total.contiguous())          # in place, and not at all when the upstream gradient is 1 (decided on the device)
+            return dl.reshape(ctx.shape), None, None, None, None, None, None, None
         return (dl * g_total).reshape(ctx.shape), None, None, None, None, None, None, None
 
 

@@ -238,6 +238,32 @@ def test_mask_objective_channels_as_one_batch_are_bit_identical(cuda, topk_frac)
 
 
 @pytest.mark.gpu
+def test_loss_gradient_is_scaled_on_the_device_only_when_needed(cuda):
+    """tcow_scale_unless_one (the fused objective's backward): x *= s decided on the device -- s == 1 leaves every bit alone, any other s scales all
+    n elements (n % 4 != 0 included); through autograd: (3 * total).backward() gives three times the gradient of total.backward()."""
+    from tcow_amd import ops
+    from tcow_amd.tcow_loss import FusedMaskObjective
+    torch.manual_seed(2)
+    for n in (1, 7, 4096, 100003):
+        x = torch.randn(n, device='cuda')
+        ref = x.clone()
+        ops.scale_unless_one(x, torch.ones((), device='cuda'))
+        assert torch.equal(x, ref)
+        ops.scale_unless_one(x, torch.full((), 0.5, device='cuda'))
+        assert torch.equal(x, ref * 0.5)
+    BQ, Tn, Hn, Wn = 2, 3, 8, 16
+    lo0 = torch.randn(1, BQ, 3, Tn, Hn, Wn, device='cuda'); tg = (torch.rand(1, BQ, 3, Tn, Hn, Wn, device='cuda') > 0.6).float()
+    sw = torch.rand(1, BQ, Tn, Hn, Wn, device='cuda') + 0.5; fw = torch.rand(BQ * Tn, device='cuda') + 0.5
+    grads = []
+    for mult in (1.0, 3.0):
+        lo = lo0.clone().requires_grad_(True)
+        total, _ = FusedMaskObjective.apply(lo, tg, sw.reshape(BQ, Tn, Hn, Wn).contiguous(), fw, fw, (1.0, 0.5, 0.25), 0.8, 0.5)
+        (total * mult).backward()
+        grads.append(lo.grad.clone())
+    assert float(grads[0].abs().max()) > 0 and torch.equal(grads[1], grads[0] * 3.0)
+
+
+@pytest.mark.gpu
 def test_iou_counts_kernel_matches_tensor_path(cuda):
     """tcow_iou_counts (integer areas, exact) behind calculate_metrics_mask_track vs the tensor reductions on the CPU."""
     torch.manual_seed(3)
