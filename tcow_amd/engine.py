@@ -520,8 +520,8 @@ def run_backward(module, sv, params, d_mask, d_flags):
     # Who undoes the loss scale.  With a data-parallel hook every finished bucket is multiplied back before the hook sees it (ranks choose their own
     # scales).  Without one (or with one that says it is not `active`: a GradSync of one rank), and with a FusedAdamWClip attached that knows how (it says so in module._optim_unscales), the buckets stay scaled and
     # the optimizer's clip-coefficient kernel folds the inverse scale into the update (tcow_adamw_clip_step_scaled): 488 MB less read and written per
-    # step.  param.grad then holds SCALED gradients until optimizer.step() -- torch.cuda.amp.GradScaler's convention; module.pending_inv_scale
-    # (device scalar) is the factor.  Without an attached optimizer the gradients are unscaled here, as before.
+    # step.  param.grad then holds SCALED gradients (as under torch.cuda.amp.GradScaler before unscale_); module.pending_inv_scale (device scalar,
+    # valid until the next backward) is the factor the optimizer applies on the fly.  Without an attached optimizer the gradients are unscaled here, as before.
     defer_unscale = (module.grad_hook is None or getattr(module.grad_hook, 'active', True) is False) and bool(module.__dict__.get('_optim_unscales'))
 
     def publish(tag, flat):

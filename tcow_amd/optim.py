@@ -141,7 +141,7 @@ class FusedAdamWClip(torch.optim.Optimizer):
             return loss
         step = self._step_base + self._steps_pending + 1
         trk = self._tracker
-        inv_scale = trk.__dict__.pop('pending_inv_scale', None) if trk is not None else None      # binary16: the last backward left its gradients loss-scaled
+        inv_scale = trk.__dict__.get('pending_inv_scale') if trk is not None else None      # binary16: the last backward left its gradients loss-scaled (it stays valid until the next backward rewrites them)
         L.check(L.lib().tcow_adamw_clip_step_scaled(_ops_stream(), self._table.data_ptr(), self._table.shape[0], float(grp['lr']),
                                                     float(grp['betas'][0]), float(grp['betas'][1]), float(grp['eps']), float(grp['weight_decay']), step,
                                                     float(self.max_norm or 0.0), self.scratch.data_ptr(), inv_scale.data_ptr() if inv_scale is not None else None),
