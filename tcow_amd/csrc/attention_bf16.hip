@@ -172,8 +172,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_stream(SeqDesc sd, int nt, co
 // (Walking a chunk's tiles by an unrolled loop -- fragment addresses as lane constant + immediate -- was tried: hipcc then carries the accumulators through
 // 50 register copies per step and needs 202 registers, one wave per SIMD less.)
 // The lazy maximum is fwd_tile's: the reference moves only when some row grew by more than 2^8, and the first key tile always sets it.
-__device__ __forceinline__ void fwd_tile_pre(const char* ktile, const char* vtile, const bf16x8 (&qf)[4], bool first, bool pad, int lr, int l31, int hi, int lane, float& m,
-                                             float& l, f32x16& negm, f32x16& o0, f32x16& o1) {
+__device__ __forceinline__ void fwd_tile_pre(const char* ktile, const char* vtile, const bf16x8 (&qf)[4], bool first, bool pad, bool half, int lr, int l31, int hi, int lane,
+                                             float& m, float& l, f32x16& negm, f32x16& o0, f32x16& o1) {
     f32x16 s = TCOW_MFMA_32x32x16_H16(frag_row(ktile, l31, 0, hi), qf[0], negm, 0, 0, 0);      // (negm = 0 until the first key tile has set the reference)
 #pragma unroll
     for (int ks = 1; ks < 4; ++ks) s = TCOW_MFMA_32x32x16_H16(frag_row(ktile, l31, ks, hi), qf[ks], s, 0, 0, 0);
@@ -195,59 +195,115 @@ __device__ __forceinline__ void fwd_tile_pre(const char* ktile, const char* vtil
 #pragma unroll
         for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; s[r] -= delta; negm[r] = -m; }
     }
+    // `half`: the sequence's last key tile when at most 16 of its keys exist (S = 301: 13).  Keys 0..15 of a tile are registers 0..7 of the S^T
+    // accumulator (crow32(r, hi) = 8 (r >> 2) + 4 hi + (r & 3)) and contraction slots 0..15 of the P V product: registers 8..15 are padding (probability
+    // exactly 0), so their exponentials and the second k-step of both P V MFMAs are skipped -- half the softmax arithmetic and 6 instead of 8 MFMAs.
     float p[16];
     float pa = 0.f, pb = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; r += 2) { p[r] = __builtin_amdgcn_exp2f(s[r]); p[r + 1] = __builtin_amdgcn_exp2f(s[r + 1]); pa += p[r]; pb += p[r + 1]; }
-    l += pa + pb;
-    const bf16x8 pb0 = pack8(p), pb1 = pack8(p + 8);
+    for (int r = 0; r < 8; r += 2) { p[r] = __builtin_amdgcn_exp2f(s[r]); p[r + 1] = __builtin_amdgcn_exp2f(s[r + 1]); pa += p[r]; pb += p[r + 1]; }
+    const bf16x8 pb0 = pack8(p);
     o0 = TCOW_MFMA_32x32x16_H16(frag_tr(vtile, 0, 0, lane), pb0, o0, 0, 0, 0);
     o1 = TCOW_MFMA_32x32x16_H16(frag_tr(vtile, 0, 1, lane), pb0, o1, 0, 0, 0);
-    o0 = TCOW_MFMA_32x32x16_H16(frag_tr(vtile, 1, 0, lane), pb1, o0, 0, 0, 0);
-    o1 = TCOW_MFMA_32x32x16_H16(frag_tr(vtile, 1, 1, lane), pb1, o1, 0, 0, 0);
+    if (!half) {
+        TCOW_NO_IFCVT();
+#pragma unroll
+        for (int r = 8; r < 16; r += 2) { p[r] = __builtin_amdgcn_exp2f(s[r]); p[r + 1] = __builtin_amdgcn_exp2f(s[r + 1]); pa += p[r]; pb += p[r + 1]; }
+        const bf16x8 pb1 = pack8(p + 8);
+        o0 = TCOW_MFMA_32x32x16_H16(frag_tr(vtile, 1, 0, lane), pb1, o0, 0, 0, 0);
+        o1 = TCOW_MFMA_32x32x16_H16(frag_tr(vtile, 1, 1, lane), pb1, o1, 0, 0, 0);
+    }
+    l += pa + pb;
 }
 
-template <int CH>
+// Work placement of attn_fwd_stream_nc.  PACK = false: stream_work (a sequence's ceil(nt / 4) workgroups back to back on one XCD).  PACK = true, for
+// nt % 4 == 2 (S = 301: ten query tiles = 4 + 4 + 2): the third workgroup of a (frame, head) would run with two idle waves -- a sixth of the wave
+// slots of a kernel whose throughput is set by how many waves a SIMD has to switch between.  Two sequences that follow each other on an XCD (pairs p
+// and p + 8) form a group of 2 (nt / 4) + 1 workgroups: the full ones of each, and ONE mixed workgroup whose waves 0-1 take the two remaining query
+// tiles of the first sequence and waves 2-3 those of the second; it walks the keys two tiles at a time (wave w stages tile c0 + (w & 1) of ITS
+// sequence: the same 32 KiB of LDS).  An odd sequence out at the end of an XCD's list keeps the ordinary mapping.
+struct NcWork { int pair, qt; bool mixed, valid; };
+template <bool PACK>
+__device__ __forceinline__ NcWork nc_work(int pairs, int nt, int wave) {
+    NcWork w; w.mixed = false;
+    if (!PACK) {
+        const StreamWork sw_ = stream_work(pairs, (nt + 3) / 4);
+        w.pair = sw_.pair; w.qt = sw_.chunk * 4 + wave; w.valid = sw_.valid;
+        return w;
+    }
+    const int nfull = nt >> 2, G = 2 * nfull + 1;
+    const int x = blockIdx.x & 7, k = blockIdx.x >> 3;
+    const int ngr = ((pairs + 7) >> 3) >> 1;                 // groups of two per XCD list
+    int lp, chunk;
+    if (k < ngr * G) {
+        const int g = k / G, slot = k - g * G;
+        if (slot < nfull) { lp = 2 * g; chunk = slot; }
+        else if (slot < 2 * nfull) { lp = 2 * g + 1; chunk = slot - nfull; }
+        else { w.mixed = true; lp = 2 * g + (wave >> 1); chunk = nfull; }
+    } else { lp = 2 * ngr; chunk = k - ngr * G; }
+    w.pair = 8 * lp + x; w.valid = w.pair < pairs;
+    w.qt = w.mixed ? 4 * nfull + (wave & 1) : 4 * chunk + wave;
+    return w;
+}
+static inline int nc_grid(int pairs, int nt, bool pack) {
+    if (!pack) return stream_grid(pairs, (nt + 3) / 4);
+    const int npl = (pairs + 7) >> 3, nfull = nt >> 2;
+    return 8 * ((npl >> 1) * (2 * nfull + 1) + (npl & 1) * (nfull + 1));
+}
+
+template <int CH, bool PACK>
 __global__ __launch_bounds__(256, 2) void attn_fwd_stream_nc(SeqDesc sd, int nt, const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse) {
     __shared__ __attribute__((aligned(16))) char smem[2 * CH * TILE_B];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
-    const StreamWork sw_ = stream_work(sd.n_outer * sd.n_inner * sd.heads, (nt + 3) / 4);
-    if (!sw_.valid) return;
-    const int item = sw_.pair / sd.heads, head = sw_.pair - item * sd.heads;
+    const NcWork nw = nc_work<PACK>(sd.n_outer * sd.n_inner * sd.heads, nt, wave);
+    if (!nw.mixed && !nw.valid) return;                    // (a mixed workgroup whose second sequence does not exist keeps its waves for the barriers)
+    const int item = nw.pair / sd.heads, head = nw.pair - item * sd.heads;
     const long base = seq_base(sd, item);
     const long ld3 = 3L * sd.D, pse = sd.pos_stride * ld3;
     const bf16_t* qh = qkv + base * ld3 + head * ATT_HD;
     char* kt = smem;
     char* vt = smem + CH * TILE_B;
-    load_chunk2<CH>(qh + sd.D, pse, qh + 2 * sd.D, pse, 0, nt, sd.L, kt, vt, wave, lane);
-    const int qt = sw_.chunk * 4 + wave;
-    const bool active = qt < nt;
+    const bool mixed = PACK && nw.mixed;
+    auto load_pair_tiles = [&](int c0) {                   // mixed workgroup: K / V tile c0 + (wave & 1) of this wave's sequence into slot `wave`
+        if (nw.valid) {
+            load_tile(qh + sd.D, pse, 32 * (c0 + (wave & 1)), sd.L, kt + wave * TILE_B, lane);
+            load_tile(qh + 2 * sd.D, pse, 32 * (c0 + (wave & 1)), sd.L, vt + wave * TILE_B, lane);
+        }
+    };
+    if (mixed) load_pair_tiles(0);
+    else load_chunk2<CH>(qh + sd.D, pse, qh + 2 * sd.D, pse, 0, nt, sd.L, kt, vt, wave, lane);
+    const int qt = nw.qt;
+    const bool active = nw.valid && qt < nt;
     const int q = 32 * qt + l31;
     const int qc = q < sd.L ? q : sd.L - 1;
     bf16x8 qf[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
         typedef __attribute__((ext_vector_type(8))) float f32x8;
-        qf[ks] = __builtin_convertvector(__builtin_convertvector(frag_row_global(qh, pse, qc, ks, hi), f32x8) * (kScale * kLog2e), bf16x8);
+        qf[ks] = __builtin_convertvector(__builtin_convertvector(frag_row_global(qh, pse, nw.valid ? qc : 0, ks, hi), f32x8) * (kScale * kLog2e), bf16x8);
     }
     f32x16 o0, o1, negm;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; negm[r] = 0.f; }
     float m = 0.f, l = 0.f;
     const int lr = sd.L - 32 * (nt - 1);                    // valid keys of the last tile
-    const bool pad = lr < 32;
-    for (int c0 = 0; c0 < nt; c0 += CH) {
+    const bool pad = lr < 32, half_last = lr <= 16;
+    const int step = mixed ? 2 : CH, slot0 = mixed ? (wave & 2) : 0;
+    for (int c0 = 0; c0 < nt; c0 += step) {
         if (c0) {
             __syncthreads();                               // previous chunk fully consumed
-            load_chunk2<CH>(qh + sd.D, pse, qh + 2 * sd.D, pse, c0, nt, sd.L, kt, vt, wave, lane);
+            if (mixed) load_pair_tiles(c0);
+            else load_chunk2<CH>(qh + sd.D, pse, qh + 2 * sd.D, pse, c0, nt, sd.L, kt, vt, wave, lane);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        const int jend = (c0 + CH < nt) ? c0 + CH : nt;
+        const int jend = (c0 + step < nt) ? c0 + step : nt;
         if (active)
-            for (int j = c0; j < jend; ++j) fwd_tile_pre(kt + (j - c0) * TILE_B, vt + (j - c0) * TILE_B, qf, j == 0, pad && j == nt - 1, lr, l31, hi, lane, m, l, negm, o0, o1);
+            for (int j = c0; j < jend; ++j)
+                fwd_tile_pre(kt + (slot0 + j - c0) * TILE_B, vt + (slot0 + j - c0) * TILE_B, qf, j == 0, pad && j == nt - 1, half_last && j == nt - 1, lr, l31, hi, lane, m, l, negm,
+                             o0, o1);
     }
     if (active) fwd_store(sd, base, head, q, hi, m, l, o0, o1, out, lse);
 }
@@ -981,7 +1037,10 @@ int tcow_attn_mfma_fwd(hipStream_t st, const SeqDesc& d, bool shared, const void
     const int pairs = d.n_outer * d.n_inner * d.heads;
     if (shared || nt > 2) {
         // (forward: four tiles per chunk -- with five, 40 KiB per workgroup, the fourth workgroup of a CU no longer fits and 56 us become 60)
-        if (d.diag >= (1 << 27) && nt >= 2) hipLaunchKernelGGL(attn_fwd_stream_nc<4>, dim3(stream_grid(pairs, cdiv(nt, 4))), dim3(256), 0, st, d, nt, (const bf16_t*)qkv, (bf16_t*)out, lse);
+        if (d.diag >= (1 << 27) && nt >= 2) {
+            if (nt % 4 == 2) hipLaunchKernelGGL((attn_fwd_stream_nc<4, true>), dim3(nc_grid(pairs, nt, true)), dim3(256), 0, st, d, nt, (const bf16_t*)qkv, (bf16_t*)out, lse);
+            else hipLaunchKernelGGL((attn_fwd_stream_nc<4, false>), dim3(nc_grid(pairs, nt, false)), dim3(256), 0, st, d, nt, (const bf16_t*)qkv, (bf16_t*)out, lse);
+        }
         else hipLaunchKernelGGL(attn_fwd_stream<4>, dim3(stream_grid(pairs, cdiv(nt, 4))), dim3(256), 0, st, d, nt, (const bf16_t*)qkv, (bf16_t*)out, lse);
     } else {
         const int lds = 4 * 3 * nt * TILE_B;

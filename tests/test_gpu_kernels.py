@@ -296,6 +296,9 @@ def _ref_attn(qkv, B, T, S, D, heads, ca, spatial):
     (False, 1, 4, 17, 4, 1), (False, 2, 30, 21, 2, 1), (False, 1, 30, 9, 2, 0), (False, 1, 7, 9, 2, 3), (False, 1, 40, 9, 2, 1), (False, 1, 70, 5, 1, 2),
     (True, 1, 2, 17, 4, 1), (True, 2, 3, 301, 2, 1), (True, 1, 2, 77, 2, 2), (True, 1, 1, 2, 1, 0), (True, 1, 1, 333, 1, 1),
     (True, 1, 2, 100, 2, 1), (True, 1, 1, 161, 1, 1), (True, 2, 1, 256, 2, 1), (True, 1, 1, 289, 3, 1),      # the one-kernel backward's range (4..10 key tiles): ragged / exact / one valid key in the last tile
+    # the forward's packed placement (query tiles 4 + 4 + 2: the remainders of two sequences share a workgroup) with ragged lists per XCD -- a mixed workgroup
+    # whose second sequence does not exist, an odd sequence out, mixed workgroups only (two tiles) -- and its half last key tile (<= 16 keys: 13 / exactly 16 / 17)
+    (True, 1, 3, 301, 5, 1), (True, 1, 3, 40, 3, 1), (True, 1, 5, 173, 5, 1), (True, 1, 2, 304, 2, 1), (True, 1, 2, 305, 3, 0), (True, 3, 9, 301, 1, 1),
     (True, 1, 2, 1201, 12, 1)])          # last: the spatial sequence of BASELINE configs[3] (480x640: 1200 patches + cls)
 def test_attention_fwd_bwd(ops, cuda, mname, tol, spatial, B, T, S, heads, ca):
     """Empty / ragged cases included: S=2 (one patch), T not a multiple of 32, sequences longer than the MFMA limits

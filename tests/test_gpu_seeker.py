@@ -449,7 +449,10 @@ def test_full_size_properties(cuda):
 
 
 def test_train_step_reduces_loss_and_droppath(cuda):
-    from tcow_amd.loss import mask_loss
+    import torch.nn.functional as F
+
+    def mask_loss(logits, target):                                           # a plain objective for the step test (the TCOW objective: test_pipeline_loss_metrics.py)
+        return F.binary_cross_entropy_with_logits(logits, target)
     cfg = synth.seeker_config(num_total_frames=4, frame_height=64, frame_width=64, embed_dim=256, depth=4, num_heads=4, causal_attention=1)
     sd = synth.make_state_dict(cfg, 900)
     net = build_hip_seeker(cfg, sd, 'bf16', drop_path_rate=0.3).cuda().train()
