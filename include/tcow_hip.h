@@ -55,7 +55,9 @@ extern "C" {
 #define TCOW_ACT_GELU_DSAVE 3 /* C = GELU_erf(v) and aux = GELU_erf'(v): the erf / exp are shared, so the      */
 #define TCOW_ACT_MUL_AUX 4   /* backward is C = v * aux -- one multiply instead of a second erf + exp per element */
 
-/* ABI version (bumped on any signature change) and last error text of the calling thread. */
+/* ABI version (bumped on any signature change) and last error text of the calling thread.  A host compares tcow_version() with the TCOW_ABI_VERSION it
+ * was built against before the first call (tcow_amd/_lib.py does, for both builds of the library). */
+#define TCOW_ABI_VERSION 10
 int tcow_version(void);
 const char* tcow_last_error(void);
 
@@ -263,10 +265,12 @@ int tcow_upsample_bwd(void* stream, int B, int T, int C, int h, int w, int st, i
                       float* dpooled);
 /* tcow_upsample_bwd for the bilinear stride-4 head (h, w > 4) that also leaves max |dout| in amax_bits[0 .. TCOW_AMAX_SLOTS) as float bit patterns:
  * max |dout| = the maximum of the slots (atomic maxima, one per workgroup, spread over the slots; the caller zeroes all of them) -- the statistic the
- * binary16 mode's power-of-two loss scale is chosen from, taken in the pass that reads dout anyway.  (ABI 9: one slot before.) */
+ * binary16 mode's power-of-two loss scale is chosen from, taken in the pass that reads dout anyway.  n_slots = the words the caller's buffer holds and must
+ * equal TCOW_AMAX_SLOTS (anything else is TCOW_ERR_INVALID_ARG: ABI 8 wrote ONE word, ABI 9 sixty-four behind an unchanged signature -- a host built
+ * against the older header would have been overrun silently; ABI 10 makes the size part of the call). */
 #define TCOW_AMAX_SLOTS 64
 int tcow_upsample_bwd_amax(void* stream, int B, int T, int C, int h, int w, int st, const float* dout, float* dpooled,
-                           unsigned* amax_bits);
+                           unsigned* amax_bits, int n_slots);
 int tcow_flags_fwd(void* stream, int BT, int S, int D, int F, const float* x, const float* Wf, const float* bf,
                    float* flags);
 
@@ -332,7 +336,11 @@ typedef struct {
     float* dlogits;  long dlogits_seq_stride;
     void* ws;  size_t ws_bytes;
 } tcow_mask_loss_args;
+/* Workspace of one channel: tcow_mask_loss_workspace_bytes = the most any job of this geometry needs; tcow_mask_loss_workspace_bytes_for = what THIS job
+ * needs -- the 4-byte-per-pixel image of loss bit patterns (n_frames * frame_len * 4 bytes, the bulk) only exists when the radix select runs, i.e. when
+ * topk_frac < 1 and aot_loss > 0.  The call checks ws_bytes against the latter.  (ABI 10) */
 size_t tcow_mask_loss_workspace_bytes(long n_frames, long frame_len);
+size_t tcow_mask_loss_workspace_bytes_for(long n_frames, long frame_len, double topk_frac, float aot_loss);
 int tcow_mask_loss(void* stream, const tcow_mask_loss_args* args);
 /* n <= 4 channels of the objective (args[0 .. n)) as ONE set of launches: same n_frames / frame_len, the same `total` (accumulated in argument
  * order), a separate workspace each.  (ABI 9) */

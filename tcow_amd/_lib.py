@@ -104,7 +104,7 @@ SIGNATURES = {
     'tcow_unpatchify_pool_bwd': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'tcow_upsample_fwd': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'tcow_upsample_bwd': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
-    'tcow_upsample_bwd_amax': (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    'tcow_upsample_bwd_amax': (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i]),
     'tcow_flags_fwd': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'tcow_droppath_rows': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'tcow_scale_cast': (_i, [_vp, _i, _l, _i, _vp, _l, _vp, _vp, _l]),
@@ -116,6 +116,7 @@ SIGNATURES = {
     'tcow_adamw_clip_step': (_i, [_vp, _vp, _i, _f, _f, _f, _f, _f, _i, _f, _vp]),
     'tcow_adamw_clip_step_scaled': (_i, [_vp, _vp, _i, _f, _f, _f, _f, _f, _i, _f, _vp, _vp]),
     'tcow_mask_loss_workspace_bytes': (ctypes.c_size_t, [_l, _l]),
+    'tcow_mask_loss_workspace_bytes_for': (ctypes.c_size_t, [_l, _l, ctypes.c_double, _f]),
     'tcow_mask_loss': (_i, [_vp, ctypes.POINTER(MaskLossArgs)]),
     'tcow_mask_loss_batch': (_i, [_vp, ctypes.POINTER(MaskLossArgs), _i]),
     'tcow_iou_counts': (_i, [_vp, _vp, _vp, _l, _l, _vp]),
@@ -125,6 +126,9 @@ SIGNATURES = {
     'tcow_snitch_weights_workspace_bytes': (ctypes.c_size_t, [_l, _i, _i]),
     'tcow_snitch_weights': (_i, [_vp, _l, _i, _i, _i, _vp, _l, _vp, _vp, _vp, _i, _f, _vp, _vp, ctypes.c_size_t]),
 }
+
+
+ABI_VERSION = 10       # TCOW_ABI_VERSION of include/tcow_hip.h
 
 
 def _declare(L):
@@ -150,6 +154,9 @@ def lib(fmt='bf16'):
         L = ctypes.CDLL(path)
         L.tcow_last_error.restype = ctypes.c_char_p
         L.tcow_version.restype = ctypes.c_int
+        if L.tcow_version() != ABI_VERSION and not (fmt == 'bf16' and os.environ.get('TCOW_LIB')):      # (TCOW_LIB: an older build on purpose, same-box A/B of whole libraries)
+            # a stale build next to newer host code (or the reverse): signatures may differ -- refuse before the first call
+            raise TcowError(f'{path} reports ABI version {L.tcow_version()}, this host code was written against {ABI_VERSION} (include/tcow_hip.h): rebuild with `make`')
         _declare(L)
         _libs[fmt] = L
     return L

@@ -35,7 +35,7 @@ static int check_shape(const tcow_attn_shape* s, const char* who) {
     TCOW_CHECK_ARG(s != nullptr, "%s: null shape", who);
     TCOW_CHECK_ARG(s->B > 0 && s->T > 0 && s->S > 1 && s->heads > 0, "%s: bad shape B=%d T=%d S=%d heads=%d", who, s->B, s->T, s->S, s->heads);
     TCOW_CHECK_ARG(s->D == s->heads * ATT_HD, "%s: head_dim must be 64 (D=%d heads=%d)", who, s->D, s->heads);
-    TCOW_CHECK_ARG(s->dtype == TCOW_F32 || s->dtype == TCOW_BF16, "%s: unknown dtype %d", who, s->dtype);
+    TCOW_CHECK_ARG(s->dtype == TCOW_F32 || s->dtype == TCOW_BF16 || s->dtype == TCOW_F32X3, "%s: unknown dtype %d", who, s->dtype);
     return TCOW_OK;
 }
 
@@ -49,6 +49,11 @@ int tcow_attn_mfma_bwd(hipStream_t st, const SeqDesc& d, bool shared, const void
 int tcow_attn_f32_fwd(hipStream_t st, const SeqDesc& d, const void* qkv, void* out, float* lse);
 int tcow_attn_f32_bwd(hipStream_t st, const SeqDesc& d, const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv);
 
+// f32 storage, split-bf16 MFMA arithmetic (attention_x3.hip; dtype TCOW_F32X3): sequences of two or more tiles
+bool tcow_attn_x3_supported(const SeqDesc& d);
+int tcow_attn_x3_fwd(hipStream_t st, const SeqDesc& d, const void* qkv, void* out, float* lse);
+int tcow_attn_x3_bwd(hipStream_t st, const SeqDesc& d, const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv);
+
 static bool use_mfma(const tcow_attn_shape* s, const SeqDesc& d, int spatial) {
     return s->dtype == TCOW_BF16 && tcow_attn_mfma_supported(d, spatial != 0);
 }
@@ -61,6 +66,7 @@ int tcow_attn_fwd_dispatch(hipStream_t st, const tcow_attn_shape* s, int spatial
         if (rc) return rc;
     }
     if (use_mfma(s, d, spatial)) return tcow_attn_mfma_fwd(st, d, spatial != 0, qkv, out, lse);      // 16-bit storage: attention_bf16.hip
+    if (s->dtype == TCOW_F32X3 && tcow_attn_x3_supported(d)) return tcow_attn_x3_fwd(st, d, qkv, out, lse);   // f32 storage, bf16 x 3 split products (attention_x3.hip)
     return tcow_attn_f32_fwd(st, d, qkv, out, lse);                                                   // f32 storage: exact-f32 MFMA kernels (attention_f32.hip)
 }
 
@@ -85,6 +91,7 @@ int tcow_attn_bwd_dispatch(hipStream_t st, const tcow_attn_shape* s, int spatial
         if (rc) return rc;
     }
     if (use_mfma(s, d, spatial)) return tcow_attn_mfma_bwd(st, d, spatial != 0, qkv, out, dout, lse, ws, dqkv);
+    if (s->dtype == TCOW_F32X3 && tcow_attn_x3_supported(d)) return tcow_attn_x3_bwd(st, d, qkv, out, dout, lse, (float*)ws, dqkv);
     return tcow_attn_f32_bwd(st, d, qkv, out, dout, lse, (float*)ws, dqkv);
 }
 

@@ -690,8 +690,9 @@ int tcow_upsample_bwd(void* stream, int B, int T_, int C, int h, int w, int st, 
     return TCOW_OK;
 }
 
-int tcow_upsample_bwd_amax(void* stream, int B, int T_, int C, int h, int w, int st, const float* dout, float* dpooled, unsigned* amax_bits) {
+int tcow_upsample_bwd_amax(void* stream, int B, int T_, int C, int h, int w, int st, const float* dout, float* dpooled, unsigned* amax_bits, int n_slots) {
     TCOW_CHECK_ARG(B > 0 && T_ > 0 && C > 0 && h > 4 && w > 4 && st == 4 && dout && dpooled && amax_bits, "tcow_upsample_bwd_amax: bilinear stride 4 with h, w > 4 only");
+    TCOW_CHECK_ARG(n_slots == TCOW_AMAX_SLOTS, "tcow_upsample_bwd_amax: amax_bits must hold TCOW_AMAX_SLOTS = %d words (got %d)", TCOW_AMAX_SLOTS, n_slots);
     hipLaunchKernelGGL(upsample_bwd_kernel, dim3(gs_blocks((long)B * C * T_ * h * w)), dim3(256), 0, (hipStream_t)stream, B, T_, C, h, w, st, 1, dout, dpooled, amax_bits);
     TCOW_CHECK_LAUNCH();
     return TCOW_OK;

@@ -139,13 +139,13 @@ __device__ __forceinline__ unsigned vbits(float bce, float w, int weighted) {
 }
 
 // ---- pass A: sums for the three terms + level-1 histogram of the loss values
-__device__ __forceinline__ void ml_stats_body(const MlView& v, const MlWs& ws) {
+__device__ __forceinline__ void ml_stats_body(const MlView& v, const MlWs& ws, int radix) {
     __shared__ unsigned hist[kBins12];
     __shared__ double red[kThreads / 64];
     const int f = blockIdx.y;
     const MlCtl* c = ws.ctl;
     const bool live = c->valid && ws.fsel[f];
-    const bool need_hist = live && !c->mode_all;
+    const bool need_hist = live && !c->mode_all && radix;      // (no radix select -- topk_frac = 1 or aot_loss = 0 --: no histogram, and the workspace has no bit-pattern image)
     if (need_hist) { for (int i = threadIdx.x; i < kBins12; i += kThreads) hist[i] = 0u; }
     __syncthreads();
     float s[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
@@ -344,7 +344,7 @@ __device__ __forceinline__ void ml_final_body(const MlView& v, const MlWs& ws, f
 // ---- the launches: one per pass for all jobs of a batch
 __global__ void __launch_bounds__(kThreads) ml_frames_kernel(MlBatch b) { const MlJob& J = b.j[blockIdx.y]; ml_frames_body(J.v, J.ws); }
 __global__ void __launch_bounds__(kThreads) ml_ctl_kernel(MlBatch b) { const MlJob& J = b.j[blockIdx.x]; ml_ctl_body(J.v, J.ws, J.topk_frac); }
-__global__ void __launch_bounds__(kThreads) ml_stats_kernel(MlBatch b) { const MlJob& J = b.j[blockIdx.z]; ml_stats_body(J.v, J.ws); }
+__global__ void __launch_bounds__(kThreads) ml_stats_kernel(MlBatch b) { const MlJob& J = b.j[blockIdx.z]; ml_stats_body(J.v, J.ws, J.radix); }
 template <int LEVEL> __global__ void __launch_bounds__(kThreads) ml_hist_kernel(MlBatch b) { const MlJob& J = b.j[blockIdx.z]; if (J.radix) ml_hist_body<LEVEL>(J.v, J.ws); }
 template <int LEVEL> __global__ void __launch_bounds__(kThreads) ml_scan_kernel(MlBatch b) { const MlJob& J = b.j[blockIdx.x]; if (LEVEL == 1 || J.radix) ml_scan_body<LEVEL>(J.v, J.ws); }
 __global__ void __launch_bounds__(kThreads) ml_grad_kernel(MlBatch b) { const MlJob& J = b.j[blockIdx.z]; ml_grad_body(J.v, J.ws, J.aot, J.lw); }
@@ -359,7 +359,12 @@ static int ml_nblk(long n_frames, long frame_len) { return (int)(n_frames * ((fr
 
 extern "C" {
 
-size_t tcow_mask_loss_workspace_bytes(long n_frames, long frame_len) {
+static size_t ml_ws_bytes(long n_frames, long frame_len, bool radix);
+size_t tcow_mask_loss_workspace_bytes(long n_frames, long frame_len) { return ml_ws_bytes(n_frames, frame_len, true); }
+size_t tcow_mask_loss_workspace_bytes_for(long n_frames, long frame_len, double topk_frac, float aot_loss) {
+    return ml_ws_bytes(n_frames, frame_len, topk_frac < 1.0 && aot_loss > 0.f);
+}
+static size_t ml_ws_bytes(long n_frames, long frame_len, bool radix) {
     if (n_frames <= 0 || frame_len <= 0) return 0;
     size_t b = 0;
     b += ((size_t)n_frames * sizeof(int) + 255) & ~(size_t)255;
@@ -367,7 +372,7 @@ size_t tcow_mask_loss_workspace_bytes(long n_frames, long frame_len) {
     b += ((size_t)ml_nblk(n_frames, frame_len) * kNPart * sizeof(double) + 255) & ~(size_t)255;
     b += (2 * kBins12 + kBins3) * sizeof(unsigned);
     b += 512;
-    b += (size_t)n_frames * (size_t)frame_len * sizeof(unsigned);           // the loss values' bit patterns between pass A and the radix passes
+    if (radix) b += (size_t)n_frames * (size_t)frame_len * sizeof(unsigned);           // the loss values' bit patterns between pass A and the radix passes
     return b;
 }
 
@@ -379,8 +384,8 @@ static int ml_make_job(const tcow_mask_loss_args* a, MlJob& J) {
     TCOW_CHECK_ARG(a->logits_seq_stride % 4 == 0 && a->target_seq_stride % 4 == 0 && a->dlogits_seq_stride % 4 == 0,
                    "tcow_mask_loss: sequence strides must be multiples of 4 elements");
     TCOW_CHECK_ARG(a->n_frames * (a->frame_len / 4) < (1L << 31) && a->n_frames < 65536, "tcow_mask_loss: too many pixels for one call");
-    TCOW_CHECK_ARG(a->ws_bytes >= tcow_mask_loss_workspace_bytes(a->n_frames, a->frame_len), "tcow_mask_loss: workspace too small");
     TCOW_CHECK_ARG(a->topk_frac > 0.0 && a->topk_frac <= 1.0, "tcow_mask_loss: topk_frac %g outside (0, 1]", a->topk_frac);
+    TCOW_CHECK_ARG(a->ws_bytes >= tcow_mask_loss_workspace_bytes_for(a->n_frames, a->frame_len, a->topk_frac, a->aot_loss), "tcow_mask_loss: workspace too small");
     MlView& v = J.v;
     v.x = a->logits; v.xs = a->logits_seq_stride; v.t = a->target; v.ts = a->target_seq_stride;
     v.pw = a->pixel_w; v.fw = a->frame_w; v.dx = a->dlogits; v.dxs = a->dlogits_seq_stride;

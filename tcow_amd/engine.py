@@ -347,11 +347,12 @@ def run_forward(module, rgb, qm, params, save):
     BP, ix = _layout(module)
     joint = module.attention_type != 'divided_space_time'
     fold = _fold_on(module)
-    shape_attn = ops.attn_shape(mode, B, T, S, D, heads, ca)
+    amode = gmode if gmode == ops.F32X3 else mode      # precision='bf16x3': the attention products on split-bf16 MFMAs too (csrc/attention_x3.hip)
+    shape_attn = ops.attn_shape(amode, B, T, S, D, heads, ca)
     if joint:
         jrows = _joint_rows(module, g, dev)
         Lj = 1 + T * (S - 1)
-        shape_joint = ops.attn_shape(mode, B, 1, Lj, D, heads, 0)          # one sequence of 1 + N*T tokens per clip, cls included, no mask (vit.py:159-161)
+        shape_joint = ops.attn_shape(amode, B, 1, Lj, D, heads, 0)          # one sequence of 1 + N*T tokens per clip, cls included, no mask (vit.py:159-161)
     for i in range(module.network_depth):
         q = params[5 + i * BP: 5 + (i + 1) * BP]
         P_ = lambda name, k=0: q[ix[name] + k].detach()                     # weight (k = 0) / bias (k = 1) of a sub-module of this block
@@ -490,7 +491,7 @@ def run_backward(module, sv, params, d_mask, d_flags):
     # out of the adjoint's own pass over d_mask (tcow_upsample_bwd_amax) instead of an abs + amax pair of passes.
     gscale = inv_gscale = None
     ls_mode = getattr(module, 'loss_scale', 'dynamic') if mode == ops.FP16 else None
-    if ls_mode == 'dynamic' and not module.__dict__.get('_optim_attached') and not module.__dict__.get('_warned_ls'):
+    if ls_mode == 'dynamic' and _live_optim(module) is None and not module.__dict__.get('_warned_ls'):
         import warnings
         module.__dict__['_warned_ls'] = True
         warnings.warn("precision='fp16' with the dynamic loss scale but no FusedAdamWClip(..., module=net) attached: nothing lowers the scale "
@@ -518,11 +519,17 @@ def run_backward(module, sv, params, d_mask, d_flags):
     grads = [None] * len(params)
 
     # Who undoes the loss scale.  With a data-parallel hook every finished bucket is multiplied back before the hook sees it (ranks choose their own
-    # scales).  Without one (or with one that says it is not `active`: a GradSync of one rank), and with a FusedAdamWClip attached that knows how (it says so in module._optim_unscales), the buckets stay scaled and
+    # scales).  Without one (or with one that says it is not `active`: a GradSync of one rank), and with a live FusedAdamWClip(module=net) attached, the buckets stay scaled and
     # the optimizer's clip-coefficient kernel folds the inverse scale into the update (tcow_adamw_clip_step_scaled): 488 MB less read and written per
     # step.  param.grad then holds SCALED gradients (as under torch.cuda.amp.GradScaler before unscale_); module.pending_inv_scale (device scalar,
     # valid until the next backward) is the factor the optimizer applies on the fly.  Without an attached optimizer the gradients are unscaled here, as before.
-    defer_unscale = (module.grad_hook is None or getattr(module.grad_hook, 'active', True) is False) and bool(module.__dict__.get('_optim_unscales'))
+    # The deferral needs ONE backward per optimizer step -- several backwards into the same param.grad (the reference's per-query model loop, gradient
+    # accumulation, DataParallel replicas) would make autograd add buckets that carry different scales -- so it is tied to `persistent_grads` (whose
+    # contract is exactly that: each backward OVERWRITES the gradients), never taken by a DataParallel replica, and only while the attached optimizer is
+    # still alive (a weak reference: a discarded or replaced FusedAdamWClip must not leave param.grad scaled for torch.optim.AdamW or clip_grad_norm_).
+    defer_unscale = ((module.grad_hook is None or getattr(module.grad_hook, 'active', True) is False) and _live_optim(module) is not None
+                     and bool(getattr(module, 'persistent_grads', False)) and not getattr(module, '_is_replica', False)
+                     and module.__dict__.get('_defer_unscale', True))                 # (tests switch the deferral off to compare the two paths)
 
     def publish(tag, flat):
         """A finished gradient bucket: undo the loss scale (unless the optimizer will), then hand it to the data-parallel hook."""
@@ -670,11 +677,12 @@ def run_backward(module, sv, params, d_mask, d_flags):
         ops.layernorm_bwd(ops.F32, dFeat, sv['X_final'], sv['muf'], sv['rsf'], params[nb].detach(), None, dX, galloc(nb), galloc(nb + 1))
     else:
         dX = dFeat     # model.norm takes no part when norm_embeddings is False (vision_tf.py:152): its grads stay None
-    shape_attn = ops.attn_shape(mode, B, T, S, D, heads, ca)
+    amode = gmode if gmode == ops.F32X3 else mode      # precision='bf16x3': the attention products on split-bf16 MFMAs too (csrc/attention_x3.hip)
+    shape_attn = ops.attn_shape(amode, B, T, S, D, heads, ca)
     if joint:
         jrows = _joint_rows(module, g, dev)
         Lj = 1 + T * (S - 1)
-        shape_joint = ops.attn_shape(mode, B, 1, Lj, D, heads, 0)
+        shape_joint = ops.attn_shape(amode, B, 1, Lj, D, heads, 0)
     dR3 = dX
     G3_next = None
     for i in reversed(range(module.network_depth)):
@@ -805,6 +813,12 @@ def run_backward(module, sv, params, d_mask, d_flags):
         if hasattr(module.grad_hook, 'finish'):
             module.grad_hook.finish()
     return grads
+
+
+def _live_optim(module):
+    """The FusedAdamWClip attached to this module (FusedAdamWClip(..., module=net)), or None when there is none or it has been garbage-collected."""
+    ref = module.__dict__.get('_optim_ref')
+    return ref() if ref is not None else None
 
 
 class SeekerFunction(torch.autograd.Function):

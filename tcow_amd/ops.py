@@ -305,7 +305,7 @@ AMAX_SLOTS = 64          # TCOW_AMAX_SLOTS of include/tcow_hip.h
 def upsample_bwd_amax(dout, B, T, C, h, w, st, dpooled):
     """upsample_bwd (bilinear, stride 4, h, w > 4) that also returns max |dout| as a 0-dim f32 device tensor (see tcow_upsample_bwd_amax)."""
     bits = torch.zeros(AMAX_SLOTS, dtype=torch.int32, device=dout.device)           # TCOW_AMAX_SLOTS partial maxima (one atomic per workgroup, spread over the slots)
-    L.check(L.lib().tcow_upsample_bwd_amax(_stream(), B, T, C, h, w, st, dout.data_ptr(), dpooled.data_ptr(), bits.data_ptr()), 'tcow_upsample_bwd_amax')
+    L.check(L.lib().tcow_upsample_bwd_amax(_stream(), B, T, C, h, w, st, dout.data_ptr(), dpooled.data_ptr(), bits.data_ptr(), AMAX_SLOTS), 'tcow_upsample_bwd_amax')
     return dpooled, bits.view(torch.float32).amax()
 
 
@@ -366,7 +366,7 @@ def mask_loss(logits, target, channel, pixel_w=None, frame_w=None, weighted_aot=
     if frame_w is not None and (frame_w.dtype != torch.float32 or not frame_w.is_contiguous() or frame_w.numel() != n_frames):
         raise L.TcowError('mask_loss: frame_w must be a contiguous f32 tensor with one weight per frame')
     lib = L.lib()
-    nb = lib.tcow_mask_loss_workspace_bytes(n_frames, frame_len)
+    nb = lib.tcow_mask_loss_workspace_bytes_for(n_frames, frame_len, float(topk_frac), float(aot_loss))
     ws = workspace(nb, logits.device, 'mask_loss')
     off = channel * T * frame_len * 4
     a = L.MaskLossArgs(n_frames, frame_len, T, logits.data_ptr() + off, C * T * frame_len, target.data_ptr() + off, C * T * frame_len,
@@ -387,7 +387,7 @@ def mask_loss_channels(logits, target, jobs, aot_loss=0.8, topk_frac=1.0, total=
             raise L.TcowError('mask_loss: logits / target / dlogits must be contiguous f32 tensors of one shape')
     n_frames, frame_len = BQ * T, H * W
     lib = L.lib()
-    nb = lib.tcow_mask_loss_workspace_bytes(n_frames, frame_len)
+    nb = lib.tcow_mask_loss_workspace_bytes_for(n_frames, frame_len, float(topk_frac), float(aot_loss))      # (the 4 B / pixel bit-pattern image only when the radix select runs)
     arr = (L.MaskLossArgs * len(jobs))()
     for i, (channel, pixel_w, frame_w, weighted_aot, loss_weight, loss_out) in enumerate(jobs):
         _need_cuda(pixel_w, frame_w, loss_out)

@@ -21,6 +21,8 @@ step (device side, no synchronisation).  Skips are COUNTED on the device in ever
 -- one sync -- whenever you log: a NaN gradient in bf16 / fp32 training shows up there instead of silently freezing the weights), and the
 update kernel subtracts them from the step number of its bias correction, so moments and correction stay in step; `state_dict()`
 stores the applied-update count, i.e. what torch.optim.AdamW would have counted behind a GradScaler."""
+import weakref
+
 import numpy as np
 import torch
 
@@ -52,8 +54,10 @@ class FusedAdamWClip(torch.optim.Optimizer):
             self._tracker = tracker
             if hasattr(tracker, 'invalidate_weight_cache'):
                 self.on_step.append(tracker.invalidate_weight_cache)
-            tracker.__dict__['_optim_attached'] = True      # (engine.run_backward warns when precision='fp16' trains without one: its loss scale could never recover)
-            tracker.__dict__['_optim_unscales'] = True      # binary16: gradient buckets may stay loss-scaled, step() folds the inverse scale into the clip coefficient (engine.run_backward)
+            # A WEAK reference to the attached optimizer (engine._live_optim).  While it is alive, precision='fp16' has somebody who lowers the loss scale
+            # after an overflow (run_backward warns otherwise), and -- with persistent_grads, one backward per step -- gradient buckets may stay loss-scaled:
+            # step() folds the inverse scale into the clip coefficient.  Once this optimizer is discarded the module unscales in the backward again.
+            tracker.__dict__['_optim_ref'] = weakref.ref(self)
         assert L.lib().tcow_adamw_chunk_bytes() == 40
 
     @property
@@ -157,6 +161,31 @@ class FusedAdamWClip(torch.optim.Optimizer):
         for cb in self.on_step:
             cb()
         return loss
+
+    def unscale_(self):
+        """precision='fp16' with persistent_grads: param.grad holds LOSS-SCALED gradients between backward and step() (torch.cuda.amp.GradScaler's
+        convention; step() undoes the scale on the fly).  Call this first when something else must see true gradients in between -- clip_grad_norm_,
+        gradient logging, another optimizer: multiplies every live gradient by the pending inverse scale (one pass over the gradients) and clears it.
+        A no-op in every other mode."""
+        trk = self._tracker
+        inv = trk.__dict__.get('pending_inv_scale') if trk is not None else None
+        if inv is None:
+            return
+        seen = set()
+        for p in self.params:
+            if p.grad is not None and p.grad.data_ptr() not in seen:
+                seen.add(p.grad.data_ptr())
+                p.grad.mul_(inv)
+        trk.__dict__['pending_inv_scale'] = None
+
+    def detach(self):
+        """Detach from the module given as module= (its fp16 backwards unscale their gradients themselves again)."""
+        trk = self._tracker
+        if trk is not None:
+            self.unscale_()
+            ref = trk.__dict__.get('_optim_ref')
+            if ref is not None and ref() is self:
+                trk.__dict__.pop('_optim_ref', None)
 
     def grad_norm(self):
         """Total gradient norm of the last step (device tensor, no sync)."""

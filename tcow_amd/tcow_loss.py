@@ -79,9 +79,13 @@ class FusedMaskObjective(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_total, _g_terms):
-        dl = ctx.dl; ctx.dl = None
-        if dl is None:
+        if not ctx.needs_input_grad[0]:
             return None, None, None, None, None, None, None, None
+        dl = ctx.dl; ctx.dl = None
+        if dl is None:         # the gradient image is scaled IN PLACE below and handed on: a second backward through this node has nothing left to scale
+            from ._lib import TcowError
+            raise TcowError('FusedMaskObjective: backward called twice on the same objective (retain_graph=True is not supported: '
+                            'd(loss)/d(logits) is scaled in place by the first call) -- recompute the loss, or use TcowLosses(fused=False)')
         if g_total.dtype == torch.float32 and g_total.numel() == 1 and g_total.device == dl.device:
             from . import ops
             ops.scale_unless_one(dl, g_total.contiguous())          # in place, and not at all when the upstream gradient is 1 (decided on the device)

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
         lib = _lib.lib(fmt)               # raises TcowError if the .so is missing: the product has no fallback
         for name in _declared():
             assert hasattr(lib, name), f'{name} declared in tcow_hip.h but not exported by the {fmt} build'
-        assert lib.tcow_version() >= 4
+        assert lib.tcow_version() == _lib.ABI_VERSION
         assert isinstance(lib.tcow_last_error(), bytes)
     assert _lib.lib('bf16') is not _lib.lib('fp16') and _lib.lib('bf16').tcow_version() == _lib.lib('fp16').tcow_version()
 
@@ -32,6 +32,9 @@ def test_library_exports_every_declared_symbol():
 def test_python_signatures_cover_the_header():
     from tcow_amd import _lib
     assert sorted(_lib.SIGNATURES) == _declared()
+    hdr = open(os.path.join(ROOT, 'include', 'tcow_hip.h')).read()
+    assert int(re.search(r'#define\s+TCOW_ABI_VERSION\s+(\d+)', hdr).group(1)) == _lib.ABI_VERSION      # the version the loader insists on (a stale .so is refused at load)
+    assert int(re.search(r'#define\s+TCOW_AMAX_SLOTS\s+(\d+)', hdr).group(1)) == __import__('tcow_amd.ops', fromlist=['x']).AMAX_SLOTS
 
 
 def test_no_oracle_import_in_product():

@@ -564,6 +564,86 @@ def test_fp16_overflow_skips_the_step_and_lowers_the_loss_scale(cuda):
     assert all(bool(torch.isfinite(p).all()) for p in net.parameters()) and -6.0 < float(net.seeker.ls_log2) < -5.9
 
 
+def test_fp16_deferred_unscale_only_with_one_backward_per_step(cuda):
+    """ADVICE r5 (engine.py deferred unscale): the loss scale is chosen per backward, so leaving gradients scaled for the optimizer is only sound when ONE
+    backward feeds a step.  (a) default module (persistent_grads False) + FusedAdamWClip(module=): two model calls in one graph (the reference's per-query
+    loop, pipeline.py:134-174) -- nothing is deferred, param.grad = the sum of the two calls' TRUE gradients; (b) persistent_grads: deferred, and
+    unscale_() turns param.grad into the true gradient, after which step() gives bit-identical parameters; (c) a discarded optimizer no longer leaves
+    gradients scaled; (d) a DataParallel-style replica never defers."""
+    import gc
+    from tcow_amd.optim import FusedAdamWClip
+    cfg = synth.seeker_config(num_total_frames=4, frame_height=32, frame_width=32, embed_dim=128, depth=2, num_heads=2, causal_attention=1)
+    sd = synth.make_state_dict(cfg, 5)
+    clip = synth.make_clip(2, 4, 32, 32, seed=2)
+    rgb = torch.from_numpy(clip['rgb']).cuda()
+    qms = [torch.from_numpy(synth.make_query_mask(clip, 0, 0)).cuda(), torch.from_numpy(synth.make_query_mask(clip, 1, 1)).cuda()]
+    loss_of = lambda om, fl, k: om.square().mean() * (1e-4 * (1 + 300 * k)) + fl.square().mean() * 1e-4      # very different seed magnitudes -> different scales
+
+    def grads(net):
+        return [None if p.grad is None else p.grad.detach().clone().float() for p in net.parameters()]
+
+    # (a) two calls, one graph
+    net = build_hip_seeker(cfg, sd, 'fp16').cuda().train()
+    opt = FusedAdamWClip(list(net.parameters()), lr=1e-3, max_norm=0.3, module=net)
+    singles = []
+    for k in range(2):
+        opt.zero_grad(set_to_none=True)
+        om, fl = net(rgb, qms[k]); loss_of(om, fl, k).backward()
+        assert net.seeker.__dict__.get('pending_inv_scale') is None
+        singles.append(grads(net))
+    opt.zero_grad(set_to_none=True)
+    (om0, fl0), (om1, fl1) = net(rgb, qms[0]), net(rgb, qms[1])
+    (loss_of(om0, fl0, 0) + loss_of(om1, fl1, 1)).backward()
+    assert net.seeker.__dict__.get('pending_inv_scale') is None
+    both = grads(net)
+    for g, a, b in zip(both, singles[0], singles[1]):
+        if g is not None:
+            assert torch.allclose(g, a + b, rtol=1e-5, atol=1e-9 + 1e-6 * float((a + b).abs().max()))
+    opt.step()
+    assert math.isfinite(float(opt.grad_norm())) and float(opt.skipped_steps) == 0
+
+    # (b) persistent_grads: deferred; unscale_() -> true gradients; step after unscale_ == step without it, bit for bit
+    res = {}
+    for use_unscale in (False, True):
+        net = build_hip_seeker(cfg, sd, 'fp16').cuda().train(); net.seeker.persistent_grads = True
+        opt = FusedAdamWClip(list(net.parameters()), lr=1e-3, max_norm=0.3, module=net)
+        om, fl = net(rgb, qms[0]); loss_of(om, fl, 0).backward()
+        inv = net.seeker.__dict__.get('pending_inv_scale')
+        assert inv is not None and float(inv) != 1.0
+        scaled = grads(net)
+        if use_unscale:
+            opt.unscale_()
+            assert net.seeker.__dict__.get('pending_inv_scale') is None
+            for g, s_ in zip(grads(net), scaled):
+                if g is not None:
+                    assert torch.equal(g, s_ * float(inv))
+            n = float(torch.nn.utils.clip_grad_norm_(net.parameters(), 1e9))      # what INTEGRATION.md's isfinite(clip_grad_norm_) check sees: the true norm
+        opt.step()
+        if use_unscale:
+            assert abs(n - float(opt.grad_norm())) <= 1e-4 * n
+        res[use_unscale] = [p.detach().clone() for p in net.parameters()]
+    assert all(torch.equal(a, b) for a, b in zip(res[False], res[True]))
+
+    # (c) the optimizer is gone: the next backward unscales itself again
+    del opt; gc.collect()
+    om, fl = net(rgb, qms[0])
+    with pytest.warns(UserWarning, match='no FusedAdamWClip'):
+        loss_of(om, fl, 0).backward()
+    assert net.seeker.__dict__.get('pending_inv_scale') is None
+    true0 = grads(net)
+    # (d) a replica (torch.nn.DataParallel's shallow copy, flagged by torch) never defers, whatever its dict inherited
+    opt = FusedAdamWClip(list(net.parameters()), lr=1e-3, max_norm=0.3, module=net)
+    net.seeker._is_replica = True
+    try:
+        om, fl = net(rgb, qms[0]); loss_of(om, fl, 0).backward()
+        assert net.seeker.__dict__.get('pending_inv_scale') is None
+    finally:
+        del net.seeker._is_replica
+    for g, t in zip(grads(net), true0):
+        if g is not None:
+            assert torch.equal(g, t)
+
+
 def test_fp16_unscaling_inside_the_optimizer_is_bit_identical(cuda):
     """precision='fp16' with FusedAdamWClip(module=net) and no data-parallel hook: the backward leaves the gradient buckets loss-scaled and the
     optimizer folds the inverse scale (a power of two) into its clip coefficient (tcow_adamw_clip_step_scaled) instead of a multiplication pass
@@ -580,7 +660,7 @@ def test_fp16_unscaling_inside_the_optimizer_is_bit_identical(cuda):
         net.seeker.persistent_grads = True
         opt = FusedAdamWClip(list(net.parameters()), lr=1e-3, max_norm=0.3, module=net)
         if not deferred:
-            net.seeker.__dict__['_optim_unscales'] = False
+            net.seeker.__dict__['_defer_unscale'] = False
         norms = []
         for it in range(3):
             om, fl = net(rgb, qm)

@@ -261,6 +261,17 @@ def test_loss_gradient_is_scaled_on_the_device_only_when_needed(cuda):
         (total * mult).backward()
         grads.append(lo.grad.clone())
     assert float(grads[0].abs().max()) > 0 and torch.equal(grads[1], grads[0] * 3.0)
+    # a second backward through the same node fails loudly (the gradient image was scaled in place and handed on; it used to come back as zeros): ADVICE r5
+    from tcow_amd._lib import TcowError
+    lo = lo0.clone().requires_grad_(True)
+    total, _ = FusedMaskObjective.apply(lo, tg, sw.reshape(BQ, Tn, Hn, Wn).contiguous(), fw, fw, (1.0, 0.5, 0.25), 0.8, 0.5)
+    total.backward(retain_graph=True)
+    with pytest.raises(TcowError, match='backward called twice'):
+        total.backward()
+    # the channel workspace holds the 4 B / pixel bit-pattern image only when the radix select runs (topk_frac < 1 and aot_loss > 0)
+    lib = ops.L.lib()
+    full, small = lib.tcow_mask_loss_workspace_bytes(6, 128), lib.tcow_mask_loss_workspace_bytes_for(6, 128, 1.0, 0.8)
+    assert full == lib.tcow_mask_loss_workspace_bytes_for(6, 128, 0.5, 0.8) and full - small == 6 * 128 * 4 and small == lib.tcow_mask_loss_workspace_bytes_for(6, 128, 0.5, 0.0)
 
 
 @pytest.mark.gpu
