@@ -2,8 +2,7 @@
 // matrix product formed as THREE bf16 MFMAs on hi / lo operand splits, exactly as gemm_x3.hip does for the Linear layers:
 //   x = hi + lo, hi = bf16(x) (round to nearest even), lo = bf16(x - hi), |x - hi - lo| <= 2^-18 |x|;   a.b ~ a_lo*b_hi + a_hi*b_lo + a_hi*b_hi (f32 accumulate).
 // Until round 6 the mode ran its attention on the exact-f32 MFMA (attention_f32.hip: 1/16 of the bf16 rate): 1 499 us per spatial forward at configs[1], a fifth
-// of that mode's step.  Same contract as attention_f32.hip (f32 qkv [rows, 3D] in, f32 out / dqkv, natural-log LSE, delta workspace in the lse layout);
-// sequences of one tile (temporal attention, T <= 32) stay on attention_f32.hip's wave-private kernels.
+// of that mode's step.  Same contract as attention_f32.hip (f32 qkv [rows, 3D] in, f32 out / dqkv, natural-log LSE, delta workspace in the lse layout).
 //
 // Structure = the streaming kernels of attention_bf16.hip: a 256-thread workgroup owns 4 query (forward, dQ) or 4 key (dK / dV) tiles of one (sequence, head),
 // one per wave, and walks the other side in chunks of CH tiles.  A chunk is read as f32 by all 256 threads (one 8-element piece of a row per thread and
@@ -440,8 +439,9 @@ int x3_bwd_launch(hipStream_t st, const SeqDesc& d, int nt, int grid, const void
 
 }  // namespace
 
-// (DEV: one-tile sequences through the streaming kernels with CH = 1 when TCOW_DEV_X3SOLO=1)
-bool tcow_attn_x3_supported(const SeqDesc& d) { static const int dev = getenv("TCOW_DEV_X3SOLO") ? atoi(getenv("TCOW_DEV_X3SOLO")) : 0; return d.L > 32 || dev; }
+// Every length.  One-tile sequences (temporal attention, T <= 32) run the same kernels with CH = 1 (16 KiB of LDS; one active wave per workgroup, all four
+// stage the tile): 84 / 302 us forward / backward at configs[1] against 127 / 407 us on attention_f32.hip's wave-private exact-f32 kernels.
+bool tcow_attn_x3_supported(const SeqDesc& d) { (void)d; return true; }
 
 int tcow_attn_x3_fwd(hipStream_t st, const SeqDesc& d, const void* qkv, void* out, float* lse) {
     const int nt = cdiv(d.L, 32), grid = x_grid(d.n_outer * d.n_inner * d.heads, cdiv(nt, 4));

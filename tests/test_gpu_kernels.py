@@ -291,7 +291,7 @@ def _ref_attn(qkv, B, T, S, D, heads, ca, spatial):
     return out.reshape(B * T * S, D)
 
 
-@pytest.mark.parametrize('mname,tol', [('f32', 2e-5), ('bf16', 1.5e-2), ('fp16', 2e-3), ('f32x3', 6e-5)])   # f32x3: f32 tensors, split-bf16 products (csrc/attention_x3.hip; one-tile sequences: the f32 kernels)
+@pytest.mark.parametrize('mname,tol', [('f32', 2e-5), ('bf16', 1.5e-2), ('fp16', 2e-3), ('f32x3', 6e-5)])   # f32x3: f32 tensors, split-bf16 products (csrc/attention_x3.hip)
 @pytest.mark.parametrize('spatial,B,T,S,heads,ca', [
     (False, 1, 4, 17, 4, 1), (False, 2, 30, 21, 2, 1), (False, 1, 30, 9, 2, 0), (False, 1, 7, 9, 2, 3), (False, 1, 40, 9, 2, 1), (False, 1, 70, 5, 1, 2),
     (True, 1, 2, 17, 4, 1), (True, 2, 3, 301, 2, 1), (True, 1, 2, 77, 2, 2), (True, 1, 1, 2, 1, 0), (True, 1, 1, 333, 1, 1),

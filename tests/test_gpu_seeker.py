@@ -92,6 +92,42 @@ def test_gradients_vs_reference_golden(cuda, precision, tol):
             assert abs(float(named[k].grad.norm()) - n) <= tol * n + 1e-7, k
 
 
+@pytest.mark.parametrize('name', ['g17_resize_a', 'g17_resize_b'])
+@pytest.mark.parametrize('precision,tol', [('fp32', 2e-4), ('bf16', 4e-2), ('bf16x3', 2e-4), ('fp16', 5e-3)])
+def test_forward_time_embedding_resize_vs_reference_golden(cuda, name, precision, tol):
+    """vision_tf.py:103-115,127-132 (engine._effective_embeddings): a stored pos_embed of another square grid (3x3 -> 4x4 patches; 5x5 -> 2x4, H != W, with
+    H = x.size(1) // W counting the cls row) and a time_embed of another length (6 -> 4, 3 -> 7) are nearest-resized in the forward.  G17: the REFERENCE ran
+    with the tables grafted after construction (oracle/make_golden_r6.py); outputs, the gradients of the STORED tables (the adjoint scatters through the
+    index maps), cls_token / patch-embed bias, and every parameter's gradient norm."""
+    from test_oracle_golden import resize_tables
+    meta, g = load_golden(name)
+    cfg, sd, rgb, qm = golden_inputs(meta)
+    net = build_hip_seeker(cfg, sd, precision)
+    pos, te = resize_tables(meta)
+    net.seeker.vit.pos_embed = torch.nn.Parameter(torch.from_numpy(pos.copy()))           # grafted after construction, as the reference run did
+    net.seeker.vit.time_embed = torch.nn.Parameter(torch.from_numpy(te.copy()))
+    net = net.cuda().train()                                                             # (drop_path_rate 0: train == eval arithmetic, gradients enabled)
+    om, fl = net(rgb.cuda(), qm.cuda())
+    d = np.abs(om.detach().cpu().numpy() - g['output_mask']).max(); df = np.abs(fl.detach().cpu().numpy() - g['output_flags']).max()
+    if precision in EXACT:
+        assert d < EXACT[precision] and df < EXACT[precision]
+    else:
+        assert d < h16(precision) * bf16_tol(g['output_mask']) and df < h16f(precision) * bf16_flags_tol(g['output_flags'])
+    Gm = torch.from_numpy(synth._rng(meta['seed'], 'gradprobe_mask').standard_normal(size=tuple(om.shape), dtype=np.float32)).cuda()
+    Gf = torch.from_numpy(synth._rng(meta['seed'], 'gradprobe_flags').standard_normal(size=tuple(fl.shape), dtype=np.float32)).cuda()
+    ((om * Gm).sum() + (fl * Gf).sum()).backward()
+    named = dict(net.named_parameters())
+    for k, ref in g.items():
+        if k.startswith('grad::'):
+            got = named[k[6:]].grad.cpu().numpy()
+            assert got.shape == ref.shape and np.abs(got - ref).max() <= tol * np.abs(ref).max() + 1e-7, k
+    for k, n in meta['grad_norms'].items():
+        if n is None:
+            assert named[k].grad is None, k
+        else:
+            assert abs(float(named[k].grad.norm()) - n) <= tol * n + 1e-7, k
+
+
 @pytest.mark.parametrize('name', ['g3_mid_T8_96x128', 'g4_cfg2_T30_240x320', 'g4b_cfg2_seed2'])
 @pytest.mark.parametrize('precision', ['fp32', 'bf16', 'bf16x3', 'fp16'])
 def test_large_geometries_vs_reference_golden(cuda, name, precision):
@@ -634,6 +670,7 @@ def test_fp16_deferred_unscale_only_with_one_backward_per_step(cuda):
     # (d) a replica (torch.nn.DataParallel's shallow copy, flagged by torch) never defers, whatever its dict inherited
     opt = FusedAdamWClip(list(net.parameters()), lr=1e-3, max_norm=0.3, module=net)
     net.seeker._is_replica = True
+    net.zero_grad(set_to_none=True)
     try:
         om, fl = net(rgb, qms[0]); loss_of(om, fl, 0).backward()
         assert net.seeker.__dict__.get('pending_inv_scale') is None

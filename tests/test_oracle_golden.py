@@ -185,3 +185,35 @@ def test_joint_space_time_matches_reference():
                 assert np.abs(tsd[k.split('::', 2)[2]].grad.numpy() - ref).max() <= 2e-4 * np.abs(ref).max() + 1e-7, k
             elif k.startswith(f'{mode}::gsample::'):
                 assert np.abs(so.grad_sample(tsd[k.split('::', 2)[2]].grad.numpy()) - ref).max() <= 2e-4 * np.abs(ref).max() + 1e-7, k
+
+
+@pytest.mark.parametrize('name', ['g17_resize_a', 'g17_resize_b'])
+def test_forward_time_embedding_resize_matches_reference(name):
+    """vision_tf.py:103-115,127-132: a stored pos_embed of another square grid / a time_embed of another length are nearest-resized in the forward
+    (H = x.size(1) // W counts the cls row).  The REFERENCE ran with the tables grafted after construction (oracle/make_golden_r6.py); outputs and the
+    gradients of the STORED tables (a scatter-add through the resize) must match."""
+    meta, g = load_golden(name)
+    cfg, sd, rgb, qm = golden_inputs(meta)
+    pos, te = resize_tables(meta)
+    sd = dict(sd); sd[so.PREFIX + 'pos_embed'] = pos; sd[so.PREFIX + 'time_embed'] = te
+    tsd = {k: torch.from_numpy(np.asarray(v).copy()).requires_grad_(True) for k, v in sd.items()}
+    om, fl = so.seeker_forward(tsd, cfg, rgb, qm)
+    assert np.abs(om.detach().numpy() - g['output_mask']).max() < TOL and np.abs(fl.detach().numpy() - g['output_flags']).max() < TOL
+    Gm = torch.from_numpy(synth._rng(meta['seed'], 'gradprobe_mask').standard_normal(size=tuple(om.shape), dtype=np.float32))
+    Gf = torch.from_numpy(synth._rng(meta['seed'], 'gradprobe_flags').standard_normal(size=tuple(fl.shape), dtype=np.float32))
+    ((om * Gm).sum() + (fl * Gf).sum()).backward()
+    for k, ref in g.items():
+        if k.startswith('grad::'):
+            got = tsd[k[6:]].grad.numpy()
+            assert got.shape == ref.shape and np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max() + 1e-7, k
+    # every stored row the nearest map never selects gets exactly zero gradient
+    gp = tsd[so.PREFIX + 'pos_embed'].grad[0]
+    assert gp.shape[0] == 1 + meta['stored_grid'] ** 2 and tsd[so.PREFIX + 'time_embed'].grad.shape[1] == meta['stored_time']
+
+
+def resize_tables(meta):
+    """The grafted tables of the g17 fixtures (oracle/make_golden_r6.py::stored_tables)."""
+    D = meta['cfg']['embed_dim']
+    pos = synth._rng(meta['seed'], 'resize_pos').standard_normal(size=(1, 1 + meta['stored_grid'] ** 2, D), dtype=np.float32) * 0.5
+    te = synth._rng(meta['seed'], 'resize_time').standard_normal(size=(1, meta['stored_time'], D), dtype=np.float32) * 0.5
+    return pos.astype(np.float32), te.astype(np.float32)
