@@ -70,6 +70,38 @@ class KernelTimer:
         return self.result
 
 
+class AttnTimer:
+    """The same for the four attention entry points (tcow_prof_attn_begin/_end): the north-star's "achieved fraction of the attention roofline" -- per class
+    the average HIP-event time of a call, its algorithmic TFLOP/s against the dense MFMA peak and its algorithmic bytes / time against 8 TB/s of HBM
+    (spatial attention at configs[1] has 151 FLOP/B: left of the ridge, so the HBM fraction is the one that can approach 1)."""
+    NAMES = ('spatial_fwd', 'spatial_bwd', 'temporal_fwd', 'temporal_bwd')
+
+    def __init__(self, fmt='bf16'):
+        from tcow_amd import _lib
+        self.L = _lib; self.fmt = fmt; self.result = None
+
+    def begin(self, max_launches):
+        self.L.check(self.L.lib(self.fmt).tcow_prof_attn_begin(int(max_launches)), 'tcow_prof_attn_begin')
+
+    def end(self, steps, peak_tflops):
+        import ctypes
+        ms, fl, by = (ctypes.c_double * 4)(), (ctypes.c_double * 4)(), (ctypes.c_double * 4)()
+        n = (ctypes.c_long * 4)()
+        self.L.check(self.L.lib(self.fmt).tcow_prof_attn_end(ms, fl, by, n), 'tcow_prof_attn_end')
+        out = {}
+        for c, name in enumerate(self.NAMES):
+            if n[c]:
+                t = ms[c] * 1e-3
+                out[name] = dict(us=ms[c] * 1e3 / n[c], launches_per_step=n[c] / steps, tflops=fl[c] / t / 1e12, mfma_frac=fl[c] / t / 1e12 / peak_tflops,
+                                 gbps=by[c] / t / 1e9, hbm_frac=by[c] / t / 1e9 / PEAK_HBM_GBS, flops_per_launch=fl[c] / n[c], bytes_per_launch=by[c] / n[c])
+        if out:
+            tot_ms = sum(ms[c] for c in range(4))
+            out['ms_per_step'] = tot_ms / steps
+            out['note'] = ('HIP events on the launch stream around every attention call of an untimed pass of --steps steps; FLOPs = 4 L^2 d per (sequence, head) '
+                           'forward, x 2.5 backward; bytes = q, k, v, o (+ dO, dq, dk, dv; + O for spatial) once each; peaks: dense MFMA of the dtype, 8 TB/s HBM')
+        self.result = out or None
+
+
 def cpu_baseline(cfg, budget_s):
     """Times the oracle (our CPU port of the reference path, oracle/seeker_oracle.py) on this host's cores, as BASELINE.md section 3 plans it:
     1 warm-up + 3 timed query forwards and 1 timed forward + backward at the benchmark geometry (~60 s on the GPU box's 64 threads; a slower
@@ -341,19 +373,94 @@ def self_launch(args):
     return subprocess.run(cmd, env=env).returncode
 
 
+class RankErrors:
+    """N > 1: no rank may die silently and no rank may hang on one that did.  Every rank writes an exception it meets into a directory all ranks of this
+    launch share (/tmp/tcow_bench_<launcher pid>_<MASTER_PORT>/rank<r>.json) and waits a moment before it re-raises; a daemon thread on every rank polls
+    that directory -- it works while the main thread is blocked inside a collective or a stream synchronisation -- and when a report appears rank 0's
+    thread prints the ONE JSON line of the contract with `value: null` and `ddp.error` = the reports (rank, exception type, message, traceback tail),
+    then every rank exits with code 3 instead of waiting for the collective timeout.  (torch.distributed.run would also tear the job down, but without
+    a line on stdout, and only after the failing rank's process has ended.)"""
+
+    def __init__(self, rank, world, args):
+        import tempfile
+        self.rank, self.world, self.args = rank, world, args
+        self.dir = os.path.join(tempfile.gettempdir(), f'tcow_bench_{os.getppid()}_{os.environ.get("MASTER_PORT", "0")}')
+        self.done = False
+        if world > 1:
+            import threading
+            os.makedirs(self.dir, exist_ok=True)
+            threading.Thread(target=self._watch, daemon=True).start()
+
+    def report(self, exc):
+        import traceback
+        if self.world <= 1:
+            return
+        tb = traceback.format_exception(type(exc), exc, exc.__traceback__)
+        rec = dict(rank=self.rank, type=type(exc).__name__, message=str(exc)[:2000], traceback_tail=''.join(tb)[-1500:])
+        tmp = os.path.join(self.dir, f'.rank{self.rank}.tmp')
+        with open(tmp, 'w') as f:
+            json.dump(rec, f)
+        os.replace(tmp, os.path.join(self.dir, f'rank{self.rank}.json'))
+        time.sleep(4.0)                 # (rank 0's watcher prints the line before this process -- and with it the launcher's whole job -- goes away)
+
+    def _reports(self):
+        out = []
+        for name in sorted(os.listdir(self.dir)):
+            if name.startswith('rank') and name.endswith('.json'):
+                try:
+                    out.append(json.load(open(os.path.join(self.dir, name))))
+                except (OSError, ValueError):
+                    pass
+        return out
+
+    def _watch(self):
+        while not self.done:
+            time.sleep(0.5)
+            try:
+                found = self._reports()
+            except OSError:
+                continue
+            if found:
+                time.sleep(1.0)         # let the other failing ranks finish writing
+                found = self._reports() or found
+                if self.rank == 0:
+                    a = self.args
+                    print(json.dumps(dict(metric='train clips/sec (T=30, 240x320)', value=None, unit='clips/s', n_gpus=self.world, steps=a.steps, warmup=a.warmup,
+                                          ms_per_step=None, higher_is_better=True, scaling='weak', vs_baseline=None, data='synthetic',
+                                          ddp=dict(error=found, ranks=self.world, note='a rank raised: the run was stopped instead of hanging in the next collective'))), flush=True)
+                    sys.stderr.write(f'bench.py: stopped, rank(s) {[r["rank"] for r in found]} raised: {found[0]["type"]}: {found[0]["message"][:300]}\n')
+                os._exit(3)
+
+
 def main():
     args = parse()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(self_launch(args))
+    errors = RankErrors(int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1')), args)
+    try:
+        run(args)
+    except BaseException as e:          # noqa: BLE001 -- SystemExit of a rank-count mismatch included
+        if not (isinstance(e, SystemExit) and e.code in (0, None)):
+            errors.report(e)
+        raise
+    finally:
+        errors.done = True
+
+
+def run(args):
     from tcow_amd import ddp, engine, flops, ops, synth
     from tcow_amd.seeker import Seeker
     rank, local_rank, world = ddp.init_distributed()
+    # the first collective of the run: small, checked, with a host-side timeout and a message that names the environment (ddp.first_contact)
+    contact = ddp.first_contact(torch.device('cuda', local_rank % max(torch.cuda.device_count(), 1)) if world > 1 and torch.distributed.get_backend() == 'nccl' else None) if world > 1 else None
+    if os.environ.get('TCOW_BENCH_FAIL_RANK') == str(rank):       # (tests: a rank that dies right after the rendezvous -- rank 0 must still print a line)
+        raise RuntimeError(f'TCOW_BENCH_FAIL_RANK: injected failure on rank {rank}')
     if args.launch_selftest:
-        one = torch.ones(1)
-        if world > 1:
-            torch.distributed.all_reduce(one.cuda() if torch.distributed.get_backend() == 'nccl' else one)
+        if world > 1 and os.environ.get('TCOW_BENCH_FAIL_RANK') is not None:
+            torch.distributed.barrier()        # (the surviving ranks sit in a collective the failed one never joins: the situation RankErrors exists for)
         if rank == 0:
-            print(json.dumps(dict(selftest='launch', n_gpus=world, ranks_seen=(torch.distributed.get_world_size() if world > 1 else 1), gpus_arg=args.gpus)), flush=True)
+            print(json.dumps(dict(selftest='launch', n_gpus=world, ranks_seen=(torch.distributed.get_world_size() if world > 1 else 1), gpus_arg=args.gpus,
+                                  first_contact=contact)), flush=True)
         if world > 1:
             torch.distributed.destroy_process_group()
         return
@@ -399,6 +506,7 @@ def main():
 
     net, step = make_trainer(args.precision)
     timer = KernelTimer('fp16' if args.precision == 'fp16' else 'bf16')
+    atimer = AttnTimer('fp16' if args.precision == 'fp16' else 'bf16')
 
     for _ in range(args.warmup):
         step()
@@ -416,10 +524,12 @@ def main():
     ddp_stats = net.seeker.grad_hook.stats() if world > 1 else None
     # second, untimed pass of the same step count: per-launch HIP events around every NT GEMM (roofline.achieved)
     timer.begin(400 * args.steps)
+    atimer.begin(120 * args.steps)
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
     timer.end()
+    atimer.end(args.steps, {'bf16': PEAK_BF16_TFLOPS, 'fp16': PEAK_BF16_TFLOPS, 'fp32': PEAK_F32_TFLOPS, 'bf16x3': PEAK_BF16_TFLOPS / 3.0}[args.precision])
     # host time to enqueue ONE step into an empty stream (the loop above is throttled by the queue depth: the host runs ahead of the GPU)
     enq = []
     for _ in range(3):
@@ -457,13 +567,13 @@ def main():
                                clips_per_gpu=1, num_queries=Qs, parallelism=f'dp{world}', optimizer='AdamW lr 1e-4, clip 0.3',
                                loss='TCOW mask losses (loss.py:238-421): class-balanced BCE + bootstrapped BCE + soft Jaccard on 3 channels'),
                    query_forwards_per_s=clips_per_s * Qs, step_model_tflops=step_tflops, step_mfma_frac=step_tflops / peak,
-                   final_loss=float(loss.detach()), host_enqueue_ms=round(sorted(enq)[1], 2), roofline=roof)
+                   final_loss=float(loss.detach()), host_enqueue_ms=round(sorted(enq)[1], 2), roofline=roof, roofline_attention=atimer.result)
         if world > 1:
             # what the scaling curve needs to explain itself: how long the compute stream stood still for the gradient all-reduce (rank 0),
             # how much went over xGMI per step in how many collectives, and the spread of the per-rank step times
             res['ddp'] = dict(ddp_stats, ms_per_step_min=min(rank_ms), ms_per_step_max=max(rank_ms), ranks=world,
                               group_blocks=engine.group_sizes(args.depth),          # blocks per gradient group, top group first (TCOW_DDP_GROUP)
-                              rccl=rccl_knobs(),
+                              rccl=rccl_knobs(), rccl_version=contact.get('rccl_version'), backend=contact.get('backend'), first_contact_ms=round(contact.get('ms', 0.0), 1),
                               cpu_baseline='reported at N = 1 only (rank 0 of a single-GPU run)')
         ref_mask = None
         if not args.no_cpu_baseline and world == 1:

@@ -100,6 +100,11 @@ int tcow_gemm_nt(void* stream, const tcow_gemm_args* args);
  * number of launches (at most max_launches are recorded). */
 int tcow_prof_gemm_begin(int max_launches);
 int tcow_prof_gemm_end(double* total_ms, double* total_flops, long* launches);
+/* The same for the four attention entry points (ABI 10): per class c = 0 spatial forward, 1 spatial backward, 2 temporal forward, 3 temporal backward the summed
+ * HIP-event time (ms), algorithmic FLOPs (4 L^2 d per sequence and head forward, 2.5 x backward) and bytes (4 / 8 / 7 x rows x D x element size) and the
+ * launch count of the calls between begin and end: bench.py's `roofline_attention`. */
+int tcow_prof_attn_begin(int max_launches);
+int tcow_prof_attn_end(double* ms4, double* flops4, double* bytes4, long* launches4);
 
 /* Weight-gradient GEMM  dW[N,K] (f32) (+)= dY[M,N]^T . X[M,K]   (autograd of nn.Linear.weight).
  * dY, X: `dtype` row-major (ldy, ldx in elements).  The M (token) dimension is split across workgroups;

@@ -73,6 +73,8 @@ SIGNATURES = {
     'tcow_gemm_nt': (_i, [_vp, ctypes.POINTER(GemmArgs)]),
     'tcow_prof_gemm_begin': (_i, [_i]),
     'tcow_prof_gemm_end': (_i, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long)]),
+    'tcow_prof_attn_begin': (_i, [_i]),
+    'tcow_prof_attn_end': (_i, [_vp, _vp, _vp, _vp]),
     'tcow_gemm_tn_workspace_bytes': (_l, [_i, _i, _i]),
     'tcow_gemm_tn': (_i, [_vp, _i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _vp, _i, _vp, _l]),
     'tcow_gemm_tn_grouped_workspace_bytes': (_l, [_i, _i, _vp]),

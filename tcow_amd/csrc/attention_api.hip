@@ -9,6 +9,9 @@
 // gone: both storage types have MFMA kernels for every shape.)
 #include <stdlib.h>
 
+#include <mutex>
+#include <vector>
+
 #include "attention_common.h"
 
 namespace {
@@ -95,30 +98,93 @@ int tcow_attn_bwd_dispatch(hipStream_t st, const tcow_attn_shape* s, int spatial
     return tcow_attn_f32_bwd(st, d, qkv, out, dout, lse, (float*)ws, dqkv);
 }
 
+// ---- optional HIP-event timing of the four attention entry points on the launch stream (bench.py's `roofline_attention` block: the north-star asks for
+// the achieved fraction of the attention roofline next to clips/s).  Classes: 0 spatial forward, 1 spatial backward, 2 temporal forward, 3 temporal backward.
+// Algorithmic work of a call: FLOPs = 4 L^2 d per (sequence, head) forward (Q K^T and P V, dense -- a causal mask does not discount it), 2.5 x that
+// backward (five products); bytes = q, k, v in + o out forward (4 R D e), q, k, v, dO (+ O for the spatial kernel, which forms delta itself) in + dq, dk, dv
+// out backward (8 / 7 R D e), R = rows the sequences cover, e = element size.
+namespace {
+struct AttnProf {
+    std::mutex mu;
+    std::vector<hipEvent_t> ev;
+    std::vector<int> cls;
+    std::vector<double> flops, bytes;
+    size_t used = 0, cap = 0;
+    bool on = false;
+};
+AttnProf g_ap;
+
+template <typename F>
+int attn_profiled(void* stream, const tcow_attn_shape* s, int spatial, int backward, F&& launch) {
+    if (!g_ap.on) return launch();
+    std::lock_guard<std::mutex> lock(g_ap.mu);
+    if (!g_ap.on || g_ap.used >= g_ap.cap) return launch();
+    const size_t i = g_ap.used++;
+    const SeqDesc d = spatial ? spatial_desc(s) : temporal_desc(s);
+    const double seqs = (double)d.n_outer * d.n_inner, rows = seqs * d.L, es = s->dtype == TCOW_BF16 ? 2.0 : 4.0;
+    const double fwd_flops = 4.0 * d.L * (double)d.L * ATT_HD * seqs * d.heads;
+    g_ap.cls[i] = (spatial ? 0 : 2) + (backward ? 1 : 0);
+    g_ap.flops[i] = backward ? 2.5 * fwd_flops : fwd_flops;
+    g_ap.bytes[i] = (backward ? (spatial ? 8.0 : 7.0) : 4.0) * rows * d.D * es;
+    (void)hipEventRecord(g_ap.ev[2 * i], (hipStream_t)stream);
+    const int rc = launch();
+    (void)hipEventRecord(g_ap.ev[2 * i + 1], (hipStream_t)stream);
+    return rc;
+}
+}  // namespace
+
 extern "C" {
+
+int tcow_prof_attn_begin(int max_launches) {
+    TCOW_CHECK_ARG(max_launches > 0, "tcow_prof_attn_begin: max_launches must be positive");
+    std::lock_guard<std::mutex> lock(g_ap.mu);
+    while (g_ap.ev.size() < (size_t)max_launches * 2) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) { tcow_set_error("tcow_prof_attn_begin: hipEventCreate failed"); return TCOW_ERR_LAUNCH; }
+        g_ap.ev.push_back(e);
+    }
+    g_ap.cls.assign(max_launches, 0); g_ap.flops.assign(max_launches, 0.0); g_ap.bytes.assign(max_launches, 0.0);
+    g_ap.used = 0; g_ap.cap = (size_t)max_launches; g_ap.on = true;
+    return TCOW_OK;
+}
+
+int tcow_prof_attn_end(double* ms4, double* flops4, double* bytes4, long* launches4) {
+    TCOW_CHECK_ARG(ms4 && flops4 && bytes4 && launches4, "tcow_prof_attn_end: null output");
+    std::lock_guard<std::mutex> lock(g_ap.mu);
+    g_ap.on = false;
+    for (int c = 0; c < 4; ++c) { ms4[c] = 0.0; flops4[c] = 0.0; bytes4[c] = 0.0; launches4[c] = 0; }
+    for (size_t i = 0; i < g_ap.used; ++i) {
+        if (hipEventSynchronize(g_ap.ev[2 * i + 1]) != hipSuccess) { tcow_set_error("tcow_prof_attn_end: event sync failed"); return TCOW_ERR_LAUNCH; }
+        float t = 0.f;
+        (void)hipEventElapsedTime(&t, g_ap.ev[2 * i], g_ap.ev[2 * i + 1]);
+        const int c = g_ap.cls[i];
+        ms4[c] += t; flops4[c] += g_ap.flops[i]; bytes4[c] += g_ap.bytes[i]; launches4[c] += 1;
+    }
+    return TCOW_OK;
+}
 
 int tcow_attn_temporal_fwd(void* stream, const tcow_attn_shape* s, const void* qkv, void* out, float* lse) {
     int rc = check_shape(s, "tcow_attn_temporal_fwd"); if (rc) return rc;
     TCOW_CHECK_ARG(qkv && out, "tcow_attn_temporal_fwd: null pointer");
-    return tcow_attn_fwd_dispatch((hipStream_t)stream, s, 0, qkv, out, lse);
+    return attn_profiled(stream, s, 0, 0, [&] { return tcow_attn_fwd_dispatch((hipStream_t)stream, s, 0, qkv, out, lse); });
 }
 int tcow_attn_spatial_fwd(void* stream, const tcow_attn_shape* s, const void* qkv, void* out, float* lse) {
     int rc = check_shape(s, "tcow_attn_spatial_fwd"); if (rc) return rc;
     TCOW_CHECK_ARG(qkv && out, "tcow_attn_spatial_fwd: null pointer");
-    return tcow_attn_fwd_dispatch((hipStream_t)stream, s, 1, qkv, out, lse);
+    return attn_profiled(stream, s, 1, 0, [&] { return tcow_attn_fwd_dispatch((hipStream_t)stream, s, 1, qkv, out, lse); });
 }
 long tcow_attn_bwd_workspace_bytes(const tcow_attn_shape* s) { return s ? bwd_ws_bytes(s) : 0; }
 int tcow_attn_temporal_bwd(void* stream, const tcow_attn_shape* s, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
                            void* workspace, long workspace_bytes) {
     int rc = check_shape(s, "tcow_attn_temporal_bwd"); if (rc) return rc;
     TCOW_CHECK_ARG(qkv && out && dout && lse && dqkv && workspace && workspace_bytes >= tcow_attn_bwd_workspace_bytes(s), "tcow_attn_temporal_bwd: bad pointers / workspace");
-    return tcow_attn_bwd_dispatch((hipStream_t)stream, s, 0, qkv, out, dout, lse, workspace, dqkv);
+    return attn_profiled(stream, s, 0, 1, [&] { return tcow_attn_bwd_dispatch((hipStream_t)stream, s, 0, qkv, out, dout, lse, workspace, dqkv); });
 }
 int tcow_attn_spatial_bwd(void* stream, const tcow_attn_shape* s, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
                           void* workspace, long workspace_bytes) {
     int rc = check_shape(s, "tcow_attn_spatial_bwd"); if (rc) return rc;
     TCOW_CHECK_ARG(qkv && out && dout && lse && dqkv && workspace && workspace_bytes >= tcow_attn_bwd_workspace_bytes(s), "tcow_attn_spatial_bwd: bad pointers / workspace");
-    return tcow_attn_bwd_dispatch((hipStream_t)stream, s, 1, qkv, out, dout, lse, workspace, dqkv);
+    return attn_profiled(stream, s, 1, 1, [&] { return tcow_attn_bwd_dispatch((hipStream_t)stream, s, 1, qkv, out, dout, lse, workspace, dqkv); });
 }
 
 }  // extern "C"

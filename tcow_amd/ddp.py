@@ -24,6 +24,7 @@ over replicas (loss.py:356-369), so the MI355X counterpart is plain gradient ave
     any rank and are simply not part of any bucket -- no unused-parameter handshake is needed.
 """
 import collections
+import datetime
 import os
 
 import torch
@@ -44,8 +45,45 @@ def init_distributed(backend=None):
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend == 'nccl':
             torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        # a finite collective timeout (TCOW_DIST_TIMEOUT_S, default 300 s): a rank that never arrives ends the run with an error instead of a hang
+        tmo = datetime.timedelta(seconds=float(os.environ.get('TCOW_DIST_TIMEOUT_S', '300')))
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=tmo)
     return rank, local_rank, world
+
+
+def rccl_version():
+    """Version of the collective library behind backend 'nccl' (RCCL on ROCm) as a string, or None."""
+    try:
+        v = torch.cuda.nccl.version()
+        return '.'.join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+    except Exception:          # noqa: BLE001 -- a build without the binding
+        return None
+
+
+def first_contact(device=None, timeout_s=None, group=None):
+    """The FIRST collective of a run, on purpose small and checked: every rank contributes its rank number, the sum must be world (world - 1) / 2.
+    Waits on the host with a timeout, so that a broken fabric / IPC set-up (HSA_ENABLE_IPC_MODE_LEGACY, a rank on the wrong device, a firewall on the
+    rendezvous port) is reported in seconds with the environment that matters, not as a hung job.  Returns dict(ms, world, backend, rccl_version)."""
+    import time
+    if not dist.is_initialized() or dist.get_world_size(group) <= 1:
+        return dict(ms=0.0, world=1, backend=None, rccl_version=None)
+    world, rank, backend = dist.get_world_size(group), dist.get_rank(group), dist.get_backend(group)
+    timeout_s = float(os.environ.get('TCOW_FIRST_CONTACT_TIMEOUT_S', '120')) if timeout_s is None else float(timeout_s)
+    t = torch.tensor([float(rank), 1.0], dtype=torch.float32, device=device if backend == 'nccl' else 'cpu')
+    t0 = time.perf_counter()
+    try:
+        work = dist.all_reduce(t, group=group, async_op=True)
+        done = work.wait(datetime.timedelta(seconds=timeout_s))
+        if t.is_cuda:
+            torch.cuda.synchronize(t.device)
+        got = t.cpu().tolist()
+    except Exception as e:      # noqa: BLE001
+        raise RuntimeError(f'first collective ({backend}, {world} ranks) failed on rank {rank} after {time.perf_counter() - t0:.1f} s: {type(e).__name__}: {e} '
+                           f'[MASTER_ADDR={os.environ.get("MASTER_ADDR")} MASTER_PORT={os.environ.get("MASTER_PORT")} LOCAL_RANK={os.environ.get("LOCAL_RANK")} '
+                           f'HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")} (must be 0 on this pool); set NCCL_DEBUG=INFO for RCCL\'s own log]') from e
+    if done is False or abs(got[0] - world * (world - 1) / 2.0) > 1e-3 or abs(got[1] - world) > 1e-3:
+        raise RuntimeError(f'first collective ({backend}) returned {got} on rank {rank}: expected [{world * (world - 1) / 2.0}, {float(world)}] -- ranks missing or duplicated')
+    return dict(ms=(time.perf_counter() - t0) * 1e3, world=world, backend=backend, rccl_version=rccl_version() if backend == 'nccl' else None)
 
 
 class GradSync:
@@ -79,17 +117,21 @@ class GradSync:
         self._nbuckets = 0              # buckets published since reset_stats()
         self._fresh = True
         self._exposed = collections.deque(maxlen=STATS_WINDOW)   # per finish(): (start event, end event) on the compute stream, or seconds on the CPU path
+        self._timeline = None           # last step: [(tag, bytes, event at launch, event behind the wait)] on the compute stream (GPU buckets only)
 
     @property
     def active(self):
         """False when the hook moves nothing (one rank, not forced): engine.run_backward may then leave the binary16 loss scale for the optimizer to undo."""
         return self.world > 1 or self.force
 
-    def _launch(self, flat):
+    def _launch(self, flat, tag=None):
         op = dist.ReduceOp.AVG if self.native_avg else dist.ReduceOp.SUM
         wire = flat.to(torch.bfloat16) if self.bucket_dtype == 'bf16' else flat
         self.bytes += wire.numel() * wire.element_size()
-        self.pending.append((dist.all_reduce(wire, op=op, group=self.group, async_op=True), flat, wire))
+        ev = None
+        if flat.is_cuda:               # when the backward published this bucket, on the compute stream (per-bucket timeline of stats())
+            ev = torch.cuda.Event(enable_timing=True); ev.record()
+        self.pending.append((dist.all_reduce(wire, op=op, group=self.group, async_op=True), flat, wire, ev, tag))
 
     def __call__(self, name, flat):
         if (self.world <= 1 and not self.force) or flat.numel() == 0:
@@ -99,16 +141,16 @@ class GradSync:
         self.launched.append(name)
         self._nbuckets += 1
         if self.overlap:
-            self._launch(flat)
+            self._launch(flat, name)
         else:
-            self.deferred.append(flat)
+            self.deferred.append((flat, name))
 
     def finish(self):
         """Drain: the compute stream waits for every collective of this backward.  The wait is bracketed by two events on that stream, so
         `stats()` can report how long the stream actually stood still for communication (the EXPOSED part of the all-reduce) without any
         synchronisation inside the step."""
-        for flat in self.deferred:
-            self._launch(flat)
+        for flat, name in self.deferred:
+            self._launch(flat, name)
         self.deferred = []
         self.steps += 1
         self._fresh = True
@@ -127,7 +169,7 @@ class GradSync:
             self._exposed.append(time.perf_counter() - t0)
 
     def reset_stats(self):
-        self.bytes = 0; self.launched = []; self.steps = 0; self._nbuckets = 0; self._fresh = True; self._exposed.clear()
+        self.bytes = 0; self.launched = []; self.steps = 0; self._nbuckets = 0; self._fresh = True; self._exposed.clear(); self._timeline = None
 
     def stats(self):
         """Since the last reset_stats(): all-reduce bytes and buckets per step and the mean exposed wait per step in ms (synchronises)."""
@@ -139,16 +181,36 @@ class GradSync:
             else:
                 ms += e * 1e3
         return dict(allreduce_exposed_ms=ms / max(len(self._exposed), 1), allreduce_bytes=self.bytes // n, buckets=self._nbuckets // n, bucket_dtype=self.bucket_dtype,
-                    overlap=self.overlap, native_avg=self.native_avg)
+                    overlap=self.overlap, native_avg=self.native_avg, bucket_timeline=self.bucket_timeline())
 
     def _drain(self):
-        for work, flat, wire in self.pending:
+        line = []
+        for work, flat, wire, ev, tag in self.pending:
             work.wait()                      # makes the current stream wait for the collective
+            if ev is not None:               # the compute stream has passed this bucket's wait: the collective is complete
+                e1 = torch.cuda.Event(enable_timing=True); e1.record()
+                line.append((tag, wire.numel() * wire.element_size(), ev, e1))
             if wire is not flat:
                 flat.copy_(wire)             # bf16 mean -> f32 bucket
             if not self.native_avg:
                 flat.mul_(1.0 / self.world)  # sum -> mean (loss.py:356-369 averages the per-replica losses)
         self.pending = []
+        if line:
+            self._timeline = line
+
+    def bucket_timeline(self):
+        """The LAST drained step's buckets in launch order: tag, bytes, and -- on the compute stream, in ms relative to the first bucket's launch -- when the
+        backward published the bucket (`launch_ms`) and when the stream got past its wait (`done_ms`: the collective is complete and everything before the
+        wait has run).  done - launch of an overlapped bucket = wire time + whatever backward work ran meanwhile; consecutive `done_ms` of the buckets
+        that cannot overlap (the bottom group, the late bucket) are their exposed wire times.  Synchronises; None before the first GPU step."""
+        if not self._timeline:
+            return None
+        t0 = self._timeline[0][2]
+        out = []
+        for tag, nbytes, e0, e1 in self._timeline:
+            e1.synchronize()
+            out.append(dict(tag=tag, bytes=int(nbytes), launch_ms=round(t0.elapsed_time(e0), 3), done_ms=round(t0.elapsed_time(e1), 3)))
+        return out
 
 
 def broadcast_parameters(module, src=0, group=None):

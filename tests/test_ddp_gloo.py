@@ -95,6 +95,39 @@ def test_bench_self_launches_n_ranks():
     assert bad.returncode != 0 and 'WORLD_SIZE' in (bad.stderr + bad.stdout)
 
 
+def test_a_failing_rank_surfaces_in_rank_zeros_line_instead_of_a_hang():
+    """a rank != 0 that raises after the rendezvous (here rank 1, injected) while rank 0 already sits in the next collective.  The run must
+    end within seconds -- not at the collective timeout --, with ONE JSON line on stdout whose `ddp.error` names the rank and the exception, and a
+    non-zero exit code.  Rank 0 failing itself gives the same line."""
+    import json
+    import subprocess
+    import sys
+    import time
+    from conftest import ROOT
+    for bad_rank in (1, 0):
+        env = dict(os.environ); env.pop('WORLD_SIZE', None); env.pop('RANK', None)
+        env.update(TCOW_DIST_BACKEND='gloo', TCOW_BENCH_FAIL_RANK=str(bad_rank), TCOW_DIST_TIMEOUT_S='600')
+        t0 = time.time()
+        out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--launch-selftest'], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode != 0 and time.time() - t0 < 120, (out.returncode, out.stderr[-1500:])
+        lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+        assert len(lines) == 1, out.stdout[-1500:]
+        res = json.loads(lines[0])
+        assert res['value'] is None and res['n_gpus'] == 2
+        err = res['ddp']['error']
+        assert [e['rank'] for e in err] == [bad_rank] and err[0]['type'] == 'RuntimeError' and 'injected failure' in err[0]['message']
+
+
+def test_first_contact_and_bucket_timeline_fields():
+    """ddp.first_contact outside a process group is a no-op record; GradSync.stats() carries the per-bucket timeline key (None on the CPU path)."""
+    from tcow_amd import ddp
+    c = ddp.first_contact()
+    assert c['world'] == 1 and c['ms'] == 0.0
+    st = ddp.GradSync(1).stats()
+    assert 'bucket_timeline' in st and st['bucket_timeline'] is None
+    assert ddp.rccl_version() is None or isinstance(ddp.rccl_version(), str)
+
+
 def test_group_sizes_spec():
     """TCOW_DDP_GROUP: one number or a comma list, top group first; the bottom group is small by default (its all-reduce cannot overlap)."""
     from tcow_amd.engine import group_sizes

@@ -167,3 +167,12 @@ def test_full_size_two_rank_bench_line_on_one_gpu(cuda):
     assert abs(d['allreduce_bytes'] - 488.6e6) < 2e6                                                # every trained parameter once, f32
     assert d['allreduce_exposed_ms'] >= 0.0 and 0 < d['ms_per_step_min'] <= d['ms_per_step_max'] and abs(d['ms_per_step_max'] - res['ms_per_step']) < 1e-6
     assert 'cpu_baseline' not in res and 'roofline' in res
+    # round 6: what a first SCALE run needs to explain itself -- the checked first collective, the backend / RCCL version, and per bucket when the backward
+    # published it and when the compute stream got past its wait (launch order = publishing order of the backward: top group first, late bucket last)
+    tl = d['bucket_timeline']
+    assert d['backend'] == 'gloo' and d['first_contact_ms'] >= 0.0 and 'rccl_version' in d
+    assert len(tl) == d['buckets'] and tl[0]['launch_ms'] == 0.0 and sum(b['bytes'] for b in tl) == d['allreduce_bytes']
+    assert all(a['launch_ms'] <= b['launch_ms'] and a['done_ms'] <= b['done_ms'] for a, b in zip(tl, tl[1:])) and all(b['done_ms'] >= b['launch_ms'] for b in tl)
+    ra = res['roofline_attention']
+    assert all(ra[k]['us'] > 0 and 0 < ra[k]['hbm_frac'] < 1 and 0 < ra[k]['mfma_frac'] < 1 for k in ('spatial_fwd', 'spatial_bwd', 'temporal_fwd', 'temporal_bwd'))
+    assert ra['spatial_fwd']['launches_per_step'] == 12 and ra['temporal_bwd']['launches_per_step'] == 12

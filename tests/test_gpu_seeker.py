@@ -716,6 +716,55 @@ def test_fp16_unscaling_inside_the_optimizer_is_bit_identical(cuda):
     assert all(torch.equal(a, b) for a, b in zip(pa, pb)) and all(torch.equal(a, b) for a, b in zip(va, vb))
 
 
+def test_two_threads_two_streams_match_sequential_calls(cuda):
+    """The torch.nn.DataParallel thread model (train.py:222-223) on ONE device: two host threads, each with its own stream and its own replica (same
+    weights, different clips), run forward + backward at the same time.  Outputs and every gradient must equal the sequential calls bit for bit --
+    which needs the library's scratch (attention / weight-gradient / LayerNorm / mask-head workspaces, ops.workspace) to be private to a stream:
+    with the per-device cache of rounds 1-5 both threads wrote the same attention and weight-gradient workspaces."""
+    import threading
+    cfg = synth.seeker_config(num_total_frames=8, frame_height=96, frame_width=128, embed_dim=256, depth=3, num_heads=4, causal_attention=1)
+    sd = synth.make_state_dict(cfg, 11)
+    clips = [synth.make_clip(2, 8, 96, 128, seed=40 + i) for i in range(2)]
+    ins = [(torch.from_numpy(c['rgb']).cuda(), torch.from_numpy(synth.make_query_mask(c, 0, 0)).cuda()) for c in clips]
+
+    def one(net, rgb, qm):
+        om, fl = net(rgb, qm)
+        (om.square().mean() + fl.square().mean()).backward()
+        return om.detach().clone(), fl.detach().clone(), [None if p.grad is None else p.grad.detach().clone() for p in net.parameters()]
+
+    for precision in ('bf16', 'fp32'):
+        nets = [build_hip_seeker(cfg, sd, precision).cuda().train() for _ in range(2)]
+        seq = [one(nets[i], *ins[i]) for i in range(2)]                     # sequential, default stream
+        torch.cuda.synchronize()
+        for rep in range(3):
+            for n in nets:
+                n.zero_grad(set_to_none=True)
+            streams = [torch.cuda.Stream() for _ in range(2)]
+            res, errs = [None, None], []
+            gate = threading.Barrier(2)
+
+            def worker(i):
+                try:
+                    torch.cuda.set_device(0)
+                    with torch.cuda.stream(streams[i]):
+                        gate.wait()
+                        res[i] = one(nets[i], *ins[i])
+                    streams[i].synchronize()
+                except BaseException as e:       # noqa: BLE001
+                    errs.append(e)
+
+            th = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+            [t.start() for t in th]; [t.join() for t in th]
+            assert not errs, errs
+            torch.cuda.synchronize()
+            for i in range(2):
+                assert torch.equal(res[i][0], seq[i][0]) and torch.equal(res[i][1], seq[i][1]), (precision, rep, i)
+                for a, b in zip(res[i][2], seq[i][2]):
+                    assert (a is None) == (b is None) and (a is None or torch.equal(a, b)), (precision, rep, i)
+    from tcow_amd import ops
+    assert len({k[1] for k in ops._ws_cache if k[2] == 'attn'}) >= 3        # the default stream's and the two side streams' attention scratch are distinct buffers
+
+
 def test_persistent_gradient_buckets(cuda):
     """persistent_grads=True: same gradient values, delivered in storage that is stable across steps (no autograd copy)."""
     cfg = synth.seeker_config(num_total_frames=4, frame_height=32, frame_width=32, embed_dim=128, depth=2, num_heads=2, causal_attention=1)
