@@ -258,8 +258,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_stream_nc(SeqDesc sd, int nt,
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
     const NcWork nw = nc_work<PACK>(sd.n_outer * sd.n_inner * sd.heads, nt, wave);
-    if (!nw.mixed && !nw.valid) return;                    // (a mixed workgroup whose second sequence does not exist keeps its waves for the barriers)
-    const int item = nw.pair / sd.heads, head = nw.pair - item * sd.heads;
+    if (!nw.mixed && !nw.valid) return;                    // (a mixed workgroup whose second sequence does not exist keeps its waves for the barriers ...
+    const int pair = nw.valid ? nw.pair : 0;               //  ... and must not form addresses from a sequence index past the end: it reads sequence 0's query rows, no more)
+    const int item = pair / sd.heads, head = pair - item * sd.heads;
     const long base = seq_base(sd, item);
     const long ld3 = 3L * sd.D, pse = sd.pos_stride * ld3;
     const bf16_t* qh = qkv + base * ld3 + head * ATT_HD;
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_stream_nc(SeqDesc sd, int nt,
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
         typedef __attribute__((ext_vector_type(8))) float f32x8;
-        qf[ks] = __builtin_convertvector(__builtin_convertvector(frag_row_global(qh, pse, nw.valid ? qc : 0, ks, hi), f32x8) * (kScale * kLog2e), bf16x8);
+        qf[ks] = __builtin_convertvector(__builtin_convertvector(frag_row_global(qh, pse, qc, ks, hi), f32x8) * (kScale * kLog2e), bf16x8);
     }
     f32x16 o0, o1, negm;
 #pragma unroll
