@@ -401,7 +401,7 @@ class RankErrors:
         with open(tmp, 'w') as f:
             json.dump(rec, f)
         os.replace(tmp, os.path.join(self.dir, f'rank{self.rank}.json'))
-        time.sleep(4.0)                 # (rank 0's watcher prints the line before this process -- and with it the launcher's whole job -- goes away)
+        time.sleep(5.0)                 # (rank 0's watcher prints the line before this process -- and with it the launcher's whole job -- goes away)
 
     def _reports(self):
         out = []
@@ -421,7 +421,7 @@ class RankErrors:
             except OSError:
                 continue
             if found:
-                time.sleep(1.0)         # let the other failing ranks finish writing
+                time.sleep(1.0 if self.rank == 0 else 3.0)         # rank 0: let other failing ranks finish writing; the others: let rank 0 print before any exit makes the launcher tear the job down
                 found = self._reports() or found
                 if self.rank == 0:
                     a = self.args
