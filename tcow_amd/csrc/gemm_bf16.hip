@@ -213,7 +213,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_320_kernel(NtParams p) {
     const int l31 = lane & 31, hi = lane >> 5;
     const int nblk = p.tiles_m * p.tiles_n;
     const int pid = xcd_remap(blockIdx.x, nblk);
-    const int pm = pid / p.tiles_n, pn = pid - pm * p.tiles_n;
+    int pm, pn;
+    nt_tile_of(pid, p.tiles_m, p.tiles_n, p.band, pm, pn);
     const int m0 = pm * C_BM, n0 = pn * C_BN;
     f32x16 acc[5][2];
 #pragma unroll
@@ -416,6 +417,17 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(NtParams p) {
 bool tcow_gemm_nt_c2_ok(const tcow_gemm_args* a);
 int tcow_gemm_nt_bf16_c2(hipStream_t stream, const tcow_gemm_args* a);
 
+// Tile order of the wide-output GEMMs (fc1, fc2's input gradient: N = 3072 at K = 768).  Row-major order gives an XCD a band of row tiles with all of W:
+// 4.7 MB of W do not stay in a 4 MB L2 beside the A stream, every round of workgroups re-fetches them (FETCH_SIZE 4.4x the algorithmic bytes on the 320
+// tile, 7.2x on the 160 tile).  Column bands (nt_tile_of) halve what an XCD keeps of W: measured per launch (profiles/r06_pmc_band.txt) 205 -> 172 MB with
+// bands of 6 tiles on the 320 tile, 341 -> 227 MB with bands of 4 on the 160 tile -- and the same time within +-1 % (the refills come from the Infinity
+// Cache and the kernel is not bound by them); narrower bands make more XCDs read the same A rows and fetch MORE (band 1: 516 MB).  Kept for the traffic.
+int nt_band_for(const tcow_gemm_args* a, int tiles_n, int tile) {
+    if (a->N < 3072) return 0;
+    const int band = tile == 320 ? 6 : 4;
+    return (tiles_n % band == 0 && tiles_n > band) ? band : 0;
+}
+
 int tcow_gemm_nt_bf16(hipStream_t stream, const tcow_gemm_args* a) {
     TCOW_CHECK_ARG(a->K % BK == 0, "tcow_gemm_nt(bf16): K=%d must be a multiple of %d", a->K, BK);
     TCOW_CHECK_ARG(a->lda % 8 == 0 && a->ldw % 8 == 0, "tcow_gemm_nt(bf16): lda/ldw must be multiples of 8 elements");
@@ -443,6 +455,7 @@ int tcow_gemm_nt_bf16(hipStream_t stream, const tcow_gemm_args* a) {
         }
         if (a->tile == 320 || (a->tile == 0 && fills && t320 >= 200)) {
             p.tiles_m = cdiv(a->M, C_BM); p.tiles_n = cdiv(a->N, C_BN);
+            p.band = nt_band_for(a, p.tiles_n, 320);
             // epilogue specialisations for the combinations the path uses; anything else takes the run-time-configured kernel
             typedef void (*Kern)(NtParams);
             const int rows = (a->row_scale ? 1 : 0) | (a->resid ? 2 : 0) | (a->bias2 ? 4 : 0);

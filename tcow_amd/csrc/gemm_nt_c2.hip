@@ -40,7 +40,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_c2_kernel(NtParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // = column block of the wave's 160 x 64 tile
     const int nblk = p.tiles_m * p.tiles_n;
     const int pid = xcd_remap(blockIdx.x, nblk);
-    const int pm = pid / p.tiles_n, pn = pid - pm * p.tiles_n;
+    int pm, pn;
+    nt_tile_of(pid, p.tiles_m, p.tiles_n, p.band, pm, pn);
     const int m0 = pm * D_BM, n0 = pn * D_BN;
     f32x16 acc[5][2];                                 // (unused: the epilogue's 32x32x16 form)
     f32x4 acc16[10][4];
@@ -218,12 +219,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_c2_kernel(NtParams p) {
 
 }  // namespace
 
+int nt_band_for(const tcow_gemm_args* a, int tiles_n, int tile);
 bool tcow_gemm_nt_c2_ok(const tcow_gemm_args* a) { return a->K % 128 == 0 && (long)a->M * a->lda < (1L << 30) && (long)a->N * a->ldw < (1L << 30); }   // (32-bit byte offsets below 2^31 + the out-of-range marker)
 
 // launch the 160 x 256 kernel (the caller -- tcow_gemm_nt_bf16 -- has validated the arguments)
 int tcow_gemm_nt_bf16_c2(hipStream_t stream, const tcow_gemm_args* a) {
     NtParams p = nt_params_from_args(a);
     p.tiles_m = cdiv(a->M, D_BM); p.tiles_n = cdiv(a->N, D_BN);
+    p.band = nt_band_for(a, p.tiles_n, 160);
     typedef void (*Kern)(NtParams);
     const int rows = (a->row_scale ? 1 : 0) | (a->resid ? 2 : 0) | (a->bias2 ? 4 : 0);
     const bool vec8 = a->N % 8 == 0 && a->ldc % 8 == 0 && a->ldr % 8 == 0 && a->ldaux % 8 == 0;   // the row-operand epilogues move 8 columns per lane

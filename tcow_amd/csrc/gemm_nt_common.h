@@ -25,6 +25,7 @@ struct NtParams {
     bf16_t* aux; long ldaux;
     int tiles_m, tiles_n;
     const float* bias2; const float* row_scale2;      // second bias with its own row scale (the folded temporal projection), or NULL
+    int band;                                         // tile order: 0 = row-major over (row tile, column tile); b > 0 = column bands of b tiles (nt_tile_of)
 };
 
 // the launch parameters of a validated tcow_gemm_nt call (tile counts are filled by the kernel's launcher)
@@ -35,7 +36,7 @@ static inline NtParams nt_params_from_args(const tcow_gemm_args* a) {
     p.C = a->C; p.ldc = a->ldc; p.out_f32 = a->out_f32; p.bias = a->bias; p.row_scale = a->row_scale;
     p.resid = a->resid; p.ldr = a->ldr; p.act = a->act; p.aux = (bf16_t*)a->aux; p.ldaux = a->ldaux;
     p.bias2 = a->bias2; p.row_scale2 = a->row_scale2;
-    p.tiles_m = p.tiles_n = 0;
+    p.tiles_m = p.tiles_n = 0; p.band = 0;
     return p;
 }
 
@@ -44,6 +45,16 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, k = bid >> 3;
     const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + k;
+}
+
+// Tile of a (remapped) workgroup id.  band = 0: row-major -- an XCD's contiguous range of ids is a band of row tiles with ALL column tiles: its A rows
+// are fetched once, all of W passes through its L2 for every few row tiles (fine while W fits beside the A stream: N <= 2304 at K = 768).  band = b > 0:
+// the column tiles are walked in bands of b (tiles_n % b == 0): ids run over (band, row tile, column inside the band), so an XCD's range is a row
+// range x one band -- it keeps b / tiles_n of W resident and tiles_n / b XCDs read the same A rows (from the Infinity Cache after the first).
+__device__ __forceinline__ void nt_tile_of(int pid, int tiles_m, int tiles_n, int band, int& pm, int& pn) {
+    if (band <= 0) { pm = pid / tiles_n; pn = pid - pm * tiles_n; return; }
+    const int per = tiles_m * band, j = pid / per, rem = pid - j * per;
+    pm = rem / band; pn = j * band + (rem - pm * band);
 }
 
 __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
