@@ -5,6 +5,7 @@ device pointers plus the current stream to the library and returns.  There is no
 failing library raises TcowError.
 """
 import ctypes
+import threading
 
 import numpy as np
 import torch
@@ -71,12 +72,14 @@ _ws_cache = {}
 
 
 def workspace(nbytes, device, tag='default'):
-    """Grow-only scratch buffer per (device, STREAM, tag).  Kernels on one stream run in order, so reuse within a stream is safe; two streams of one
+    """Grow-only scratch buffer per (device, STREAM, host thread, tag).  Kernels on one stream run in order, so reuse within a stream is safe; two streams of one
     device (two host threads driving replicas -- the torch.nn.DataParallel thread model of train.py:222-223 -- or a side stream) never share scratch:
     the key carries torch's current stream, the one the kernels that use the buffer are launched on (tests/test_gpu_seeker.py::test_two_threads_two_streams).
     A buffer that has to grow is replaced, not freed under a running kernel: the old tensor's storage returns to torch's caching allocator, which holds
     it for this stream until the work queued on it has drained."""
-    key = (str(device), _stream(), tag)          # (_stream(): the current stream of the current device -- the same call the launch that follows makes)
+    # (_stream(): the current stream of the current device -- the same call the launch that follows makes; the thread id: two host threads that share
+    # a stream -- torch.nn.DataParallel replicas placed on one device -- interleave their launches, and some scratch lives across two launches)
+    key = (str(device), _stream(), tag, threading.get_ident())
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=device)

@@ -765,6 +765,32 @@ def test_two_threads_two_streams_match_sequential_calls(cuda):
     assert len({k[1] for k in ops._ws_cache if k[2] == 'attn'}) >= 3        # the default stream's and the two side streams' attention scratch are distinct buffers
 
 
+def test_torch_dataparallel_wrapper_matches_the_plain_module(cuda):
+    """The reference's own multi-GPU mode is single-process torch.nn.DataParallel (train.py:222-223).  On this one-GPU box both replicas are placed on
+    device 0 (device_ids=[0, 0]): scatter -> replicate (shallow copies, `_is_replica`) -> two host threads on ONE stream -> gather, and the backward
+    through Broadcast / ReduceAddCoalesced.  Outputs = the plain module's on the full batch; parameter gradients = the plain module's (the loss is a sum
+    over clips).  fp32 so that the comparison is tight."""
+    cfg = synth.seeker_config(num_total_frames=4, frame_height=64, frame_width=64, embed_dim=128, depth=2, num_heads=2, causal_attention=1)
+    sd = synth.make_state_dict(cfg, 21)
+    clip = synth.make_clip(2, 4, 64, 64, seed=5)
+    rgb = torch.from_numpy(clip['rgb']).cuda(); qm = torch.from_numpy(synth.make_query_mask(clip, 0, 0)).cuda()
+    net = build_hip_seeker(cfg, sd, 'fp32').cuda().train()
+    om, fl = net(rgb, qm)
+    (om.square().sum() + fl.square().sum()).backward()
+    ref = [None if p.grad is None else p.grad.detach().clone() for p in net.parameters()]
+    net.zero_grad(set_to_none=True)
+    dp = torch.nn.DataParallel(net, device_ids=[0, 0])
+    for rep in range(2):
+        om2, fl2 = dp(rgb, qm)
+        assert om2.shape == om.shape and torch.allclose(om2, om.detach(), rtol=0, atol=1e-6) and torch.allclose(fl2, fl.detach(), rtol=0, atol=1e-6)
+        (om2.square().sum() + fl2.square().sum()).backward()
+        for p, r in zip(net.parameters(), ref):
+            assert (p.grad is None) == (r is None)
+            if r is not None:
+                assert float((p.grad - r).abs().max()) <= 2e-5 * float(r.abs().max()) + 1e-9
+        net.zero_grad(set_to_none=True)
+
+
 def test_persistent_gradient_buckets(cuda):
     """persistent_grads=True: same gradient values, delivered in storage that is stable across steps (no autograd copy)."""
     cfg = synth.seeker_config(num_total_frames=4, frame_height=32, frame_width=32, embed_dim=128, depth=2, num_heads=2, causal_attention=1)
