@@ -487,7 +487,7 @@ def run(args):
         net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg, 900).items()}, strict=True)
         net = net.to(dev).train()
         ddp.broadcast_parameters(net)
-        opt = FusedAdamWClip(list(net.parameters()), lr=1e-4, max_norm=0.3, module=net)   # train.py:99-102,239-241: clip_grad_norm_(0.3) + AdamW(lr 1e-4), fused
+        opt = FusedAdamWClip(list(net.parameters()), lr=1e-4, max_norm=0.3, module=net, fuse_cast=os.environ.get('TCOW_FUSE_CAST', '1') != '0')   # train.py:99-102,239-241: clip_grad_norm_(0.3) + AdamW(lr 1e-4), fused
         net.seeker.persistent_grads = True                                 # one backward per step: gradients live in persistent flat buckets
         net.seeker.grad_hook = ddp.GradSync(world, bucket_dtype=args.grad_dtype)
         pipe = SeekerPipeline(net, num_queries=Qs, train_args=default_args(), phase='train', device=dev,

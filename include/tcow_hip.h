@@ -313,6 +313,14 @@ int tcow_adamw_clip_step(void* stream, const void* chunks, int n_chunks, float l
  * coefficient x inverse scale -- exact, and the separate unscaling pass over all gradients is gone.  (ABI 9) */
 int tcow_adamw_clip_step_scaled(void* stream, const void* chunks, int n_chunks, float lr, float beta1, float beta2, float eps,
                                 float weight_decay, int step, float max_norm, float* scratch, const float* grad_inv_scale);
+/* The same step with the 16-bit operand copies of the GEMM weights written by the update itself (ABI 10): chunks[0 .. n_chunks) cover every parameter (gradient
+ * norm); flat_chunks[0 .. n_flat) the ones updated flat, the others as 64 x 64 tiles -- tiles[0 .. n_tiles) = records of tcow_adamw_tile_bytes() bytes
+ * {float* p; const float* g; float* m; float* v; void* wc; void* wt; int K, N;} with the pointers at the tile's origin in p / g / m / v / wc ([N, K], row
+ * stride K) and wt ([K, N], row stride N); wc / wt receive the updated values in this library's 16-bit format.  Replaces tcow_cast_transpose_batched for
+ * those weights (one read of 4 bytes per parameter less per step). */
+long tcow_adamw_tile_bytes(void);
+int tcow_adamw_clip_step_cast(void* stream, const void* chunks, int n_chunks, const void* flat_chunks, int n_flat, const void* tiles, int n_tiles, float lr, float beta1,
+                              float beta2, float eps, float weight_decay, int step, float max_norm, float* scratch, const float* grad_inv_scale);
 
 /* ------------------------------------------------------------------------------------------- mask objective (caller row L)
  * One channel of the TCOW mask loss, forward value and d(loss)/d(logits) together (loss.py:164-225, with

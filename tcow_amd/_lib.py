@@ -117,6 +117,8 @@ SIGNATURES = {
     'tcow_adamw_chunk_bytes': (_l, []),
     'tcow_adamw_clip_step': (_i, [_vp, _vp, _i, _f, _f, _f, _f, _f, _i, _f, _vp]),
     'tcow_adamw_clip_step_scaled': (_i, [_vp, _vp, _i, _f, _f, _f, _f, _f, _i, _f, _vp, _vp]),
+    'tcow_adamw_tile_bytes': (_l, []),
+    'tcow_adamw_clip_step_cast': (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _f, _f, _f, _f, _f, _i, _f, _vp, _vp]),
     'tcow_mask_loss_workspace_bytes': (ctypes.c_size_t, [_l, _l]),
     'tcow_mask_loss_workspace_bytes_for': (ctypes.c_size_t, [_l, _l, ctypes.c_double, _f]),
     'tcow_mask_loss': (_i, [_vp, ctypes.POINTER(MaskLossArgs)]),

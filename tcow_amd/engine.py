@@ -84,6 +84,7 @@ def _get_weight(module, p, train):
         # remember the buffers: after an optimizer step refresh_weights() re-casts ALL registered weights in one launch
         reg = module.__dict__.setdefault('_wreg', {})
         reg[key] = (p, Wc if ops.is16(mode) else None, Wt, N, K)
+        module.__dict__['_wreg_gen'] = module.__dict__.get('_wreg_gen', 0) + 1      # (FusedAdamWClip's tile table points into these buffers: it rebuilds when this moves)
     return Wc, Wt
 
 
@@ -155,7 +156,13 @@ def refresh_weights(module):
         live = [ent for k, ent in folds.items() if k in reg]         # (a fold whose operand copies are no longer registered is stale: skip it)
         if live:
             _fold_products(live)
-    ents = list(reg.items())
+    # weights whose copies the optimizer has just written itself (FusedAdamWClip's tile kernel, 16-bit modes): only their version stamps are refreshed below
+    done = module.__dict__.pop('_opt_cast_keys', None) or ()
+    all_ents = list(reg.items())
+    ents = [(k, v) for k, v in all_ents if k not in done]
+    if not ents:
+        _stamp_versions(module, all_ents, folds, mode)
+        return True
     sig = tuple((k, p.data_ptr(), 0 if Wc is None else Wc.data_ptr(), 0 if Wt is None else Wt.data_ptr()) for k, (p, Wc, Wt, N, K) in ents) + (mode,)
     tab = module.__dict__.get('_wtab')
     if tab is None or tab[0] != sig:
@@ -170,6 +177,12 @@ def refresh_weights(module):
         tab = (sig, buf, len(rec), tiles)
         module.__dict__['_wtab'] = tab
     ops.cast_transpose_batched(mode, tab[1], tab[2], tab[3])
+    _stamp_versions(module, all_ents, folds, mode)
+    return True
+
+
+def _stamp_versions(module, ents, folds, mode):
+    """The operand copies of `ents` are current for the parameters' present versions (and this weight epoch)."""
     epoch = getattr(module, '_wepoch', 0)
     for k, (p, Wc, Wt, N, K) in ents:
         if folds and k in folds:
@@ -178,7 +191,6 @@ def refresh_weights(module):
             continue
         w = _w2d(p.detach())
         module._wcache[k] = ((p._version, epoch), mode, Wc if Wc is not None else w.contiguous(), Wt)
-    return True
 
 
 def L_cast_desc_bytes():

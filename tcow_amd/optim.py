@@ -37,7 +37,7 @@ def _ops_stream():
 
 
 class FusedAdamWClip(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, max_norm=0.3, module=None):
+    def __init__(self, params, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, max_norm=0.3, module=None, fuse_cast=True):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         if len(self.param_groups) != 1:
             raise L.TcowError('FusedAdamWClip takes one parameter group (train.py:239-241 builds exactly one)')
@@ -49,6 +49,10 @@ class FusedAdamWClip(torch.optim.Optimizer):
         self._tracker = None
         self._skip_carry = 0.0         # skipped steps of earlier pointer tables (the device counter lives in the scratch buffer)
         self._live = []; self._seen_grads = []; self._step_base = 0; self._steps_pending = 0
+        # fuse_cast (16-bit modes, module= given): GEMM weights are updated tile by tile and the update writes their 16-bit W / W^T operand copies itself
+        # (tcow_adamw_clip_step_cast) -- the module's batched re-cast then only covers what is left (the folded products)
+        self.fuse_cast = bool(fuse_cast)
+        self._tiles = None; self._flat_table = None; self._cast_keys = frozenset(); self._wreg_gen = None
         if module is not None:     # a Seeker / QueryMaskTracker: batch re-cast of its GEMM operand copies right after the update
             tracker = getattr(module, 'seeker', module)
             self._tracker = tracker
@@ -85,8 +89,27 @@ class FusedAdamWClip(torch.optim.Optimizer):
             self._step_base += self._steps_pending
         self._steps_pending = 0
 
+    def _cast_registry(self):
+        """{id(parameter): (Wc, Wt, N, K)} of the GEMM weights whose 16-bit operand copies this optimizer may write (the module's registry of the current
+        training forward: engine._get_weight), or {}."""
+        trk = self._tracker
+        if not self.fuse_cast or trk is None or getattr(trk, 'precision', None) not in ('bf16', 'fp16') or getattr(trk, '_is_replica', False):
+            return {}
+        out = {}
+        for k, (p, Wc, Wt, N, K) in (trk.__dict__.get('_wreg') or {}).items():
+            if isinstance(k, int) and isinstance(p, torch.nn.Parameter) and Wc is not None and Wt is not None and N % 64 == 0 and K % 64 == 0 and p.numel() == N * K:
+                out[id(p)] = (Wc, Wt, N, K)
+        return out
+
+    def _lib(self):
+        """The build of the library whose 16-bit format the module's operand copies have."""
+        trk = self._tracker
+        return L.lib('fp16') if (trk is not None and getattr(trk, 'precision', None) == 'fp16' and self._tiles is not None) else L.lib()
+
     def _build(self, live):
-        rows = []
+        reg = self._cast_registry()
+        fused = [p for p in live if id(p) in reg]
+        rows, flat_rows = [], []        # every parameter (gradient norm, in the order of `live`: the partial sums are folded in that order) / the flat-updated ones
         for p in live:
             st = self.state[p]
             if 'exp_avg' not in st:
@@ -101,11 +124,31 @@ class FusedAdamWClip(torch.optim.Optimizer):
             n = p.numel()
             for off in range(0, n, CHUNK):
                 rows.append((p.data_ptr() + 4 * off, g.data_ptr() + 4 * off, m.data_ptr() + 4 * off, v.data_ptr() + 4 * off, min(CHUNK, n - off)))
+                if id(p) not in reg:
+                    flat_rows.append(rows[-1])
         if self.scratch is not None:
             self._skip_carry += float(self.scratch[-1])      # (rebuilds are rare: first step, re-allocated gradients, load_state_dict)
         self._table = torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(live[0].device)
         self.scratch = torch.zeros(len(rows) + 3, dtype=torch.float32, device=live[0].device)      # [chunk partials | coef, norm, skipped]
         self.scratch[-1] = self._skip_carry
+        self._tiles = None; self._flat_table = None; self._cast_keys = frozenset()
+        trk = self._tracker
+        self._wreg_gen = trk.__dict__.get('_wreg_gen') if trk is not None else None
+        if fused:
+            assert L.lib().tcow_adamw_tile_bytes() == 56
+            recs = []
+            for p in fused:
+                Wc, Wt, N, K = reg[id(p)]
+                st = self.state[p]
+                n0, k0 = np.meshgrid(np.arange(0, N, 64, dtype=np.int64), np.arange(0, K, 64, dtype=np.int64), indexing='ij')
+                o = (n0 * K + k0).reshape(-1); ot = (k0 * N + n0).reshape(-1)
+                r = np.empty((o.size, 7), dtype=np.int64)
+                r[:, 0] = p.data_ptr() + 4 * o; r[:, 1] = p.grad.data_ptr() + 4 * o; r[:, 2] = st['exp_avg'].data_ptr() + 4 * o; r[:, 3] = st['exp_avg_sq'].data_ptr() + 4 * o
+                r[:, 4] = Wc.data_ptr() + 2 * o; r[:, 5] = Wt.data_ptr() + 2 * ot; r[:, 6] = K | (N << 32)
+                recs.append(r)
+            self._tiles = torch.from_numpy(np.concatenate(recs, axis=0)).to(live[0].device)
+            self._flat_table = torch.from_numpy(np.asarray(flat_rows, dtype=np.int64).reshape(-1, 5)).to(live[0].device)
+            self._cast_keys = frozenset(id(p) for p in fused)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -126,6 +169,8 @@ class FusedAdamWClip(torch.optim.Optimizer):
                     break
         if fast and self._live:
             fast = self._live[0].grad.data_ptr() == self._key[0][1] and self._live[-1].grad.data_ptr() == self._key[-1][1]
+        if fast and self._tracker is not None and self.fuse_cast:
+            fast = self._tracker.__dict__.get('_wreg_gen') == self._wreg_gen       # the module's operand copies were re-allocated (or appeared): the tile table is stale
         if fast:
             live = self._live
         else:
@@ -134,7 +179,8 @@ class FusedAdamWClip(torch.optim.Optimizer):
                 return loss
             self._flush_steps()
             key = tuple((id(p), p.grad.data_ptr(), self.state[p]['exp_avg'].data_ptr() if 'exp_avg' in self.state[p] else 0) for p in live)
-            if key != self._key:                     # gradient / moment buffers moved (first step, re-allocated grads, load_state_dict): rebuild the pointer table
+            gen = self._tracker.__dict__.get('_wreg_gen') if self._tracker is not None else None
+            if key != self._key or (self.fuse_cast and gen != self._wreg_gen):       # gradient / moment buffers moved (first step, re-allocated grads, load_state_dict) or the module's operand copies did: rebuild the pointer tables
                 self._build(live)
                 self._key = tuple((id(p), p.grad.data_ptr(), self.state[p]['exp_avg'].data_ptr()) for p in live)
             self._live = live
@@ -146,10 +192,19 @@ class FusedAdamWClip(torch.optim.Optimizer):
         step = self._step_base + self._steps_pending + 1
         trk = self._tracker
         inv_scale = trk.__dict__.get('pending_inv_scale') if trk is not None else None      # binary16: the last backward left its gradients loss-scaled (it stays valid until the next backward rewrites them)
-        L.check(L.lib().tcow_adamw_clip_step_scaled(_ops_stream(), self._table.data_ptr(), self._table.shape[0], float(grp['lr']),
-                                                    float(grp['betas'][0]), float(grp['betas'][1]), float(grp['eps']), float(grp['weight_decay']), step,
-                                                    float(self.max_norm or 0.0), self.scratch.data_ptr(), inv_scale.data_ptr() if inv_scale is not None else None),
-                'tcow_adamw_clip_step_scaled')
+        if self._tiles is not None:
+            lib = self._lib()
+            L.check(lib.tcow_adamw_clip_step_cast(_ops_stream(), self._table.data_ptr(), self._table.shape[0], self._flat_table.data_ptr() if self._flat_table.shape[0] else None,
+                                                  self._flat_table.shape[0], self._tiles.data_ptr(), self._tiles.shape[0],
+                                                  float(grp['lr']), float(grp['betas'][0]), float(grp['betas'][1]), float(grp['eps']), float(grp['weight_decay']), step,
+                                                  float(self.max_norm or 0.0), self.scratch.data_ptr(), inv_scale.data_ptr() if inv_scale is not None else None),
+                    'tcow_adamw_clip_step_cast', lib)
+            trk.__dict__['_opt_cast_keys'] = self._cast_keys          # (consumed by the module's refresh_weights in the on_step callback below)
+        else:
+            L.check(L.lib().tcow_adamw_clip_step_scaled(_ops_stream(), self._table.data_ptr(), self._table.shape[0], float(grp['lr']),
+                                                        float(grp['betas'][0]), float(grp['betas'][1]), float(grp['eps']), float(grp['weight_decay']), step,
+                                                        float(self.max_norm or 0.0), self.scratch.data_ptr(), inv_scale.data_ptr() if inv_scale is not None else None),
+                    'tcow_adamw_clip_step_scaled')
         # precision='fp16': a non-finite gradient norm means the scaled backward overflowed binary16 -- the kernels above skipped the update
         # (clip coefficient -1); lower the module's loss-scale exponent by 4, otherwise let it creep back towards -2.  All on the device.
         ls = getattr(trk, 'ls_log2', None) if trk is not None and getattr(trk, 'precision', None) == 'fp16' and getattr(trk, 'loss_scale', None) == 'dynamic' else None

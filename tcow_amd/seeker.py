@@ -208,6 +208,7 @@ class QueryMaskTracker(nn.Module):
         self.gemm_mode = ops.F32X3 if precision == 'bf16x3' else self.mode     # GEMM arithmetic; storage / every other kernel follow `mode`
         self._wcache = {}
         self.__dict__.pop('_wreg', None); self.__dict__.pop('_wtab', None); self.__dict__.pop('_foldreg', None)
+        self.__dict__['_wreg_gen'] = self.__dict__.get('_wreg_gen', 0) + 1
         return self
 
     def invalidate_weight_cache(self):
@@ -223,6 +224,7 @@ class QueryMaskTracker(nn.Module):
         products and the persistent gradient buffers.  They are keyed by id(parameter), which survives a `.data` swap."""
         self._wcache = {}
         self.__dict__.pop('_wreg', None); self.__dict__.pop('_wtab', None); self.__dict__.pop('_foldreg', None)
+        self.__dict__['_wreg_gen'] = self.__dict__.get('_wreg_gen', 0) + 1
         self._gbufs = {}
 
     def _apply(self, fn, *a, **kw):
@@ -292,6 +294,7 @@ class QueryMaskTracker(nn.Module):
             # each replica private operand / gradient caches for this call instead of growing the shared ones with dead entries
             self._wcache, self._gbufs = {}, {}
             self.__dict__.pop('_wreg', None); self.__dict__.pop('_wtab', None); self.__dict__.pop('_foldreg', None)
+            self.__dict__['_wreg_gen'] = self.__dict__.get('_wreg_gen', 0) + 1
         rgb = input_frames.to(torch.float32).contiguous()                 # mask_tracker.py:103-104 (inputs not mutated)
         qm = query_mask.to(torch.float32).contiguous()
         from .engine import SeekerFunction
