@@ -76,14 +76,3 @@ build/ubench_tn_ab: tools/ubench_tn_ab.hip $(CSRC)/gemm_bf16.hip $(CSRC)/gemm_nt
 build/ubench_mfma: tools/ubench_mfma.hip
 	@mkdir -p build
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -x hip $< -o $@
-
-tools/attn_round_asm.inc: tools/gen_attn_round.py
-	python3 tools/gen_attn_round.py $@
-
-build/ubench_p4_ab%: tools/ubench_p4.hip tools/attn_fwd_p4.hip tools/attn_round_asm.inc $(CSRC)/attention_tiles.h $(CSRC)/common.h
-	@mkdir -p build
-	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fno-honor-nans -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form -Wno-unused-result -DP4_AB=$* -x hip $< -o $@
-
-build/ubench_p4: tools/ubench_p4.hip tools/attn_fwd_p4.hip tools/attn_round_asm.inc $(CSRC)/attention_tiles.h $(CSRC)/common.h
-	@mkdir -p build
-	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fno-honor-nans -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form -Wno-unused-result -x hip $< -o $@
