@@ -348,6 +348,7 @@ typedef struct {
     float* total;
     float* dlogits;  long dlogits_seq_stride;
     void* ws;  size_t ws_bytes;
+    int focal;                      /* train_args.focal_loss (loss.py:49-51): sigmoid focal loss (alpha 0.25, gamma 2) in place of the BCE term  (ABI 10) */
 } tcow_mask_loss_args;
 /* Workspace of one channel: tcow_mask_loss_workspace_bytes = the most any job of this geometry needs; tcow_mask_loss_workspace_bytes_for = what THIS job
  * needs -- the 4-byte-per-pixel image of loss bit patterns (n_frames * frame_len * 4 bytes, the bulk) only exists when the radix select runs, i.e. when

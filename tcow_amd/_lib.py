@@ -58,7 +58,7 @@ class MaskLossArgs(ctypes.Structure):
                 ('weighted_aot', ctypes.c_int), ('aot_loss', ctypes.c_float), ('topk_frac', ctypes.c_double),
                 ('loss_weight', ctypes.c_float), ('loss', ctypes.c_void_p), ('total', ctypes.c_void_p),
                 ('dlogits', ctypes.c_void_p), ('dlogits_seq_stride', ctypes.c_long),
-                ('ws', ctypes.c_void_p), ('ws_bytes', ctypes.c_size_t)]
+                ('ws', ctypes.c_void_p), ('ws_bytes', ctypes.c_size_t), ('focal', ctypes.c_int)]
 
 
 _libs = {}

@@ -27,6 +27,7 @@ struct MlView {
     const float* fw;                        // [n_frames] or null
     float* dx; long dxs;
     int T; int L4; int n_frames; int weighted;
+    int focal;                              // loss.py:49-51: sigmoid focal loss (alpha 0.25, gamma 2) in place of the plain BCE term
 };
 
 struct MlCtl {
@@ -54,6 +55,18 @@ __device__ __forceinline__ void bce_sig(float x, float t, float& bce, float& p) 
     const float inv = 1.0f / (1.0f + e);
     p = x >= 0.0f ? inv : e * inv;
     bce = fmaxf(x, 0.0f) - x * t + log1pf(e);
+}
+
+// The per-pixel loss value and its derivative d(value)/d(logit).  focal = 0: BCE, derivative p - t.  focal = 1 (train_args.focal_loss, loss.py:49-51 =
+// torchvision.ops.sigmoid_focal_loss with its defaults alpha = 0.25, gamma = 2, reduction 'none'): value = a_t (1 - p_t)^2 bce with
+// p_t = p t + (1 - p)(1 - t), a_t = 0.25 t + 0.75 (1 - t); derivative a_t (1 - p_t) [(1 - p_t)(p - t) - 2 p (1 - p)(2 t - 1) bce].  One instruction
+// sequence for every pass (the radix select compares bit patterns of the value across passes).
+__device__ __forceinline__ void pix_loss(float x, float t, int focal, float& val, float& dval, float& p) {
+    float bce; bce_sig(x, t, bce, p);
+    if (!focal) { val = bce; dval = p - t; return; }
+    const float pt = p * t + (1.0f - p) * (1.0f - t), at = 0.25f * t + 0.75f * (1.0f - t), q = 1.0f - pt;
+    val = at * bce * (q * q);
+    dval = at * q * (q * (p - t) - 2.0f * p * (1.0f - p) * (2.0f * t - 1.0f) * bce);
 }
 
 __device__ __forceinline__ double block_sum(double v, double* red) {
@@ -156,7 +169,7 @@ __device__ __forceinline__ void ml_stats_body(const MlView& v, const MlWs& ws, i
             unsigned vbs[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float bce, p; bce_sig(xs[e], ts[e], bce, p);
+                float bce, dval, p; pix_loss(xs[e], ts[e], v.focal, bce, dval, p);
                 const unsigned vb = vbits(bce, wv[e], v.weighted);
                 vbs[e] = vb;
                 s[0] += bce * wv[e]; s[1] += __builtin_bit_cast(float, vb);
@@ -292,11 +305,10 @@ __device__ __forceinline__ void ml_grad_body(const MlView& v, const MlWs& ws, fl
             float g[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float bce, p; bce_sig(xs[e], ts[e], bce, p);
+                float bce, d, p; pix_loss(xs[e], ts[e], v.focal, bce, d, p);
                 const unsigned vb = vbits(bce, wv[e], v.weighted);
                 const float sel = mode_all ? 1.f : (vb > tau ? 1.f : (vb == tau ? tie : 0.f));
                 tk += sel * __builtin_bit_cast(float, vb);
-                const float d = p - ts[e];
                 float gr = c_custom * wv[e] * d + c_boot * sel * (v.weighted ? wv[e] : 1.f) * d;
                 const float dJ = -(ts[e] * D - num * (1.f - ts[e])) * invD2;
                 gr += c_jac * dJ * p * (1.f - p);
@@ -389,7 +401,7 @@ static int ml_make_job(const tcow_mask_loss_args* a, MlJob& J) {
     MlView& v = J.v;
     v.x = a->logits; v.xs = a->logits_seq_stride; v.t = a->target; v.ts = a->target_seq_stride;
     v.pw = a->pixel_w; v.fw = a->frame_w; v.dx = a->dlogits; v.dxs = a->dlogits_seq_stride;
-    v.T = (int)a->frames_per_seq; v.L4 = (int)(a->frame_len / 4); v.n_frames = (int)a->n_frames; v.weighted = a->weighted_aot ? 1 : 0;
+    v.T = (int)a->frames_per_seq; v.L4 = (int)(a->frame_len / 4); v.n_frames = (int)a->n_frames; v.weighted = a->weighted_aot ? 1 : 0; v.focal = a->focal ? 1 : 0;
     MlWs& ws = J.ws; char* p = (char*)a->ws;
     ws.fsel = (int*)p; p += ((size_t)v.n_frames * sizeof(int) + 255) & ~(size_t)255;
     ws.fwsum = (double*)p; p += ((size_t)v.n_frames * sizeof(double) + 255) & ~(size_t)255;

@@ -359,7 +359,7 @@ def cast_transpose_batched(mode, table, n, total_tiles):
 
 
 def mask_loss(logits, target, channel, pixel_w=None, frame_w=None, weighted_aot=False, aot_loss=0.8, topk_frac=1.0,
-              loss_weight=1.0, loss_out=None, total=None, dlogits=None):
+              loss_weight=1.0, loss_out=None, total=None, dlogits=None, focal=False):
     """Channel `channel` of the TCOW mask objective on (BQ, C, T, H, W) f32 logits / targets (see tcow_mask_loss):
     writes loss_out[0], adds loss_weight * loss to total[0] and d(loss)/d(logits) into dlogits[:, channel]."""
     _need_cuda(logits, target, pixel_w, frame_w, loss_out, total, dlogits)
@@ -379,12 +379,12 @@ def mask_loss(logits, target, channel, pixel_w=None, frame_w=None, weighted_aot=
     a = L.MaskLossArgs(n_frames, frame_len, T, logits.data_ptr() + off, C * T * frame_len, target.data_ptr() + off, C * T * frame_len,
                        _p(pixel_w), _p(frame_w), 1 if weighted_aot else 0, float(aot_loss), float(topk_frac), float(loss_weight),
                        loss_out.data_ptr(), _p(total), (dlogits.data_ptr() + off) if dlogits is not None else None,
-                       C * T * frame_len, ws.data_ptr(), ws.numel())
+                       C * T * frame_len, ws.data_ptr(), ws.numel(), 1 if focal else 0)
     L.check(lib.tcow_mask_loss(_stream(), ctypes.byref(a)), 'tcow_mask_loss')
     return loss_out
 
 
-def mask_loss_channels(logits, target, jobs, aot_loss=0.8, topk_frac=1.0, total=None, dlogits=None):
+def mask_loss_channels(logits, target, jobs, aot_loss=0.8, topk_frac=1.0, total=None, dlogits=None, focal=False):
     """Several channels of the TCOW mask objective in ONE set of launches (tcow_mask_loss_batch).  jobs: up to 4 tuples
     (channel, pixel_w | None, frame_w | None, weighted_aot, loss_weight, loss_out[1]); `total` receives sum_j loss_weight_j * loss_j in job order."""
     _need_cuda(logits, target, total, dlogits)
@@ -407,7 +407,7 @@ def mask_loss_channels(logits, target, jobs, aot_loss=0.8, topk_frac=1.0, total=
         arr[i] = L.MaskLossArgs(n_frames, frame_len, T, logits.data_ptr() + off, C * T * frame_len, target.data_ptr() + off, C * T * frame_len,
                                 _p(pixel_w), _p(frame_w), 1 if weighted_aot else 0, float(aot_loss), float(topk_frac), float(loss_weight),
                                 loss_out.data_ptr(), _p(total), (dlogits.data_ptr() + off) if dlogits is not None else None,
-                                C * T * frame_len, ws.data_ptr(), ws.numel())
+                                C * T * frame_len, ws.data_ptr(), ws.numel(), 1 if focal else 0)
     L.check(lib.tcow_mask_loss_batch(_stream(), arr, len(jobs)), 'tcow_mask_loss_batch')
 
 

@@ -57,7 +57,7 @@ class FusedMaskObjective(torch.autograd.Function):
     from libtcow_hip's tcow_mask_loss in the forward (no host synchronisation).  Returns (total, terms[3])."""
 
     @staticmethod
-    def forward(ctx, logits, target, snitch_w, occl_fw, cont_fw, lws, aot_loss, topk_frac):
+    def forward(ctx, logits, target, snitch_w, occl_fw, cont_fw, lws, aot_loss, topk_frac, focal=False):
         from . import ops
         B, Q, C, T, H, W = logits.shape
         lo = logits.detach().reshape(B * Q, C, T, H, W).contiguous(); tg = target.reshape(B * Q, C, T, H, W).contiguous()
@@ -72,7 +72,7 @@ class FusedMaskObjective(torch.autograd.Function):
             elif dl is not None:
                 dl[:, c].zero_()
         if jobs:                                   # the active channels as ONE set of launches (tcow_mask_loss_batch)
-            ops.mask_loss_channels(lo, tg, jobs, aot_loss=aot_loss, topk_frac=topk_frac, total=total, dlogits=dl)
+            ops.mask_loss_channels(lo, tg, jobs, aot_loss=aot_loss, topk_frac=topk_frac, total=total, dlogits=dl, focal=focal)
         ctx.dl = dl; ctx.shape = logits.shape
         ctx.mark_non_differentiable(terms)
         return total, terms
@@ -80,7 +80,7 @@ class FusedMaskObjective(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_total, _g_terms):
         if not ctx.needs_input_grad[0]:
-            return None, None, None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None, None
         dl = ctx.dl; ctx.dl = None
         if dl is None:         # the gradient image is scaled IN PLACE below and handed on: a second backward through this node has nothing left to scale
             from ._lib import TcowError
@@ -89,8 +89,8 @@ class FusedMaskObjective(torch.autograd.Function):
         if g_total.dtype == torch.float32 and g_total.numel() == 1 and g_total.device == dl.device:
             from . import ops
             ops.scale_unless_one(dl, g_total.contiguous())          # in place, and not at all when the upstream gradient is 1 (decided on the device)
-            return dl.reshape(ctx.shape), None, None, None, None, None, None, None
-        return (dl * g_total).reshape(ctx.shape), None, None, None, None, None, None, None
+            return dl.reshape(ctx.shape), None, None, None, None, None, None, None, None
+        return (dl * g_total).reshape(ctx.shape), None, None, None, None, None, None, None, None
 
 
 class TcowLosses:
@@ -140,7 +140,7 @@ class TcowLosses:
             if self.args.focal_loss:
                 # loss.py:49-51: torchvision.ops.sigmoid_focal_loss(x, y, reduction='none') with its defaults alpha = 0.25, gamma = 2 -- restated
                 # from torchvision's published definition (torchvision is not installed here: no vector of the reference's pins this branch;
-                # args.py:198 defaults it to False).  Tensor path only (the fused kernels implement the BCE objective).
+                # args.py:198 defaults it to False).  The fused kernels implement the same formula (mask_loss.hip::pix_loss).
                 p = torch.sigmoid(lo)
                 p_t = p * tg + (1.0 - p) * (1.0 - tg)
                 bce = (0.25 * tg + 0.75 * (1.0 - tg)) * bce * (1.0 - p_t) ** 2
@@ -163,7 +163,7 @@ class TcowLosses:
         if metrics_only:
             return {'metrics': calculate_metrics_mask_track(out, tgt)}
         a = self.args
-        fused = (out.is_cuda and not a.focal_loss and (out.shape[-1] * out.shape[-2]) % 4 == 0) if self.fused is None else self.fused
+        fused = (out.is_cuda and (out.shape[-1] * out.shape[-2]) % 4 == 0) if self.fused is None else self.fused
         if fused:
             return self._per_example_fused(model_retval, query_time, progress)
         res = {'track': None, 'occl_mask': None, 'cont_mask': None}
@@ -209,7 +209,7 @@ class TcowLosses:
                 fws[i] = (has * (1.0 - a.occl_cont_zero_weight) + a.occl_cont_zero_weight).contiguous()
         topk_frac = min(max(1.0 - progress * 8.5, 0.15), 1.0)
         lws = (float(a.track_lw), float(a.occl_mask_lw), float(a.cont_mask_lw))
-        total, terms = FusedMaskObjective.apply(out, tgt, sw, fws[0], fws[1], lws, float(a.aot_loss), topk_frac)
+        total, terms = FusedMaskObjective.apply(out, tgt, sw, fws[0], fws[1], lws, float(a.aot_loss), topk_frac, bool(a.focal_loss))
         res = {name: (terms[i] if lws[i] > 0.0 else None) for i, name in enumerate(('track', 'occl_mask', 'cont_mask'))}
         res['_fused_total'] = total
         res['metrics'] = calculate_metrics_mask_track(out, tgt)

@@ -156,6 +156,42 @@ def test_fused_mask_objective_matches_reference_scalars(cuda, phase):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('aot', [0.8, 0.0])
+def test_fused_mask_objective_with_focal_loss(cuda, aot):
+    """train_args.focal_loss = True (loss.py:49-51: torchvision's sigmoid focal loss, alpha 0.25, gamma 2, replaces the BCE term) through the HIP objective
+    (mask_loss.hip::pix_loss: value and closed-form derivative) against the tensor restatement + autograd: the three terms, the total and d(total)/d(logits),
+    early (top-k = all) and late (top-k < all) in training.  (The reference's own number for this branch cannot be produced here -- torchvision is absent --;
+    the tensor path restates torchvision's published definition, test_focal_loss_follows_the_published_definition.)"""
+    import argparse
+    _, g = load_golden('g5_pipeline_cfg1')
+    data = _data('cuda')
+    ref_out = torch.from_numpy(g['train::output_mask']).cuda() * 4.0           # wider logits: (1 - p_t)^2 spans its range
+    sel = torch.from_numpy(g['train::sel_query_inds'])
+    args = argparse.Namespace(**{**vars(default_args(hard_negative_factor=1.0)), 'focal_loss': True, 'aot_loss': aot})
+    for progress in (0.0, 0.09, 0.5):
+        got = {}
+        for fused in (True, False):
+            out = ref_out.clone().requires_grad_(True)
+            pipe = SeekerPipeline(_Replay(out), num_queries=Qs, train_args=args, phase='train', device='cuda')
+            pipe.losses.fused = fused
+            mr = pipe.forward_kubric(data, sel_query_inds=sel)
+            res = pipe.step_losses(data, mr, progress)
+            res['total_seeker'].backward()
+            got[fused] = ({k: float(res[k]) for k in ('track', 'occl_mask', 'cont_mask', 'total_seeker')}, out.grad.clone())
+        for k, v in got[False][0].items():
+            assert abs(got[True][0][k] - v) <= 3e-6 + 2e-5 * abs(v), (k, progress, got[True][0][k], v)
+        scale = float(got[False][1].abs().max())
+        d = (got[True][1] - got[False][1]).abs()
+        assert scale > 0 and int((d > 3e-5 * scale).sum()) <= 4 and float(d.max()) <= 1.01 * scale, (progress, float(d.max()), scale)
+    # ... and it is not the BCE objective
+    args0 = argparse.Namespace(**{**vars(args), 'focal_loss': False})
+    out = ref_out.clone().requires_grad_(True)
+    pipe = SeekerPipeline(_Replay(out), num_queries=Qs, train_args=args0, phase='train', device='cuda'); pipe.losses.fused = True
+    res0 = pipe.step_losses(data, pipe.forward_kubric(data, sel_query_inds=sel), 0.5)
+    assert abs(float(res0['total_seeker']) - got[True][0]['total_seeker']) > 1e-3
+
+
+@pytest.mark.gpu
 def test_fused_mask_loss_edge_cases(cuda):
     """Frames without weight are left out (loss.py:176-181) and scale the loss by sqrt(selected fraction); ties at the top-k
     threshold; an empty target switches the Jaccard term off (loss.py:21); a negligible mean weight gives zero (loss.py:184)."""
