@@ -135,8 +135,10 @@ SIGNATURES = {
 ABI_VERSION = 10       # TCOW_ABI_VERSION of include/tcow_hip.h
 
 
-def _declare(L):
+def _declare(L, tolerant=False):
     for name, (res, args) in SIGNATURES.items():
+        if tolerant and not hasattr(L, name):      # (TCOW_LIB: an older build on purpose -- entry points it lacks simply cannot be called)
+            continue
         fn = getattr(L, name)          # AttributeError here = header/library mismatch: fail loudly
         fn.restype = res
         fn.argtypes = args
@@ -161,7 +163,7 @@ def lib(fmt='bf16'):
         if L.tcow_version() != ABI_VERSION and not (fmt == 'bf16' and os.environ.get('TCOW_LIB')):      # (TCOW_LIB: an older build on purpose, same-box A/B of whole libraries)
             # a stale build next to newer host code (or the reverse): signatures may differ -- refuse before the first call
             raise TcowError(f'{path} reports ABI version {L.tcow_version()}, this host code was written against {ABI_VERSION} (include/tcow_hip.h): rebuild with `make`')
-        _declare(L)
+        _declare(L, tolerant=(fmt == 'bf16' and bool(os.environ.get('TCOW_LIB'))))
         _libs[fmt] = L
     return L
 
