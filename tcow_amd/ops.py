@@ -82,6 +82,10 @@ def workspace(nbytes, device, tag='default'):
     key = (str(device), _stream(), tag, threading.get_ident())
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
+        if buf is None and len(_ws_cache) >= 48:         # short-lived host threads (DataParallel starts new ones per forward): forget the scratch of threads that are gone
+            alive = {t.ident for t in threading.enumerate()}
+            for k in [k for k in _ws_cache if k[3] not in alive]:
+                del _ws_cache[k]
         buf = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
     return buf
