@@ -445,6 +445,11 @@ def main():
         raise
     finally:
         errors.done = True
+        if errors.world > 1 and errors.rank == 0:
+            try:
+                os.rmdir(errors.dir)            # (empty after a clean run; a directory with reports stays for the post-mortem)
+            except OSError:
+                pass
 
 
 def run(args):
