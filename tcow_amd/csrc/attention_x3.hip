@@ -70,8 +70,9 @@ __device__ __forceinline__ XItem x_load(const float* __restrict__ src, long stri
     XItem it; it.a = *reinterpret_cast<const f32x4*>(p); it.b = *reinterpret_cast<const f32x4*>(p + 4);
     return it;
 }
-__device__ __forceinline__ void x_store(const XItem& it, char* hi_tile, char* lo_tile, int tid) {
-    const int r = tid >> 3, c = tid & 7;
+__device__ __forceinline__ void x_store_rc(const XItem& it, char* hi_tile, char* lo_tile, int r, int c);
+__device__ __forceinline__ void x_store(const XItem& it, char* hi_tile, char* lo_tile, int tid) { x_store_rc(it, hi_tile, lo_tile, tid >> 3, tid & 7); }
+__device__ __forceinline__ void x_store_rc(const XItem& it, char* hi_tile, char* lo_tile, int r, int c) {
     xu4 h, l;
     const float v[8] = {it.a[0], it.a[1], it.a[2], it.a[3], it.b[0], it.b[1], it.b[2], it.b[3]};
     xsplit8u(v, h, l);
@@ -93,6 +94,23 @@ __device__ __forceinline__ void x_stage(const float* __restrict__ a, long sa, co
             x_store(ia[t], smem + t * XTILE, smem + (CH + t) * XTILE, tid);
             x_store(ib[t], smem + (2 * CH + t) * XTILE, smem + (3 * CH + t) * XTILE, tid);
         }
+}
+
+// SOLO kernels (one-tile sequences, temporal attention): every WAVE owns its own (sequence, head) and stages the one tile of each source itself -- row (lane >> 3) + 8 pass,
+// columns 8 (lane & 7) .. + 7, four passes per tile -- into wave-private LDS; no workgroup barrier (a wave's LDS operations execute in order).
+__device__ __forceinline__ void x_stage_wave(const float* __restrict__ a, long sa, const float* __restrict__ b, long sb, int L, char* wsm, int lane) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {               // two rounds of 16 rows: 32 registers of loads in flight instead of 64 (the SOLO kernels hold their own fragments too)
+        XItem ia[2], ib[2];
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) { ia[ps] = x_load(a, sa, 16 * half + 8 * ps, L, lane); ib[ps] = x_load(b, sb, 16 * half + 8 * ps, L, lane); }
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            x_store_rc(ia[ps], wsm, wsm + XTILE, 16 * half + 8 * ps + (lane >> 3), lane & 7);
+            x_store_rc(ib[ps], wsm + 2 * XTILE, wsm + 3 * XTILE, 16 * half + 8 * ps + (lane >> 3), lane & 7);
+        }
+        asm volatile("" ::: "memory");                   // (keeps hipcc from issuing the second round's loads with the first)
+    }
 }
 
 // A/B fragment of a row-major tile for a contraction over d: lane (row, hi) gets d = 16 ks + 8 hi .. + 7
@@ -145,21 +163,24 @@ __device__ __forceinline__ void x_store_row(float* __restrict__ drow, int hi, co
 }
 
 // ------------------------------------------------------------------------------------------------ forward
-template <int CH>
+template <int CH, bool SOLO = false>
 __global__ __launch_bounds__(256, 2) void attn_x3_fwd(SeqDesc sd, int nt, const float* __restrict__ qkv, float* __restrict__ out, float* __restrict__ lse) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];           // [K hi][K lo][V hi][V lo], CH tiles each
+    extern __shared__ __attribute__((aligned(16))) char smem_[];          // [K hi][K lo][V hi][V lo], CH tiles each (SOLO: one such set per wave)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
-    const XWork w = x_work(sd.n_outer * sd.n_inner * sd.heads, (nt + 3) / 4);
+    XWork w = x_work(sd.n_outer * sd.n_inner * sd.heads, (nt + 3) / 4);
+    if (SOLO) { w.pair = blockIdx.x * 4 + wave; w.chunk = 0; w.valid = w.pair < sd.n_outer * sd.n_inner * sd.heads; }
     if (!w.valid) return;
+    char* smem = SOLO ? smem_ + wave * (4 * XTILE) : smem_;
     const int item = w.pair / sd.heads, head = w.pair - item * sd.heads;
     const long base = seq_base(sd, item);
     const long ld3 = 3L * sd.D, pse = sd.pos_stride * ld3;
     const float* qh = qkv + base * ld3 + head * ATT_HD;
-    const int qt = w.chunk * 4 + wave;
+    const int qt = SOLO ? 0 : w.chunk * 4 + wave;
     const bool active = qt < nt;
     const int q = 32 * qt + l31, qc = q < sd.L ? q : sd.L - 1;
+    if (SOLO) x_stage_wave(qh + sd.D, pse, qh + 2 * sd.D, pse, sd.L, smem, lane);      // (before the wave's own fragments are loaded: the staging registers are dead by then)
     xb8 qfh[4], qfl[4];
     xfrag_global(qh + (size_t)qc * pse, hi, qfh, qfl);
     f32x16 o0, o1;
@@ -172,9 +193,11 @@ __global__ __launch_bounds__(256, 2) void attn_x3_fwd(SeqDesc sd, int nt, const 
     const long klim_wg = (long)32 * (w.chunk * 4 + 3) + 31 + sd.diag;          // last key tile any wave of this workgroup needs
     const int kt_end_wg = klim_wg >= (long)sd.L - 1 ? nt : (int)(klim_wg / 32) + 1;
     for (int c0 = 0; c0 < kt_end_wg; c0 += CH) {
-        __syncthreads();                                                   // previous chunk fully consumed
-        x_stage<CH>(qh + sd.D, pse, qh + 2 * sd.D, pse, c0, kt_end_wg, sd.L, smem, tid);
-        __syncthreads();
+        if (!SOLO) {
+            __syncthreads();                                               // previous chunk fully consumed
+            x_stage<CH>(qh + sd.D, pse, qh + 2 * sd.D, pse, c0, kt_end_wg, sd.L, smem, tid);
+            __syncthreads();
+        }
         const int jend = (c0 + CH < kt_end) ? c0 + CH : kt_end;
         for (int j = c0; j < jend; ++j) {
             const char* kh = smem + (j - c0) * XTILE; const char* kl = kh + CH * XTILE;
@@ -234,23 +257,26 @@ __global__ __launch_bounds__(256, 2) void attn_x3_fwd(SeqDesc sd, int nt, const 
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dQ (+ delta)
-template <int CH>
+template <int CH, bool SOLO = false>
 __global__ __launch_bounds__(256, 2) void attn_x3_bwd_dq(SeqDesc sd, int nt, const float* __restrict__ qkv, const float* __restrict__ o, const float* __restrict__ dout,
                                                          const float* __restrict__ lse, float* __restrict__ delta, float* __restrict__ dqkv) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];           // [K hi][K lo][V hi][V lo]
+    extern __shared__ __attribute__((aligned(16))) char smem_[];          // [K hi][K lo][V hi][V lo] (SOLO: one set per wave)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
-    const XWork w = x_work(sd.n_outer * sd.n_inner * sd.heads, (nt + 3) / 4);
+    XWork w = x_work(sd.n_outer * sd.n_inner * sd.heads, (nt + 3) / 4);
+    if (SOLO) { w.pair = blockIdx.x * 4 + wave; w.chunk = 0; w.valid = w.pair < sd.n_outer * sd.n_inner * sd.heads; }
     if (!w.valid) return;
+    char* smem = SOLO ? smem_ + wave * (4 * XTILE) : smem_;
     const int item = w.pair / sd.heads, head = w.pair - item * sd.heads;
     const long base = seq_base(sd, item);
     const long ld3 = 3L * sd.D, pse = sd.pos_stride * ld3;
     const float* qh = qkv + base * ld3 + head * ATT_HD;
-    const int qt = w.chunk * 4 + wave;
+    const int qt = SOLO ? 0 : w.chunk * 4 + wave;
     const bool active = qt < nt;
     const int q = 32 * qt + l31, qc = q < sd.L ? q : sd.L - 1;
     const long row = base + (long)qc * sd.pos_stride;
+    if (SOLO) x_stage_wave(qh + sd.D, pse, qh + 2 * sd.D, pse, sd.L, smem, lane);
     xb8 qfh[4], qfl[4], dfh[4], dfl[4];
     xfrag_global(qh + (size_t)qc * pse, hi, qfh, qfl);
     // delta = rowsum(dO * O) of this lane's query in f32 (this half-wave's 32 channels + the other's): published for the dK / dV kernel, which runs after this one
@@ -279,9 +305,11 @@ __global__ __launch_bounds__(256, 2) void attn_x3_bwd_dq(SeqDesc sd, int nt, con
     const long klim_wg = (long)32 * (w.chunk * 4 + 3) + 31 + sd.diag;
     const int kt_end_wg = klim_wg >= (long)sd.L - 1 ? nt : (int)(klim_wg / 32) + 1;
     for (int c0 = 0; c0 < kt_end_wg; c0 += CH) {
-        __syncthreads();
-        x_stage<CH>(qh + sd.D, pse, qh + 2 * sd.D, pse, c0, kt_end_wg, sd.L, smem, tid);
-        __syncthreads();
+        if (!SOLO) {
+            __syncthreads();
+            x_stage<CH>(qh + sd.D, pse, qh + 2 * sd.D, pse, c0, kt_end_wg, sd.L, smem, tid);
+            __syncthreads();
+        }
         const int jend = (c0 + CH < kt_end) ? c0 + CH : kt_end;
         for (int j = c0; j < jend; ++j) {
             const char* kh = smem + (j - c0) * XTILE; const char* kl = kh + CH * XTILE;
@@ -322,24 +350,33 @@ __global__ __launch_bounds__(256, 2) void attn_x3_bwd_dq(SeqDesc sd, int nt, con
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
-template <int CH>
+template <int CH, bool SOLO = false>
 __global__ __launch_bounds__(256, 2) void attn_x3_bwd_dkv(SeqDesc sd, int nt, const float* __restrict__ qkv, const float* __restrict__ dout, const float* __restrict__ lse,
                                                           const float* __restrict__ delta, float* __restrict__ dqkv) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];           // [Q hi][Q lo][dO hi][dO lo], CH tiles each, + the chunk's (lse log2e, delta) table
-    float2* tab = reinterpret_cast<float2*>(smem + 4 * CH * XTILE);
+    extern __shared__ __attribute__((aligned(16))) char smem_[];          // [Q hi][Q lo][dO hi][dO lo], CH tiles each, + the chunk's (lse log2e, delta) table (SOLO: per wave)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
-    const XWork w = x_work(sd.n_outer * sd.n_inner * sd.heads, (nt + 3) / 4);
+    XWork w = x_work(sd.n_outer * sd.n_inner * sd.heads, (nt + 3) / 4);
+    if (SOLO) { w.pair = blockIdx.x * 4 + wave; w.chunk = 0; w.valid = w.pair < sd.n_outer * sd.n_inner * sd.heads; }
     if (!w.valid) return;
+    char* smem = SOLO ? smem_ + wave * (4 * XTILE + 256) : smem_;
+    float2* tab = reinterpret_cast<float2*>(smem + 4 * CH * XTILE);
     const int item = w.pair / sd.heads, head = w.pair - item * sd.heads;
     const long base = seq_base(sd, item);
     const long ld3 = 3L * sd.D, pse = sd.pos_stride * ld3, pso = sd.pos_stride * sd.D;
     const float* qh = qkv + base * ld3 + head * ATT_HD;
     const float* doh = dout + base * sd.D + head * ATT_HD;
-    const int jt = w.chunk * 4 + wave;
+    const int jt = SOLO ? 0 : w.chunk * 4 + wave;
     const bool active = jt < nt;
     const int key = 32 * jt + l31, kc = key < sd.L ? key : sd.L - 1;
+    if (SOLO) {
+        x_stage_wave(qh, pse, doh, pso, sd.L, smem, lane);
+        if (lane < 32) {
+            const long row = base + (long)(lane < sd.L ? lane : sd.L - 1) * sd.pos_stride;
+            tab[lane] = make_float2(lse[row * sd.heads + head] * xLog2e, delta[row * sd.heads + head]);
+        }
+    }
     xb8 kfh[4], kfl[4], vfh[4], vfl[4];
     xfrag_global(qh + (size_t)kc * pse + sd.D, hi, kfh, kfl);
     xfrag_global(qh + (size_t)kc * pse + 2 * sd.D, hi, vfh, vfl);
@@ -353,14 +390,16 @@ __global__ __launch_bounds__(256, 2) void attn_x3_bwd_dkv(SeqDesc sd, int nt, co
     const long qlo_wg = (long)32 * (w.chunk * 4) - sd.diag;
     const int c_start = qlo_wg > 0 ? ((int)(qlo_wg / 32) / CH) * CH : 0;
     for (int c0 = c_start; c0 < nt; c0 += CH) {
-        __syncthreads();
-        x_stage<CH>(qh, pse, doh, pso, c0, nt, sd.L, smem, tid);
-        if (tid < CH * 32) {
-            const int qi = 32 * c0 + tid;
-            const long row = base + (long)(qi < sd.L ? qi : sd.L - 1) * sd.pos_stride;
-            tab[tid] = make_float2(lse[row * sd.heads + head] * xLog2e, delta[row * sd.heads + head]);
+        if (!SOLO) {
+            __syncthreads();
+            x_stage<CH>(qh, pse, doh, pso, c0, nt, sd.L, smem, tid);
+            if (tid < CH * 32) {
+                const int qi = 32 * c0 + tid;
+                const long row = base + (long)(qi < sd.L ? qi : sd.L - 1) * sd.pos_stride;
+                tab[tid] = make_float2(lse[row * sd.heads + head] * xLog2e, delta[row * sd.heads + head]);
+            }
+            __syncthreads();
         }
-        __syncthreads();
         if (!active) continue;
         const int ib = c0 > i0 ? c0 : i0, ie = c0 + CH < nt ? c0 + CH : nt;
         for (int i = ib; i < ie; ++i) {
@@ -439,17 +478,35 @@ int x3_bwd_launch(hipStream_t st, const SeqDesc& d, int nt, int grid, const void
 
 }  // namespace
 
-// Every length.  One-tile sequences (temporal attention, T <= 32) run the same kernels with CH = 1 (16 KiB of LDS; one active wave per workgroup, all four
-// stage the tile): 84 / 302 us forward / backward at configs[1] against 127 / 407 us on attention_f32.hip's wave-private exact-f32 kernels.
+// Every length.  One-tile sequences (temporal attention, T <= 32) run the SOLO instantiations: a wave per (sequence, head) with wave-private LDS tiles, no barriers
+// (the same kernels with one tile per chunk and one active wave per workgroup measured 84 / 302 us forward / backward at configs[1], attention_f32.hip's wave-private
+// exact-f32 kernels 127 / 407 us).
 bool tcow_attn_x3_supported(const SeqDesc& d) { (void)d; return true; }
 
 int tcow_attn_x3_fwd(hipStream_t st, const SeqDesc& d, const void* qkv, void* out, float* lse) {
-    const int nt = cdiv(d.L, 32), grid = x_grid(d.n_outer * d.n_inner * d.heads, cdiv(nt, 4));
-    return nt == 1 ? x3_fwd_launch<1>(st, d, nt, grid, qkv, out, lse) : x3_fwd_launch<X3_CH>(st, d, nt, grid, qkv, out, lse);
+    const int nt = cdiv(d.L, 32), pairs = d.n_outer * d.n_inner * d.heads, grid = x_grid(pairs, cdiv(nt, 4));
+    if (nt == 1) {                       // one-tile sequences: a wave per (sequence, head), wave-private 16 KiB
+        constexpr int lds = 4 * 4 * XTILE;
+        tcow_ensure_lds((const void*)attn_x3_fwd<1, true>, lds);
+        hipLaunchKernelGGL((attn_x3_fwd<1, true>), dim3(cdiv(pairs, 4)), dim3(256), lds, st, d, nt, (const float*)qkv, (float*)out, lse);
+        TCOW_CHECK_LAUNCH();
+        return TCOW_OK;
+    }
+    return x3_fwd_launch<X3_CH>(st, d, nt, grid, qkv, out, lse);
 }
 
 // `delta` = rows * heads floats of workspace (the layout of lse)
 int tcow_attn_x3_bwd(hipStream_t st, const SeqDesc& d, const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv) {
-    const int nt = cdiv(d.L, 32), grid = x_grid(d.n_outer * d.n_inner * d.heads, cdiv(nt, 4));
-    return nt == 1 ? x3_bwd_launch<1>(st, d, nt, grid, qkv, out, dout, lse, delta, dqkv) : x3_bwd_launch<X3_CH>(st, d, nt, grid, qkv, out, dout, lse, delta, dqkv);
+    const int nt = cdiv(d.L, 32), pairs = d.n_outer * d.n_inner * d.heads, grid = x_grid(pairs, cdiv(nt, 4));
+    if (nt == 1) {
+        constexpr int lds = 4 * 4 * XTILE, lds_dkv = 4 * (4 * XTILE + 256);
+        tcow_ensure_lds((const void*)attn_x3_bwd_dq<1, true>, lds);
+        tcow_ensure_lds((const void*)attn_x3_bwd_dkv<1, true>, lds_dkv);
+        hipLaunchKernelGGL((attn_x3_bwd_dq<1, true>), dim3(cdiv(pairs, 4)), dim3(256), lds, st, d, nt, (const float*)qkv, (const float*)out, (const float*)dout, lse, delta, (float*)dqkv);
+        TCOW_CHECK_LAUNCH();
+        hipLaunchKernelGGL((attn_x3_bwd_dkv<1, true>), dim3(cdiv(pairs, 4)), dim3(256), lds_dkv, st, d, nt, (const float*)qkv, (const float*)dout, lse, (const float*)delta, (float*)dqkv);
+        TCOW_CHECK_LAUNCH();
+        return TCOW_OK;
+    }
+    return x3_bwd_launch<X3_CH>(st, d, nt, grid, qkv, out, dout, lse, delta, dqkv);
 }
