@@ -35,10 +35,10 @@ int tcow_gemm_nt_f32(hipStream_t stream, const tcow_gemm_args* a);
 int tcow_gemm_tn_bf16(hipStream_t stream, int M, int N, int K, const bf16_t* dY, long ldy, const bf16_t* X, long ldx, float* slab, int splits, int* nz_out,
                       float* bias_part, int* bias_parts_out);
 int tcow_gemm_tn_f32(hipStream_t stream, int M, int N, int K, const float* dY, long ldy, const float* X, long ldx, float* dW, long lddw, int accumulate,
-                     float* slab, int splits);
+                     float* slab, int splits, const float* bias_part, int bias_nparts, float* bias_out);
 int tcow_gemm_nt_x3(hipStream_t stream, const tcow_gemm_args* a);
 int tcow_gemm_tn_x3(hipStream_t stream, int M, int N, int K, const float* dY, long ldy, const float* X, long ldx, float* dW, long lddw, int accumulate,
-                    float* slab, int splits);
+                    float* slab, int splits, const float* bias_part, int bias_nparts, float* bias_out);
 int tcow_tn_group_max(void);
 bool tcow_tn_group_ok(int n, const tcow_tn_problem* pr);
 int tcow_tn_group_slices(int n, const tcow_tn_problem* pr);
@@ -55,6 +55,7 @@ bool tcow_fold_vec_ok(const float* slab, long slab_stride, long cols, float* out
 int tcow_launch_slab_reduce_group(hipStream_t stream, int n, const float* const* slab, int nz, const long* rows, const long* cols, float* const* out, const long* ldo,
                                   const int* accumulate, const float* const* bias_part, const int* bias_nparts, float* const* bias_out);
 int tcow_launch_colsum(hipStream_t stream, int dtype, const void* Y, long ldy, int M, int N, float* out, int accumulate, float* part, int max_parts);
+int tcow_launch_colsum_partials(hipStream_t stream, int dtype, const void* Y, long ldy, int M, int N, float* part, int max_parts, int* nparts);
 
 extern "C" {
 
@@ -155,14 +156,18 @@ int tcow_gemm_tn(void* stream, int dtype, int M, int N, int K, const void* dY, l
         rc = tcow_launch_slab_reduce((hipStream_t)stream, slab, nz, (long)N * K, N, K, dW, lddw, accumulate, fuse_bias ? part : nullptr, nparts, N, bias_grad);
         if (rc) return rc;
         if (fuse_bias) return TCOW_OK;
-    } else if (dtype == TCOW_F32) {
-        const int splits = tcow_tn_splits(M, N, K, 64);
-        rc = tcow_gemm_tn_f32((hipStream_t)stream, M, N, K, (const float*)dY, ldy, (const float*)X, ldx, dW, lddw, accumulate, slab, splits);
-        if (rc) return rc;
-    } else if (dtype == TCOW_F32X3) {
-        const int splits = tcow_tn_splits_x3(M, N, K);
-        rc = tcow_gemm_tn_x3((hipStream_t)stream, M, N, K, (const float*)dY, ldy, (const float*)X, ldx, dW, lddw, accumulate, slab, splits);
-        if (rc) return rc;
+    } else if (dtype == TCOW_F32 || dtype == TCOW_F32X3) {
+        // f32 storage: the bias gradient's column-sum partials first, their fold rides on the weight gradient's slab fold (one launch instead of two per Linear)
+        int nparts = 0;
+        if (bias_grad) {
+            rc = tcow_launch_colsum_partials((hipStream_t)stream, TCOW_F32, dY, ldy, M, N, part, kColsumParts < 64 ? kColsumParts : 64, &nparts);
+            if (rc) return rc;
+        }
+        if (dtype == TCOW_F32) rc = tcow_gemm_tn_f32((hipStream_t)stream, M, N, K, (const float*)dY, ldy, (const float*)X, ldx, dW, lddw, accumulate, slab, tcow_tn_splits(M, N, K, 64),
+                                                     bias_grad ? part : nullptr, nparts, bias_grad);
+        else rc = tcow_gemm_tn_x3((hipStream_t)stream, M, N, K, (const float*)dY, ldy, (const float*)X, ldx, dW, lddw, accumulate, slab, tcow_tn_splits_x3(M, N, K),
+                                  bias_grad ? part : nullptr, nparts, bias_grad);
+        return rc;
     } else {
         tcow_set_error("tcow_gemm_tn: unknown dtype %d", dtype);
         return TCOW_ERR_INVALID_ARG;

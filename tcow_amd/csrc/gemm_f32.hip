@@ -393,6 +393,20 @@ int tcow_launch_row_reduce3(hipStream_t stream, const float* part, int nrows, lo
     return TCOW_OK;
 }
 
+// the partial sums only: `part` [parts][N], returns the number of parts (the caller folds them -- with the weight-gradient slabs, in one launch)
+int tcow_launch_colsum_partials(hipStream_t stream, int dtype, const void* Y, long ldy, int M, int N, float* part, int max_parts, int* nparts) {
+    int parts = cdiv(M, 256); if (parts > max_parts) parts = max_parts; if (parts < 1) parts = 1;
+    const int rpb = cdiv(M, parts);
+    parts = cdiv(M, rpb);
+    if (dtype == TCOW_BF16)
+        hipLaunchKernelGGL(colsum_partial_kernel<bf16_t>, dim3(cdiv(N, 128), parts), dim3(256), 0, stream, (const bf16_t*)Y, ldy, M, N, rpb, part);
+    else
+        hipLaunchKernelGGL(colsum_partial_kernel<float>, dim3(cdiv(N, 128), parts), dim3(256), 0, stream, (const float*)Y, ldy, M, N, rpb, part);
+    TCOW_CHECK_LAUNCH();
+    *nparts = parts;
+    return TCOW_OK;
+}
+
 int tcow_launch_colsum(hipStream_t stream, int dtype, const void* Y, long ldy, int M, int N, float* out, int accumulate, float* part, int max_parts) {
     int parts = cdiv(M, 256); if (parts > max_parts) parts = max_parts; if (parts < 1) parts = 1;
     const int rpb = cdiv(M, parts);
@@ -406,7 +420,7 @@ int tcow_launch_colsum(hipStream_t stream, int dtype, const void* Y, long ldy, i
 }
 
 int tcow_gemm_tn_f32(hipStream_t stream, int M, int N, int K, const float* dY, long ldy, const float* X, long ldx, float* dW, long lddw,
-                     int accumulate, float* slab, int splits) {
+                     int accumulate, float* slab, int splits, const float* bias_part, int bias_nparts, float* bias_out) {
     F32Params p;
     p.M = N; p.N = K; p.K = M;                       // output [N,K], contraction over tokens
     p.A = dY; p.sai = 1; p.sak = ldy;
@@ -417,5 +431,5 @@ int tcow_gemm_tn_f32(hipStream_t stream, int M, int N, int K, const float* dY, l
     p.kps = kps; p.slab = slab;
     hipLaunchKernelGGL(gemm_f32_kernel, dim3(cdiv(K, FT), cdiv(N, FT), nz), dim3(256), 0, stream, p);
     TCOW_CHECK_LAUNCH();
-    return tcow_launch_slab_reduce(stream, slab, nz, (long)N * K, N, K, dW, lddw, accumulate, nullptr, 0, 0, nullptr);
+    return tcow_launch_slab_reduce(stream, slab, nz, (long)N * K, N, K, dW, lddw, accumulate, bias_part, bias_nparts, N, bias_out);
 }

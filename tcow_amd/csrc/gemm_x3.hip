@@ -327,7 +327,7 @@ int tcow_tn_splits_x3(int M, int N, int K) {
 }
 
 int tcow_gemm_tn_x3(hipStream_t stream, int M, int N, int K, const float* dY, long ldy, const float* X, long ldx, float* dW, long lddw,
-                    int accumulate, float* slab, int splits) {
+                    int accumulate, float* slab, int splits, const float* bias_part, int bias_nparts, float* bias_out) {
     F32Params p;
     p.M = N; p.N = K; p.K = M;                       // output [N,K], contraction over tokens
     p.A = dY; p.sai = 1; p.sak = ldy;
@@ -341,7 +341,7 @@ int tcow_gemm_tn_x3(hipStream_t stream, int M, int N, int K, const float* dY, lo
     if (vec) hipLaunchKernelGGL(gemm_x3_kernel<LD_RVEC>, grid, dim3(256), 0, stream, p);
     else hipLaunchKernelGGL(gemm_x3_kernel<LD_ANY>, grid, dim3(256), 0, stream, p);
     TCOW_CHECK_LAUNCH();
-    return tcow_launch_slab_reduce(stream, slab, nz, (long)N * K, N, K, dW, lddw, accumulate, nullptr, 0, 0, nullptr);
+    return tcow_launch_slab_reduce(stream, slab, nz, (long)N * K, N, K, dW, lddw, accumulate, bias_part, bias_nparts, N, bias_out);       // (bias partials of tcow_launch_colsum_partials ride on the fold)
 }
 
 // ---- tcow_sgemm_x3_batched: C = A B for up to 24 small f32 problems in one launch; every operand is addressed by (row stride, k stride),
